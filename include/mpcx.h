@@ -1,0 +1,98 @@
+/*
+ * mpcx.h -- C ABI of libmpcx.so, the MI355X (gfx950) batched constellation-MPC engine.
+ *
+ * The reference (rgovindjee/mpconstellation) has no FFI layer: its hot path is two Python
+ * classes.  Each entry point below names the reference interface it replaces (file:line into
+ * the reference repo); mpconstellation_amd/_ffi.py is the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - plain C, fp64 everywhere, row-major (numpy C-order) arrays, satellite index outermost;
+ *  - every function returns 0 on success or a negative MPCX_E_* code; mpcx_last_error() gives
+ *    the text; per-satellite outcomes come back in int32 status arrays (MPCX_ST_*);
+ *  - "_dev" variants take DEVICE pointers (HBM resident) and enqueue on `stream` (a hipStream_t
+ *    passed as void*, NULL = default stream) without synchronising; the others take HOST
+ *    pointers, stage through HBM and return when the results are in the caller's buffers;
+ *  - the library never keeps a caller pointer after a call returns (host variants) or after
+ *    the enqueued work has completed (device variants);
+ *  - there is no CPU fallback: without a HIP device mpcx_create fails with MPCX_E_NODEVICE.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_VERSION 100
+
+/* return codes */
+#define MPCX_OK 0
+#define MPCX_E_NODEVICE (-1)
+#define MPCX_E_BADARG (-2)
+#define MPCX_E_HIP (-3)
+#define MPCX_E_NOMEM (-4)
+
+/* per-satellite status */
+#define MPCX_ST_OK 0
+#define MPCX_ST_MASS 1        /* mass <= 0 in the dynamics (reference raises, simulator.py:135-136) */
+#define MPCX_ST_STEP 2        /* RK45 step size underflow (scipy: "Required step size is less than spacing") */
+#define MPCX_ST_FOH 3         /* FOH index outside the input table (reference: IndexError) */
+#define MPCX_ST_SINGULAR 4    /* state-transition matrix not invertible (np.linalg.inv raises) */
+#define MPCX_ST_MAXITER 5     /* solver hit max_iter without meeting tol */
+#define MPCX_ST_NUMERIC 6     /* solver: non-finite value or factorisation breakdown */
+#define MPCX_ST_ACCEPTABLE 7  /* solver stopped at the 'acceptable' level (ipopt acceptable_tol) */
+
+/* dynamics flags (reference include_drag / include_J2 keyword arguments) */
+#define MPCX_FLAG_DRAG 1
+#define MPCX_FLAG_J2 2
+
+/* normalised constants per satellite: reference constants.py:11-20 field order */
+enum { MPCX_C_MU = 0, MPCX_C_R_E, MPCX_C_J2, MPCX_C_G0, MPCX_C_ISP, MPCX_C_S, MPCX_C_R0,
+       MPCX_C_RHO, MPCX_NCONST };
+
+/* packed per-interval stage record written by the discretizer and read by the solver:
+ * [A 7x7 | B_kn 7x3 | B_kp 7x3 | Sigma 7 | xi 7], row-major blocks */
+#define MPCX_STAGE_DOUBLES 105
+
+typedef struct mpcx_ctx mpcx_ctx;
+
+int mpcx_version(void);
+/* one context per (device, host thread); calls on different contexts are thread-safe */
+int mpcx_create(int device, mpcx_ctx **out);
+void mpcx_destroy(mpcx_ctx *ctx);
+const char *mpcx_last_error(const mpcx_ctx *ctx); /* ctx may be NULL: last create error */
+int mpcx_synchronize(mpcx_ctx *ctx, void *stream);
+
+/*
+ * Replaces Discretizer.discretize (linearize_discretize.py:334-390), i.e. get_matrices (:8-82)
+ * for every interval of every satellite, including dPhi (:257-291), A_func (:119-183),
+ * B_func (:186-215), xi_func (:218-236), Sigma_func (:239-254), u_FOH (:294-315) and the
+ * RK45 integration the reference delegates to scipy (rtol 1e-3, atol 1e-6, max_step, automatic
+ * first step), with f = Simulator.satellite_dynamics (simulator.py:116-161).
+ *   xbar   [S][7][K]     reference trajectories         ubar [S][3][Ku]  reference thrust
+ *   tf     [S]           reference final times          consts [S][MPCX_NCONST]
+ *   A      [S][K-1][7][7]   Bp, Bn [S][K-1][7][3]   Sigma, xi [S][7][K-1]   (reference shapes,
+ *   reference return order A, B_kp, B_kn, Sigma, xi)     status [S]
+ */
+int mpcx_discretize_batch(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                          const double *ubar, const double *tf, const double *consts, int flags,
+                          double max_step, double *A, double *Bp, double *Bn, double *Sigma,
+                          double *xi, int32_t *status);
+int mpcx_discretize_batch_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                              const double *ubar, const double *tf, const double *consts,
+                              int flags, double max_step, double *A, double *Bp, double *Bn,
+                              double *Sigma, double *xi, int32_t *status, void *stream);
+/* same computation, output as packed stage records stage[S][K-1][MPCX_STAGE_DOUBLES] (the
+ * layout the solver consumes; A/B never take the reference's five-array form) */
+int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                               const double *ubar, const double *tf, const double *consts,
+                               int flags, double max_step, double *stage, int32_t *status,
+                               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

@@ -1,0 +1,8 @@
+"""mpconstellation_amd -- MI355X-native batched constellation MPC (hot path of
+rgovindjee/mpconstellation: linearise/discretise + per-satellite finite-horizon solve)."""
+from .constants import Constants
+from .satellite import Satellite
+from .satellite_scale import SatelliteScale
+from .linearize_discretize import Discretizer
+
+__all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer"]

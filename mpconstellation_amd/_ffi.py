@@ -1,0 +1,98 @@
+"""ctypes binding of libmpcx.so (include/mpcx.h).  No CPU fallback: if the HIP library or a
+gfx950 device is missing, every compute entry point raises."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmpcx.so")
+
+STATUS_TEXT = {
+    0: "ok", 1: "satellite mass <= 0", 2: "RK45 step size underflow",
+    3: "FOH index outside the input table", 4: "state-transition matrix singular",
+    5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
+}
+FLAG_DRAG, FLAG_J2 = 1, 2
+NCONST = 8
+STAGE_DOUBLES = 105
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+
+class MpcxError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+_SIGS = {
+    "mpcx_version": (C.c_int, []),
+    "mpcx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "mpcx_destroy": (None, [_vp]),
+    "mpcx_last_error": (C.c_char_p, [_vp]),
+    "mpcx_synchronize": (C.c_int, [_vp, _vp]),
+    "mpcx_discretize_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
+                                        C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "mpcx_discretize_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                            C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpcx_discretize_stages_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                             C.c_int, C.c_double, _vp, _vp, _vp]),
+}
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def load():
+    """dlopen libmpcx.so and declare signatures.  Raises MpcxError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise MpcxError(f"{LIB_PATH} is missing: run `python -m mpconstellation_amd.build` "
+                                "(hipcc, gfx950). There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def context(device=0):
+    """One mpcx context per (process, device)."""
+    lib = load()
+    with _lock:
+        if device not in _ctxs:
+            h = _vp()
+            rc = lib.mpcx_create(device, C.byref(h))
+            if rc != 0:
+                raise MpcxError(f"mpcx_create(device={device}) failed ({rc}): "
+                                f"{lib.mpcx_last_error(None).decode()}")
+            _ctxs[device] = h
+        return _ctxs[device]
+
+
+def check(rc, ctx, what):
+    if rc != 0:
+        raise MpcxError(f"{what} failed ({rc}): {load().mpcx_last_error(ctx).decode()}")
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)

@@ -1,0 +1,64 @@
+// api.hip -- context management of libmpcx.so (see include/mpcx.h).
+#include "mpcx_host.hpp"
+
+static char g_create_err[512] = "";
+
+extern "C" int mpcx_version(void) { return MPCX_VERSION; }
+
+extern "C" int mpcx_create(int device, mpcx_ctx **out)
+{
+    if (!out) return MPCX_E_BADARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        snprintf(g_create_err, sizeof g_create_err,
+                 "no HIP device available (%s); libmpcx has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return MPCX_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        snprintf(g_create_err, sizeof g_create_err, "device %d out of range [0,%d)", device, n);
+        return MPCX_E_BADARG;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        snprintf(g_create_err, sizeof g_create_err, "hipGetDeviceProperties failed");
+        return MPCX_E_HIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_create_err, sizeof g_create_err,
+                 "device %d is %s; libmpcx is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return MPCX_E_NODEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return MPCX_E_HIP;
+    mpcx_ctx *c = new mpcx_ctx();
+    c->device = device; c->err[0] = 0; c->ws = nullptr; c->ws_bytes = 0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        snprintf(g_create_err, sizeof g_create_err, "hipStreamCreate failed");
+        return MPCX_E_HIP;
+    }
+    *out = c;
+    return MPCX_OK;
+}
+
+extern "C" void mpcx_destroy(mpcx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *mpcx_last_error(const mpcx_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int mpcx_synchronize(mpcx_ctx *ctx, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    MPCX_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return MPCX_OK;
+}

@@ -1,0 +1,500 @@
+// discretize.hip -- batched linearise/discretise of the orbital dynamics on gfx950.
+//
+// Replaces Discretizer.discretize / get_matrices of the reference
+// (linearize_discretize.py:8-82, 257-291, 334-390) for S satellites x (K-1) intervals.
+//
+// Mapping (CDNA4, wave64): one 8-lane group per (satellite, interval), 8 groups per wave.
+// The 56-component ODE state [Phi (7x7) ; x (7)] is held column-wise: lane c < 7 owns column c
+// of Phi, lane 7 owns x.  Every column obeys the same linear ODE d(col)/dtau = A(x,u) col, so
+// the 8 lanes run the same instruction stream; the only cross-lane traffic per RHS evaluation
+// is the broadcast of (r, m) from lane 7 (4 x ds_bpermute pairs) and the 3-step xor butterfly
+// of the RMS error norm.  All groups of a wave take their own adaptive RK45 step sequence
+// (scipy's controller, reproduced decision for decision); the loop is wave-uniform and a
+// group that has reached its end point idles under predicate.  At every accepted node each
+// lane forms one of the 8 quadrature columns [B lam-, B lam+, Sigma, xi], solves
+// Phi(tau_i) g = column (6x6 LU with partial pivoting, Phi staged through LDS) and adds its
+// trapezoid slice, so no node is ever stored.
+#include "mpcx_device.hpp"
+#include "mpcx_host.hpp"
+
+namespace mpcx {
+
+constexpr int kRec = 112;              
+constexpr int kMaxRkIters = 200000;   // attempts per interval before giving up (status STEP)
+
+enum { LAYOUT_STAGE = 0, LAYOUT_REF = 1 };
+
+struct DiscArgs {
+    int S, K, Ku, flags;
+    double max_step;
+    const double *xbar, *ubar, *tf, *consts;
+    double *stage;                       // LAYOUT_STAGE
+    double *A, *Bp, *Bn, *Sigma, *xi;    // LAYOUT_REF
+    int32_t *status;
+};
+
+__device__ __forceinline__ double group_sum(double v)
+{
+    v += __shfl_xor(v, 1, 8);
+    v += __shfl_xor(v, 2, 8);
+    v += __shfl_xor(v, 4, 8);
+    return v;   // bitwise identical on the 8 lanes (each level adds the same two operands)
+}
+
+struct RhsCtx {
+    const double *us;
+    int Ku, flags, c;
+    double tf;
+    SatConst cst;
+};
+
+// One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.
+__device__ __forceinline__ void rhs_eval(const RhsCtx &p, const double (&ys)[7], double ts,
+                                         double (&out)[7], int &err)
+{
+    double u[3];
+    foh3(ts, p.us, p.Ku, u, err);
+    const double rx = __shfl(ys[0], 7, 8), ry = __shfl(ys[1], 7, 8), rz = __shfl(ys[2], 7, 8);
+    const double m = __shfl(ys[6], 7, 8);
+    double G[3][3], gm[3];
+    jacobian_blocks(rx, ry, rz, m, u, p.cst, p.flags, G, gm);
+    const double tf = p.tf;
+    // Phi column: (tf * Dxf) @ col
+    double op[7];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        op[i] = tf * ys[3 + i];
+        double acc = (tf * G[i][0]) * ys[0];
+        acc += (tf * G[i][1]) * ys[1];
+        acc += (tf * G[i][2]) * ys[2];
+        acc += (tf * gm[i]) * ys[6];
+        op[3 + i] = acc;
+    }
+    op[6] = 0.0;
+    // x column: tf * f(x, u)   (meaningful on lane 7 only)
+    const double xv[7] = {rx, ry, rz, ys[3], ys[4], ys[5], m};
+    double yd[7];
+    dynamics_unscaled(xv, u, p.cst, p.flags, yd);
+    const bool isx = (p.c == 7);
+    if (isx && m <= 0.0) err = MPCX_ST_MASS;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) out[i] = isx ? tf * yd[i] : op[i];
+}
+
+// Solve P z = b in place (6x6, partial pivoting); returns false on a zero pivot.
+__device__ __forceinline__ bool lu_solve6(double (&P)[6][6], double (&b)[6])
+{
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        int piv = p;
+        double best = fabs(P[p][p]);
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) {
+            const double v = fabs(P[i][p]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (best == 0.0) ok = false;
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) {
+            const bool sw = (piv == i);
+#pragma unroll
+            for (int j = p; j < 6; ++j) {
+                const double a = P[p][j], bb = P[i][j];
+                P[p][j] = sw ? bb : a;
+                P[i][j] = sw ? a : bb;
+            }
+            const double a = b[p], bb = b[i];
+            b[p] = sw ? bb : a;
+            b[i] = sw ? a : bb;
+        }
+        const double inv = 1.0 / P[p][p];
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) {
+            const double mlt = P[i][p] * inv;
+#pragma unroll
+            for (int j = p + 1; j < 6; ++j) P[i][j] -= mlt * P[p][j];
+            b[i] -= mlt * b[p];
+        }
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= P[i][j] * b[j];
+        b[i] = s / P[i][i];
+    }
+    return ok;
+}
+
+// Quadrature integrand column of this lane at an accepted node (linearize_discretize.py:60-75):
+// g = Phi(t)^-1 [B lam-, B lam+, Sigma, xi][:, c]
+__device__ __forceinline__ void node_integrand(const RhsCtx &p, double *rec, const double (&y)[7],
+                                               double t, double tau_k, double tau_kp1,
+                                               double (&g)[7], int &err)
+{
+    const int c = p.c;
+    double x[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = __shfl(y[i], 7, 8);
+    double u[3];
+    foh3(t, p.us, p.Ku, u, err);
+    const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);
+    const double lam_p = (t - tau_k) / (tau_kp1 - tau_k);
+    const double tf = p.tf, m = x[6];
+
+    // stage Phi through LDS so that every lane sees the whole matrix
+    if (c < 7) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rec[i * 7 + c] = y[i];
+    }
+    __syncthreads();
+    double P[6][6], q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) P[i][j] = rec[i * 7 + j];
+        q[i] = rec[i * 7 + 6];
+    }
+    __syncthreads();
+
+    // B column (B_func :186-215), Sigma (:239-254), xi (:218-236)
+    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const int j = (c < 3) ? c : c - 3;
+    const double uj = (j == 0) ? u[0] : (j == 1 ? u[1] : u[2]);
+    const double lam = (c < 3) ? lam_n : lam_p;
+    const double Bm = (tf * (1.0 / m)) * lam;
+    const double den = p.cst.g0 * p.cst.isp * un;
+    const double B6 = (un <= kEps) ? 0.0 : (tf * (-uj / den)) * lam;
+
+    double yd[7];
+    dynamics_unscaled(x, u, p.cst, p.flags, yd);        // Sigma = f(.; tf = 1)
+
+    double G[3][3], gm[3];
+    jacobian_blocks(x[0], x[1], x[2], m, u, p.cst, p.flags, G, gm);
+    double xi[7];
+    double bu6 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xi[i] = -(tf * x[3 + i]);
+        double ax = (tf * G[i][0]) * x[0];
+        ax += (tf * G[i][1]) * x[1];
+        ax += (tf * G[i][2]) * x[2];
+        ax += (tf * gm[i]) * x[6];
+        xi[3 + i] = -(ax + (tf * (1.0 / m)) * u[i]);
+        bu6 += (un <= kEps) ? 0.0 : (tf * (-u[i] / den)) * u[i];
+    }
+    xi[6] = -(0.0 + bu6);
+
+    double R[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double rb = 0.0;
+        if (i == 3 + 0) rb = (j == 0) ? Bm : 0.0;
+        if (i == 3 + 1) rb = (j == 1) ? Bm : 0.0;
+        if (i == 3 + 2) rb = (j == 2) ? Bm : 0.0;
+        if (i == 6) rb = B6;
+        R[i] = (c < 6) ? rb : (c == 6 ? yd[i] : xi[i]);
+    }
+    // Phi = [[P q],[0 1]]  =>  g6 = R6 ; P g' = R' - q R6
+    double b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = R[i] - q[i] * R[6];
+    if (!lu_solve6(P, b)) err = MPCX_ST_SINGULAR;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = b[i];
+    g[6] = R[6];
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a)
+{
+    __shared__ double lds[8 * kRec];
+    const int lane = threadIdx.x;
+    const int grp = lane >> 3, c = lane & 7;
+    double *rec = lds + grp * kRec;
+
+    const int Km1 = a.K - 1;
+    const long total = (long)a.S * Km1;
+    const long item0 = (long)blockIdx.x * 8;
+    const long item = item0 + grp;
+    const bool valid = item < total;
+    const long it = valid ? item : total - 1;      // tail groups shadow the last item, write nothing
+    const int s = (int)(it / Km1), k = (int)(it % Km1);
+
+    RhsCtx p;
+    p.us = a.ubar + (size_t)s * 3 * a.Ku;
+    p.Ku = a.Ku; p.flags = a.flags; p.c = c;
+    p.tf = a.tf[s];
+    p.cst.load(a.consts + (size_t)s * MPCX_NCONST);
+    const double *xs = a.xbar + (size_t)s * 7 * a.K;
+
+    // np.linspace(0, 1, K)[k], [k+1]
+    const double step = 1.0 / (double)Km1;
+    const double tau_k = (double)k * step + 0.0;
+    const double tau_kp1 = (k + 1 == Km1) ? 1.0 : (double)(k + 1) * step + 0.0;
+    const double t_bound = tau_kp1;
+    const double rtol = 1e-3, atol = 1e-6;
+    int err = 0;
+
+    double y[7], f[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) y[i] = (c < 7) ? ((i == c) ? 1.0 : 0.0) : xs[(size_t)i * a.K + k];
+    double t = tau_k;
+    rhs_eval(p, y, t, f, err);
+
+    // ---- scipy select_initial_step (common.py:68-134), direction +1, order 4 ----
+    double h_abs;
+    {
+        const double interval = fabs(t_bound - t);
+        double s0 = 0.0, s1 = 0.0, scale[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            scale[i] = atol + fabs(y[i]) * rtol;
+            const double a0 = y[i] / scale[i], a1 = f[i] / scale[i];
+            s0 += a0 * a0; s1 += a1 * a1;
+        }
+        const double inv_sqrt_n = 1.0 / sqrt(56.0);
+        const double d0 = sqrt(group_sum(s0)) * inv_sqrt_n, d1 = sqrt(group_sum(s1)) * inv_sqrt_n;
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, interval);
+        double y1[7], f1[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
+        rhs_eval(p, y1, t + h0, f1, err);
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { const double d = (f1[i] - f[i]) / scale[i]; s2 += d * d; }
+        const double d2 = sqrt(group_sum(s2)) * inv_sqrt_n / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        h_abs = fmin(fmin(100.0 * h0, h1), fmin(interval, a.max_step));
+        if (interval == 0.0) h_abs = 0.0;
+    }
+
+    // ---- quadrature state: trapezoid accumulators for this lane's column ----
+    double acc[7], gprev[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = 0.0;
+    node_integrand(p, rec, y, t, tau_k, tau_kp1, gprev, err);
+
+    // ---- adaptive RK45 (rk.py:110-168); retry-after-reject folded into the same loop ----
+    bool rejected = false;
+    for (int iter = 0;; ++iter) {
+        const bool active = (t != t_bound);
+        if (!__any(active)) break;
+        if (iter >= kMaxRkIters) {       // every wave drains: hard cap on attempts
+            if (active) err = MPCX_ST_STEP;
+            break;
+        }
+        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        if (!rejected) {
+            if (h_abs > a.max_step) h_abs = a.max_step;
+            else if (h_abs < min_step) h_abs = min_step;
+        }
+        bool fail = active && !(h_abs >= min_step);   // also catches a non-finite step
+        double h = h_abs;
+        double t_new = t + h;
+        if (t_new - t_bound > 0.0) t_new = t_bound;
+        h = t_new - t;
+        const double h_try = fabs(h);
+
+        double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
+        rhs_eval(p, yt, t + RK_C[1] * h, K1, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[2][0] + K1[i] * RK_A[2][1]) * h;
+        rhs_eval(p, yt, t + RK_C[2] * h, K2, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yt[i] = y[i] + (f[i] * RK_A[3][0] + K1[i] * RK_A[3][1] + K2[i] * RK_A[3][2]) * h;
+        rhs_eval(p, yt, t + RK_C[3] * h, K3, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yt[i] = y[i] + (f[i] * RK_A[4][0] + K1[i] * RK_A[4][1] + K2[i] * RK_A[4][2] +
+                            K3[i] * RK_A[4][3]) * h;
+        rhs_eval(p, yt, t + RK_C[4] * h, K4, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yt[i] = y[i] + (f[i] * RK_A[5][0] + K1[i] * RK_A[5][1] + K2[i] * RK_A[5][2] +
+                            K3[i] * RK_A[5][3] + K4[i] * RK_A[5][4]) * h;
+        rhs_eval(p, yt, t + RK_C[5] * h, K5, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yn[i] = y[i] + h * (f[i] * RK_B[0] + K1[i] * RK_B[1] + K2[i] * RK_B[2] +
+                                K3[i] * RK_B[3] + K4[i] * RK_B[4] + K5[i] * RK_B[5]);
+        rhs_eval(p, yn, t + h, K6, err);
+
+        double se = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const double e = f[i] * RK_E[0] + K1[i] * RK_E[1] + K2[i] * RK_E[2] + K3[i] * RK_E[3] +
+                             K4[i] * RK_E[4] + K5[i] * RK_E[5] + K6[i] * RK_E[6];
+            const double sc = atol + fmax(fabs(y[i]), fabs(yn[i])) * rtol;
+            const double q = e * h / sc;
+            se += q * q;
+        }
+        const double error_norm = sqrt(group_sum(se)) / sqrt(56.0);
+        bool accept = false;
+        if (error_norm < 1.0) {
+            double factor = (error_norm == 0.0) ? RK_MAX_FACTOR
+                                                : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(error_norm, -0.2));
+            if (rejected) factor = fmin(1.0, factor);
+            if (active && !fail) { h_abs = h_try * factor; accept = true; }
+        } else if (active && !fail) {
+            // NaN error norms land here as in scipy (comparison false) and shrink the step
+            h_abs = h_try * fmax(RK_MIN_FACTOR, RK_SAFETY * pow(error_norm, -0.2));
+            rejected = true;
+        }
+        if (fail) {            // scipy: TOO_SMALL_STEP -> solver fails; freeze this group
+            err = MPCX_ST_STEP;
+            t = t_bound;
+        }
+        if (accept) {
+            rejected = false;
+            const double t_old = t;
+            t = t_new;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { y[i] = yn[i]; f[i] = K6[i]; }
+            (void)t_old;
+        }
+        // node quadrature (wave-uniform call; only accepting groups commit)
+        if (__any(accept)) {
+            double g[7];
+            node_integrand(p, rec, y, t, tau_k, tau_kp1, g, err);
+            if (accept) {
+                const double d = h;          // ts[i+1] - ts[i]
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    acc[i] += d * (g[i] + gprev[i]) / 2.0;
+                    gprev[i] = g[i];
+                }
+            }
+        }
+    }
+
+    // ---- A_k = Phi(tau_k+1); B_k-, B_k+, Sigma_k, xi_k = A_k @ trapz (:43-44, :77-80) ----
+    if (c < 7) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rec[i * 7 + c] = y[i];
+    }
+    __syncthreads();
+    double out[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) sacc += rec[i * 7 + l] * acc[l];
+        out[i] = sacc;
+    }
+    // record = [A 49 | Bn 21 | Bp 21 | Sigma 7 | xi 7]
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int off;
+        if (c < 3) off = 49 + i * 3 + c;
+        else if (c < 6) off = 70 + i * 3 + (c - 3);
+        else if (c == 6) off = 91 + i;
+        else off = 98 + i;
+        rec[off] = out[i];
+    }
+    __syncthreads();
+
+    if (LAYOUT == LAYOUT_STAGE) {
+        const long base = item0 * MPCX_STAGE_DOUBLES;
+        const long lim = total * MPCX_STAGE_DOUBLES;
+        for (int e = lane; e < 8 * MPCX_STAGE_DOUBLES; e += 64) {
+            const int gi = e / MPCX_STAGE_DOUBLES, el = e - gi * MPCX_STAGE_DOUBLES;
+            if (base + e < lim) a.stage[base + e] = lds[gi * kRec + el];
+        }
+    } else {
+        for (int e = lane; e < 8 * 49; e += 64) {
+            const int gi = e / 49, el = e - gi * 49;
+            if (item0 + gi < total) a.A[item0 * 49 + e] = lds[gi * kRec + el];
+        }
+        for (int e = lane; e < 8 * 21; e += 64) {
+            const int gi = e / 21, el = e - gi * 21;
+            if (item0 + gi < total) {
+                a.Bn[item0 * 21 + e] = lds[gi * kRec + 49 + el];
+                a.Bp[item0 * 21 + e] = lds[gi * kRec + 70 + el];
+            }
+        }
+        if (valid && c < 7) {
+            const size_t o = (size_t)s * 7 * Km1 + (size_t)c * Km1 + k;
+            a.Sigma[o] = rec[91 + c];
+            a.xi[o] = rec[98 + c];
+        }
+    }
+
+    // per-satellite status: worst code over its intervals
+    int e8 = err;
+    e8 = max(e8, __shfl_xor(e8, 1, 8));
+    e8 = max(e8, __shfl_xor(e8, 2, 8));
+    e8 = max(e8, __shfl_xor(e8, 4, 8));
+    if (valid && c == 0 && e8 != 0) atomicMax(&a.status[s], e8);
+}
+
+}  // namespace mpcx
+
+using namespace mpcx;
+
+static int launch_discretize(mpcx_ctx *ctx, int layout, DiscArgs a, hipStream_t st)
+{
+    if (a.S < 1 || a.K < 2 || a.Ku < 2) return ctx_fail(ctx, MPCX_E_BADARG, "discretize: need S>=1, K>=2, Ku>=2");
+    if (!(a.max_step > 0.0)) return ctx_fail(ctx, MPCX_E_BADARG, "discretize: max_step must be > 0");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    MPCX_HIP(ctx, hipMemsetAsync(a.status, 0, sizeof(int32_t) * a.S, st));
+    const long total = (long)a.S * (a.K - 1);
+    const unsigned blocks = (unsigned)((total + 7) / 8);
+    if (layout == LAYOUT_STAGE) hipLaunchKernelGGL(discretize_kernel<LAYOUT_STAGE>, dim3(blocks), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(discretize_kernel<LAYOUT_REF>, dim3(blocks), dim3(64), 0, st, a);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_discretize_batch_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                                         const double *ubar, const double *tf, const double *consts,
+                                         int flags, double max_step, double *A, double *Bp,
+                                         double *Bn, double *Sigma, double *xi, int32_t *status,
+                                         void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    DiscArgs a{S, K, Ku, flags, max_step, xbar, ubar, tf, consts, nullptr, A, Bp, Bn, Sigma, xi, status};
+    return launch_discretize(ctx, LAYOUT_REF, a, (hipStream_t)stream);
+}
+
+extern "C" int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                                          const double *ubar, const double *tf, const double *consts,
+                                          int flags, double max_step, double *stage, int32_t *status,
+                                          void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    DiscArgs a{S, K, Ku, flags, max_step, xbar, ubar, tf, consts, stage, nullptr, nullptr, nullptr, nullptr, nullptr, status};
+    return launch_discretize(ctx, LAYOUT_STAGE, a, (hipStream_t)stream);
+}
+
+extern "C" int mpcx_discretize_batch(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
+                                     const double *ubar, const double *tf, const double *consts,
+                                     int flags, double max_step, double *A, double *Bp, double *Bn,
+                                     double *Sigma, double *xi, int32_t *status)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 2 || Ku < 2) return ctx_fail(ctx, MPCX_E_BADARG, "discretize: need S>=1, K>=2, Ku>=2");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)S * (K - 1);
+    DeviceArena ar(ctx);
+    double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * Ku);
+    double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST);
+    double *dA = ar.alloc<double>(n * 49), *dBp = ar.alloc<double>(n * 21), *dBn = ar.alloc<double>(n * 21);
+    double *dS = ar.alloc<double>(n * 7), *dX = ar.alloc<double>(n * 7);
+    int32_t *dst = ar.alloc<int32_t>(S);
+    if (ar.failed()) return ar.code();
+    int rc = mpcx_discretize_batch_dev(ctx, S, K, Ku, dx, du, dtf, dc, flags, max_step, dA, dBp, dBn,
+                                       dS, dX, dst, ctx->stream);
+    if (rc) return rc;
+    ar.download(A, dA, n * 49); ar.download(Bp, dBp, n * 21); ar.download(Bn, dBn, n * 21);
+    ar.download(Sigma, dS, n * 7); ar.download(xi, dX, n * 7); ar.download(status, dst, S);
+    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ar.failed() ? ar.code() : MPCX_OK;
+}

@@ -1,0 +1,102 @@
+"""HIP discretizer (through the C ABI) against the golden vectors of the reference and against
+the CPU oracle on seeded inputs.  fp64; tolerance 1e-10 relative to each array's magnitude
+(the only differences are fused multiply-adds, pow and summation order)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+KEYS = ("A", "Bp", "Bn", "Sigma", "xi")
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+class _Const:
+    def __init__(self, v):
+        self.v = np.asarray(v, dtype=np.float64)
+
+    def as_vector(self):
+        return self.v
+
+
+def satellite_dynamics(*a, **k):  # token accepted by Discretizer.discretize
+    raise RuntimeError("host dynamics are never called")
+
+
+DISC_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "disc_*.npz")))
+
+
+@pytest.mark.parametrize("fn", DISC_FILES, ids=[os.path.basename(f)[5:-4] for f in DISC_FILES])
+def test_discretize_vs_reference_golden(fn):
+    from mpconstellation_amd import Discretizer
+    d = np.load(fn)
+    disc = Discretizer(_Const(d["const"]), include_J2=("J2" in fn))
+    out = disc.discretize(satellite_dynamics, d["x"], d["u"], float(d["tf"]))
+    for k, o in zip(KEYS, out):
+        assert o.shape == d[k].shape
+        assert relerr(o, d[k]) < RTOL, k
+
+
+def test_constellation_batch_vs_golden_and_oracle(golden_dir):
+    from mpconstellation_amd import Discretizer
+    c64 = np.load(os.path.join(golden_dir, "constellation64.npz"))
+    idx = list(c64["idx"])
+    x = np.stack([c64[f"x_{i}"] for i in idx]); u = np.stack([c64[f"u_{i}"] for i in idx])
+    cs = np.stack([c64[f"const_{i}"] for i in idx])
+    disc = Discretizer(_Const(cs[0]))
+    A, Bp, Bn, Sig, xi, st = disc.discretize_batch(x, u, np.ones(len(idx)), cs)
+    assert (st == 0).all()
+    for n, i in enumerate(idx):
+        for k, o in zip(KEYS, (A[n], Bp[n], Bn[n], Sig[n], xi[n])):
+            assert relerr(o, c64[f"{k}_{i}"]) < RTOL, (i, k)
+
+
+def test_random_batch_vs_oracle():
+    """Seeded ragged-ish batch: different tf, thrust tables and constants per satellite; S*(K-1)
+    not a multiple of the 8 groups per wave."""
+    from mpconstellation_amd import Discretizer
+    rng = np.random.default_rng(99)
+    S, K = 5, 12
+    cst = np.array([39.47841760435743, 0.92, 1.08262668E-3, 46.5, 0.0873, 1e-12, 6.9e6, 3.7e-17])
+    tan = O.make_ctrl(O.CTRL_TANGENTIAL, (0.5, 0, 0))
+    xs, us, tfs, css = [], [], [], []
+    for s in range(S):
+        v = 2 * np.pi * (1 + 0.1 * rng.random())
+        y0 = np.array([1, 0, 0, 0, v * np.cos(0.3 * s), v * np.sin(0.3 * s), 1.0])
+        tf = rng.uniform(0.5, 1.5)
+        c = cst.copy(); c[3] *= rng.uniform(0.8, 1.2)
+        x, rc, _ = O.propagate(y0, tf, c, tan, K)
+        assert rc == 0
+        xs.append(x); us.append(rng.normal(size=(3, K)) * 0.5); tfs.append(tf); css.append(c)
+    us[2][:] = 0.0   # zero-thrust satellite: ||u|| <= eps branch
+    disc = Discretizer(_Const(cst), include_J2=True)
+    A, Bp, Bn, Sig, xi, st = disc.discretize_batch(np.stack(xs), np.stack(us), np.array(tfs), np.stack(css))
+    assert (st == 0).all()
+    for s in range(S):
+        o = O.discretize(xs[s], us[s], tfs[s], css[s], O.FLAG_J2)
+        assert o["status"] == 0
+        for k, g in zip(KEYS, (A[s], Bp[s], Bn[s], Sig[s], xi[s])):
+            assert relerr(g, o[k]) < RTOL, (s, k)
+
+
+def test_status_codes():
+    from mpconstellation_amd import Discretizer
+    cst = np.array([39.47841760435743, 0.92, 1.08262668E-3, 46.5, 0.0873, 1e-12, 6.9e6, 3.7e-17])
+    K = 4
+    x = np.tile(np.array([1, 0, 0, 0, 6.28, 0, 1.0])[:, None], (1, K))
+    xbad = x.copy(); xbad[6, 2] = -1.0       # non-positive mass on one node
+    u = np.zeros((3, K))
+    disc = Discretizer(_Const(cst))
+    *_, st = disc.discretize_batch(np.stack([x, xbad]), np.stack([u, u]), np.ones(2), np.stack([cst, cst]))
+    assert st[0] == 0 and st[1] == 1
+    with pytest.raises(Exception):
+        disc.discretize(satellite_dynamics, xbad, u, 1.0)
+    with pytest.raises(NotImplementedError):
+        disc.discretize(lambda *a: None, x, u, 1.0)
