@@ -20,6 +20,7 @@
 #ifndef MPCX_H
 #define MPCX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,6 +92,56 @@ int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double
                                const double *ubar, const double *tf, const double *consts,
                                int flags, double max_step, double *stage, int32_t *status,
                                void *stream);
+
+/* Options of the per-satellite solve: the keys of Optimizer.init_options (optimizer.py:178-188;
+ * u_lim[1] -> u_max, r_lim -> r_min/r_max; r_des is per satellite, eps_vt is unused by the reference
+ * because the exact tangential constraint :577 is active) and the ipopt-level controls. */
+typedef struct {
+    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr;
+    double tol, acceptable_tol;
+    int32_t max_iter, acceptable_iter, n_refine, reserved;
+} mpcx_solve_opts;
+
+void mpcx_default_solve_opts(mpcx_solve_opts *o);
+size_t mpcx_solve_workspace_bytes(int S, int K);
+size_t mpcx_mpc_step_workspace_bytes(int S, int K);
+
+/*
+ * Replaces Optimizer.get_constraint_terms (optimizer.py:80-170) + the NLP transcription and
+ * ipopt solve of Optimizer.solve_OPT (optimizer.py:254-613), one independent problem (own tf)
+ * per satellite, given already discretised dynamics.
+ *   host variant: A [S][K-1][7][7], Bp, Bn [S][K-1][7][3], Sigma, xi [S][7][K-1] in the reference's
+ *   shapes; device variant: packed stage records stage[S][K-1][MPCX_STAGE_DOUBLES].
+ *   xbar [S][7][K], ubar [S][3][K], tf [S], consts [S][MPCX_NCONST], r_des [S]
+ * Results replace get_solved_trajectory / get_solved_u / get_solved_nu / get_solved_tf
+ * (optimizer.py:192-217): X [S][7][K], U [S][3][K], NU [S][7][K], tf_out [S];
+ * status [S] (MPCX_ST_*), iters [S], kkt [S] = final scaled optimality error (ipopt's E_0).
+ */
+int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,
+                     const double *Sigma, const double *xi, const double *xbar, const double *ubar,
+                     const double *tf, const double *consts, const double *r_des,
+                     const mpcx_solve_opts *opts, double *X, double *U, double *NU, double *tf_out,
+                     int32_t *status, int32_t *iters, double *kkt);
+int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *stage, const double *xbar,
+                         const double *ubar, const double *tf, const double *consts,
+                         const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
+                         double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                         void *workspace, void *stream);
+
+/*
+ * One satellite-MPC-step = Optimizer.solve_OPT as the reference runs it (optimizer.py:243-251 calls
+ * discretize, then :254-603): discretize -> constraint terms -> solve, fused on the device; the
+ * stage records never take the reference's five-array form and never leave HBM.
+ */
+int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                        const double *tf, const double *consts, const double *r_des, int flags,
+                        double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
+                        double *tf_out, int32_t *status, int32_t *iters, double *kkt);
+int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                            const double *tf, const double *consts, const double *r_des, int flags,
+                            double max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                            double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                            void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -4,5 +4,6 @@ from .constants import Constants
 from .satellite import Satellite
 from .satellite_scale import SatelliteScale
 from .linearize_discretize import Discretizer
+from .optimizer import Optimizer, mpc_step_batch, solve_batch
 
-__all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer"]
+__all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer", "Optimizer", "mpc_step_batch", "solve_batch"]

@@ -31,6 +31,15 @@ _lib = None
 _lock = threading.Lock()
 _ctxs = {}
 
+class SolveOpts(C.Structure):
+    """mpcx_solve_opts (include/mpcx.h)"""
+    _fields_ = [(n, C.c_double) for n in ("min_mass", "u_max", "r_min", "r_max", "eps_r", "eps_vr", "eps_vn",
+                                          "tf_max", "w_nu", "w_tr", "tol", "acceptable_tol")] + \
+               [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "n_refine", "reserved")]
+
+
+_po = C.POINTER(SolveOpts)
+
 _SIGS = {
     "mpcx_version": (C.c_int, []),
     "mpcx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -43,6 +52,15 @@ _SIGS = {
                                             C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpcx_discretize_stages_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                              C.c_int, C.c_double, _vp, _vp, _vp]),
+    "mpcx_default_solve_opts": (None, [_po]),
+    "mpcx_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mpcx_mpc_step_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mpcx_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int] + [_dp] * 10 + [_po, _dp, _dp, _dp, _dp, _ip, _ip, _dp]),
+    "mpcx_solve_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 6 + [_po] + [_vp] * 7 + [_vp, _vp]),
+    "mpcx_mpc_step_batch": (C.c_int, [_vp, C.c_int, C.c_int] + [_dp] * 5 + [C.c_int, C.c_double, _po, _dp, _dp, _dp, _dp,
+                                                                         _ip, _ip, _dp]),
+    "mpcx_mpc_step_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double, _po] + [_vp] * 7
+                                + [_vp, _vp]),
 }
 
 
@@ -96,3 +114,20 @@ def dptr(a):
 
 def iptr(a):
     return a.ctypes.data_as(_ip)
+
+
+# reference option keys (optimizer.py:178-188) -> mpcx_solve_opts
+def make_solve_opts(options=None, **solver):
+    """options: dict with the reference's keys (min_mass, u_lim, r_lim, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr;
+    r_des is passed per satellite); solver: tol, acceptable_tol, max_iter, acceptable_iter, n_refine."""
+    o = SolveOpts()
+    load().mpcx_default_solve_opts(C.byref(o))
+    options = options or {}
+    if "min_mass" in options: o.min_mass = options["min_mass"]
+    if "u_lim" in options: o.u_max = options["u_lim"][1]
+    if "r_lim" in options: o.r_min, o.r_max = options["r_lim"][0], options["r_lim"][1]
+    for k in ("eps_r", "eps_vr", "eps_vn", "tf_max", "w_nu", "w_tr"):
+        if k in options: setattr(o, k, options[k])
+    for k, v in solver.items():
+        setattr(o, k, v)
+    return o

@@ -1,0 +1,1493 @@
+// solve.hip -- batched per-satellite solve of the SCP subproblem on gfx950.
+//
+// Replaces Optimizer.get_constraint_terms + Optimizer.solve_OPT (reference optimizer.py:80-170,
+// 219-613: the NLP that pyomo transcribes and ipopt solves) for S satellites at once.
+//
+// One wavefront (64 lanes) per satellite runs the whole primal-dual interior-point iteration:
+//  * stage-parallel phases (KKT residuals, barrier Hessian blocks, slack/multiplier updates, step
+//    length, line-search trials) map one lane to one temporal node;
+//  * the structure-exploiting linear solve is a Riccati recursion in the shifted state
+//    y_k = x_k - Bp_{k-1} u_k (absorbs the first-order hold), 7x7 / 7x3 / 3x3 blocks staged in LDS
+//    with one lane per matrix element; the virtual control nu_k is eliminated per stage by a 7x7
+//    Cholesky; the free final time, the tangential-velocity equality and the five stiff rank-1
+//    terminal barrier terms form a 7x7 border solved by LU with partial pivoting; eight
+//    linear-term sweeps (1 right-hand side + 7 border columns) run side by side in the 8 lane
+//    groups of the wave; one step of iterative refinement on the reduced KKT system.
+// Per-satellite state lives in a global-memory workspace (HBM/L2 resident, ~4.8 KB per node); no MFMA.
+#include "mpcx_device.hpp"
+#include "mpcx_host.hpp"
+
+namespace mpcx {
+
+// ---- workspace layout (doubles) -------------------------------------------------------
+// iterate / direction record per node
+enum { I_X = 0, I_U = 7, I_NU = 10, I_T = 17, I_LAM = 24, I_STP = 31, I_ZTP = 38, I_STN = 45, I_ZTN = 52,
+       I_SU = 59, I_ZU = 60, I_SRMAX = 61, I_ZRMAX = 62, I_SRMIN = 63, I_ZRMIN = 64, IT_N = 66 };
+// global part of iterate / direction
+enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16, G_TF = 18, G_LVT = 19, GL_N = 24 };
+// Newton blocks per node
+enum { N_WX = 0, N_WU = 49, N_D = 58, N_AA = 65, N_BB = 72, N_GT = 79, N_RHO = 86, N_GX = 93, N_GU = 100,
+       N_E = 103, NB_N = 112 };
+// factorisation per node
+enum { F_P = 0, F_L = 49, F_WL = 98, F_PT = 147, F_QI = 196, F_QUY = 205, F_BH = 226, FAC_N = 248 };
+// channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
+enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, CH_N = 104 };
+constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
+constexpr int NBD = 7;        // border unknowns
+constexpr int NTERM = 5;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 1e10, kGammaNbhd = 1e-3, kTermCap = 1e4;
+
+struct SolveOpts {
+    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
+    int max_iter, acc_iter, n_refine, pad;
+};
+
+struct SolveArgs {
+    int S, K;
+    const double *stage, *xbar, *ubar, *tfbar, *consts, *r_des;
+    SolveOpts o;
+    double *X, *U, *NU, *tf_out, *kkt;
+    int32_t *status, *iters;
+    double *ws;
+    size_t ws_stride;
+};
+
+__host__ __device__ inline size_t ws_doubles(int K)
+{
+    return (size_t)K * (2 * IT_N + NB_N + FAC_N + CH_N) + 2 * GL_N + 3 * (size_t)K + 64;
+}
+
+// ---- per-satellite constant data kept in LDS --------------------------------------------
+struct SatData {
+    double aT[6][7], bT[6];
+    double b_u, b_rmax, b_rmin, b_rfmax, b_tf[2], vt_des, w_tr, w_nu, tfbar;
+    // Newton-step globals
+    double WxK[49];          // terminal Hessian used inside the recursion (soft + capped + AL)
+    double WxKsoft[49], gxKsoft[7];
+    double ta[NTERM][7], tw[NTERM], tgh[NTERM], twin[NTERM];
+    double avt[7], Hv[36], cv, gam, Wtf, gtf;
+    double Mb[NBD][NBD];     // LU of the border matrix
+    int piv[NBD];
+    double siglam[NCH], xK[NCH][7];
+    double sol[NBD];
+    double red[8];
+    int flag;
+};
+
+__device__ __forceinline__ double relax(double b) { return b + kBoundRelax * fmax(1.0, fabs(b)); }
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// c~ = |v|^2 - (r.v)^2/|r|^2 - vt_des^2 (same zero set as the quartic of optimizer.py:492-517)
+__device__ void vt_reduced(const double *x, double vt_des, double &c, double *g6, double *H36)
+{
+    const double *r = x, *v = x + 3;
+    const double q = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    const double rv = r[0] * v[0] + r[1] * v[1] + r[2] * v[2];
+    c = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - rv * rv / q - vt_des * vt_des;
+    if (!g6) return;
+    for (int i = 0; i < 3; ++i) {
+        g6[i] = -2.0 * rv * v[i] / q + 2.0 * rv * rv * r[i] / (q * q);
+        g6[3 + i] = 2.0 * v[i] - 2.0 * rv * r[i] / q;
+    }
+    if (!H36) return;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            const double Hvv = 2.0 * I - 2.0 * r[i] * r[j] / q;
+            const double Hrr = -2.0 * v[i] * v[j] / q + 4.0 * rv * (v[i] * r[j] + r[i] * v[j]) / (q * q) +
+                               2.0 * rv * rv * I / (q * q) - 8.0 * rv * rv * r[i] * r[j] / (q * q * q);
+            const double Hrv = -2.0 * v[i] * r[j] / q - 2.0 * rv * I / q + 4.0 * rv * r[i] * r[j] / (q * q);
+            H36[i * 6 + j] = Hrr;
+            H36[(3 + i) * 6 + 3 + j] = Hvv;
+            H36[i * 6 + 3 + j] = Hrv;
+            H36[(3 + j) * 6 + i] = Hrv;
+        }
+}
+
+// Optimizer.get_constraint_terms (optimizer.py:80-170) for the terminal node, incl. the
+// operator-precedence form of Dv_h_hat (:122); builds the six terminal linear inequalities.
+__device__ void build_terminal(const double *xK, double mu_grav, double r_des, const SolveOpts &o, SatData &sd)
+{
+    double r[3] = {xK[0], xK[1], xK[2]}, v[3] = {xK[3], xK[4], xK[5]}, h[3], rh[3], hh[3];
+    const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    h[0] = r[1] * v[2] - r[2] * v[1]; h[1] = r[2] * v[0] - r[0] * v[2]; h[2] = r[0] * v[1] - r[1] * v[0];
+    const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    for (int i = 0; i < 3; ++i) { rh[i] = r[i] / rn; hh[i] = h[i] / hn; }
+    const double ihn = 1.0 / hn, ihn3 = 1.0 / (hn * hn * hn), irn = 1.0 / rn, irn3 = 1.0 / (rn * rn * rn);
+    double Ph[9], hh3[9], nSv[9], Sr[9], Dr_h[9], Dv_h[9], Dr_r[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            hh3[i * 3 + j] = ihn3 * (h[i] * h[j]);
+            Ph[i * 3 + j] = (i == j ? ihn : 0.0) - hh3[i * 3 + j];
+            Dr_r[i * 3 + j] = (i == j ? irn : 0.0) - irn3 * (r[i] * r[j]);
+        }
+    // -skew(v), skew(r)
+    nSv[0] = 0; nSv[1] = v[2]; nSv[2] = -v[1]; nSv[3] = -v[2]; nSv[4] = 0; nSv[5] = v[0]; nSv[6] = v[1]; nSv[7] = -v[0]; nSv[8] = 0;
+    Sr[0] = 0; Sr[1] = -r[2]; Sr[2] = r[1]; Sr[3] = r[2]; Sr[4] = 0; Sr[5] = -r[0]; Sr[6] = -r[1]; Sr[7] = r[0]; Sr[8] = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0, b = 0.0;
+            for (int l = 0; l < 3; ++l) { a += Ph[i * 3 + l] * nSv[l * 3 + j]; b += hh3[i * 3 + l] * Sr[l * 3 + j]; }
+            Dr_h[i * 3 + j] = a;
+            Dv_h[i * 3 + j] = (i == j ? ihn : 0.0) - b;
+        }
+    double DrVr[3], DrVn[3], DvVn[3];
+    for (int j = 0; j < 3; ++j) {
+        DrVr[j] = v[0] * Dr_r[j] + v[1] * Dr_r[3 + j] + v[2] * Dr_r[6 + j];
+        DrVn[j] = v[0] * Dr_h[j] + v[1] * Dr_h[3 + j] + v[2] * Dr_h[6 + j];
+        DvVn[j] = hh[j] + (v[0] * Dv_h[j] + v[1] * Dv_h[3 + j] + v[2] * Dv_h[6 + j]);
+    }
+    const double Vr = v[0] * rh[0] + v[1] * rh[1] + v[2] * rh[2];
+    const double Vn = v[0] * hh[0] + v[1] * hh[1] + v[2] * hh[2];
+    double gR[6] = {DrVr[0], DrVr[1], DrVr[2], rh[0], rh[1], rh[2]};
+    double gN[6] = {DrVn[0], DrVn[1], DrVn[2], DvVn[0], DvVn[1], DvVn[2]};
+    double gRbar = 0.0, gNbar = 0.0;
+    for (int i = 0; i < 6; ++i) { gRbar += gR[i] * xK[i]; gNbar += gN[i] * xK[i]; }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 7; ++j) sd.aT[i][j] = 0.0;
+    for (int j = 0; j < 3; ++j) sd.aT[0][j] = -rh[j];
+    sd.bT[0] = relax(-(r_des - o.eps_r));
+    for (int j = 0; j < 6; ++j) { sd.aT[1][j] = gR[j]; sd.aT[2][j] = -gR[j]; sd.aT[3][j] = gN[j]; sd.aT[4][j] = -gN[j]; }
+    const double c0r = Vr - gRbar, c0n = Vn - gNbar;
+    sd.bT[1] = relax(o.eps_vr - c0r); sd.bT[2] = relax(o.eps_vr + c0r);
+    sd.bT[3] = relax(o.eps_vn - c0n); sd.bT[4] = relax(o.eps_vn + c0n);
+    sd.aT[5][6] = -1.0; sd.bT[5] = relax(-o.min_mass);
+    sd.b_u = relax(o.u_max * o.u_max);
+    sd.b_rmax = relax(o.r_max * o.r_max);
+    sd.b_rmin = relax(-o.r_min);
+    sd.b_rfmax = relax((r_des + o.eps_r) * (r_des + o.eps_r));
+    sd.b_tf[0] = relax(0.0); sd.b_tf[1] = relax(o.tf_max);
+    sd.vt_des = sqrt(mu_grav / r_des);
+    sd.w_tr = o.w_tr; sd.w_nu = o.w_nu;
+}
+
+// ---- view of one satellite's problem + workspace -------------------------------------------
+struct Sat {
+    int K;
+    const double *stage, *xbar, *ubar;   // stage (K-1,105); xbar (7,K); ubar (3,K)
+    double *it, *itg, *dr, *drg, *nb, *fac, *ch, *rbh;   // workspace pieces
+    __device__ const double *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
+    __device__ const double *Bn(int k) const { return A(k) + 49; }
+    __device__ const double *Bp(int k) const { return A(k) + 70; }
+    __device__ const double *Sig(int k) const { return A(k) + 91; }
+    __device__ const double *xi(int k) const { return A(k) + 98; }
+};
+
+// Trial point (iterate + a * direction) of one node, everything a residual evaluation needs.
+struct NodeVals {
+    double x[7], u[3], nu[7], t[7], lam[7];
+    double stp[7], ztp[7], stn[7], ztn[7];
+    double su, zu, srmax, zrmax, srmin, zrmin;
+};
+
+__device__ __forceinline__ void load_node(const Sat &s, int k, double a, NodeVals &n)
+{
+    const double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+    const bool z = (a == 0.0);
+#define LD(off) (z ? p[off] : p[off] + a * d[off])
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        n.x[i] = LD(I_X + i); n.nu[i] = LD(I_NU + i); n.t[i] = LD(I_T + i); n.lam[i] = LD(I_LAM + i);
+        n.stp[i] = LD(I_STP + i); n.ztp[i] = LD(I_ZTP + i); n.stn[i] = LD(I_STN + i); n.ztn[i] = LD(I_ZTN + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) n.u[i] = LD(I_U + i);
+    n.su = LD(I_SU); n.zu = LD(I_ZU); n.srmax = LD(I_SRMAX); n.zrmax = LD(I_ZRMAX);
+    n.srmin = LD(I_SRMIN); n.zrmin = LD(I_ZRMIN);
+#undef LD
+}
+
+struct ResAcc {   // accumulators of one residual evaluation
+    double dual_max, prim_max, comp_max, sq, zsum, lsum, prod_min, prod_sum;
+};
+
+// Perturbed KKT residual F_mu at (iterate + a*direction): ipopt's scaled error pieces and the
+// 2-norm used by the line search.  Lane k handles node k.  Results are wave-uniform.
+__device__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
+{
+    const int K = s.K;
+    double dual = 0.0, prim = 0.0, comp = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, psum = 0.0;
+    double gtf_part = 0.0;
+    const double tf = s.itg[G_TF] + a * s.drg[G_TF];
+    const double lvt = s.itg[G_LVT] + a * s.drg[G_LVT];
+#define ACC_D(v) { const double q_ = (v); dual = fmax(dual, fabs(q_)); sq += q_ * q_; }
+#define ACC_P(v) { const double q_ = (v); prim = fmax(prim, fabs(q_)); sq += q_ * q_; }
+#define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; comp = fmax(comp, fabs(q_)); sq += q_ * q_; \
+                        zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); psum += s_ * z_; }
+    for (int k = lane; k < K; k += 64) {
+        NodeVals n;
+        load_node(s, k, a, n);
+        double gx[7], gu[3];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * sd.w_tr * (n.x[i] - s.xbar[(size_t)i * K + k]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * sd.w_tr * (n.u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * n.u[i] * n.zu;
+        // previous-row multipliers: + lam_{k-1} on x_k, - Bp_{k-1}^T lam_{k-1} on u_k
+        if (k >= 1) {
+            const double *pl = s.it + (size_t)(k - 1) * IT_N + I_LAM, *dl = s.dr + (size_t)(k - 1) * IT_N + I_LAM;
+            const double *Bp = s.Bp(k - 1);
+            double lm[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { lm[i] = pl[i] + a * dl[i]; gx[i] += lm[i]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += Bp[i * 3 + j] * lm[i];
+                gu[j] -= acc;
+            }
+        }
+        if (k <= K - 2) {
+            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
+            const double *pn = s.it + (size_t)(k + 1) * IT_N, *dn = s.dr + (size_t)(k + 1) * IT_N;
+            double un[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) un[j] = pn[I_U + j] + a * dn[I_U + j];
+            double sl = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                // dynamics residual row i (optimizer.py:327-342)
+                double acc = Sg[i] * tf + xi[i] + n.nu[i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += A[i * 7 + j] * n.x[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += Bn[i * 3 + j] * n.u[j] + Bp[i * 3 + j] * un[j];
+                const double xn = pn[I_X + i] + a * dn[I_X + i];
+                ACC_P(xn - acc);
+                sl += Sg[i] * n.lam[i];
+                lsum += fabs(n.lam[i]);
+                // nu / t stationarity
+                ACC_D(n.ztp[i] - n.ztn[i] - n.lam[i]);
+                ACC_D(sd.w_nu - n.ztp[i] - n.ztn[i]);
+                ACC_P(n.nu[i] - n.t[i] + n.stp[i]);
+                ACC_P(-n.nu[i] - n.t[i] + n.stn[i]);
+                ACC_C(n.stp[i], n.ztp[i]);
+                ACC_C(n.stn[i], n.ztn[i]);
+            }
+            gtf_part -= sl;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += A[i * 7 + j] * n.lam[i];
+                gx[j] -= acc;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += Bn[i * 3 + j] * n.lam[i];
+                gu[j] -= acc;
+            }
+        }
+        // thrust ball, every node
+        ACC_P(n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u + n.su);
+        ACC_C(n.su, n.zu);
+        if (k >= 1) {
+            const double r2 = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2];
+            ACC_P(r2 - sd.b_rmax + n.srmax);
+            ACC_C(n.srmax, n.zrmax);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * n.x[i] * n.zrmax;
+            if (k <= K - 2) {
+                const double *rb = s.rbh + (size_t)k * 3;
+                ACC_P(-(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin + n.srmin);
+                ACC_C(n.srmin, n.zrmin);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gx[i] -= rb[i] * n.zrmin;
+            }
+        }
+        if (k == K - 1) {
+            // terminal inequalities, final-radius ball, vt equality
+            double cv, g6[6];
+            vt_reduced(n.x, sd.vt_des, cv, g6, nullptr);
+            ACC_P(cv);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
+            lsum += fabs(lvt);
+            for (int j = 0; j < 6; ++j) {
+                const double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
+                const double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
+                double gj = -sd.bT[j];
+                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * n.x[i]; gx[i] += sd.aT[j][i] * zj; }
+                ACC_P(gj + sj);
+                ACC_C(sj, zj);
+            }
+            const double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
+            ACC_P(n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax + srf);
+            ACC_C(srf, zrf);
+            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * n.x[i] * zrf;
+        }
+        if (k >= 1) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ACC_D(gx[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ACC_D(gu[i]);
+    }
+    // tf stationarity and range constraints (lane 0 adds them after the reduction of gtf_part)
+    double gtf = wave_sum(gtf_part);
+    if (lane == 0) {
+        const double s0 = s.itg[G_STF] + a * s.drg[G_STF], s1 = s.itg[G_STF + 1] + a * s.drg[G_STF + 1];
+        const double z0 = s.itg[G_ZTF] + a * s.drg[G_ZTF], z1 = s.itg[G_ZTF + 1] + a * s.drg[G_ZTF + 1];
+        gtf += 1.0 + 2.0 * sd.w_tr * (tf - sd.tfbar) - z0 + z1;
+        ACC_D(gtf);
+        ACC_P(-tf - sd.b_tf[0] + s0);
+        ACC_P(tf - sd.b_tf[1] + s1);
+        ACC_C(s0, z0);
+        ACC_C(s1, z1);
+    }
+#undef ACC_D
+#undef ACC_P
+#undef ACC_C
+    out.dual_max = wave_max(dual); out.prim_max = wave_max(prim); out.comp_max = wave_max(comp);
+    out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
+    out.prod_min = wave_min(pmin); out.prod_sum = wave_sum(psum);
+}
+
+__device__ __forceinline__ int n_ineq(int K) { return K + (K - 1) + (K - 2) + 6 + 1 + 14 * (K - 1) + 2; }
+
+__device__ double scaled_error(const ResAcc &r, int K)
+{
+    const double smax = 100.0;
+    const int nz = n_ineq(K), nl = 7 * (K - 1) + 1;
+    const double sdl = fmax(smax, (r.zsum + r.lsum) / (double)(nz + nl)) / smax;
+    const double sc = fmax(smax, r.zsum / (double)nz) / smax;
+    return fmax(fmax(r.dual_max / sdl, r.prim_max), r.comp_max / sc);
+}
+
+// ---- Newton blocks (stage-parallel) ------------------------------------------------------------
+__device__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta_w, int lane)
+{
+    const int K = s.K;
+    double wtf_part = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        NodeVals n;
+        load_node(s, k, 0.0, n);
+        double *nb = s.nb + (size_t)k * NB_N;
+        double Wx[49];
+#pragma unroll
+        for (int i = 0; i < 49; ++i) Wx[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) Wx[i * 8] = 2.0 * sd.w_tr + delta_w;
+        double gx[7], gu[3];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * sd.w_tr * (n.x[i] - s.xbar[(size_t)i * K + k]);
+        // thrust ball
+        {
+            const double g = n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u;
+            const double sig = n.zu / n.su, zh = mu / n.su + sig * (g + n.su);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gu[i] = 2.0 * sd.w_tr * (n.u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * n.u[i] * zh;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    nb[N_WU + i * 3 + j] = (i == j ? 2.0 * sd.w_tr + delta_w + 2.0 * n.zu : 0.0) + sig * 4.0 * n.u[i] * n.u[j];
+            }
+        }
+        double zh_rmax = 0.0, sig_rmax = 0.0;
+        if (k >= 1) {
+            const double r2 = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2];
+            const double g = r2 - sd.b_rmax;
+            sig_rmax = n.zrmax / n.srmax; zh_rmax = mu / n.srmax + sig_rmax * (g + n.srmax);
+        }
+        if (k >= 1 && k <= K - 2) {
+            const double *rb = s.rbh + (size_t)k * 3;
+            const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
+            const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gx[i] += 2.0 * n.x[i] * zh_rmax - rb[i] * zh;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Wx[i * 7 + j] += (i == j ? 2.0 * n.zrmax : 0.0) + sig_rmax * 4.0 * n.x[i] * n.x[j] + sig * rb[i] * rb[j];
+            }
+        }
+        if (k <= K - 2) {
+            // virtual-control block: eliminate t, keep D and rho (without multipliers)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const double g1 = n.nu[i] - n.t[i], g2 = -n.nu[i] - n.t[i];
+                const double s1 = n.ztp[i] / n.stp[i], s2 = n.ztn[i] / n.stn[i];
+                const double zh1 = mu / n.stp[i] + s1 * (g1 + n.stp[i]), zh2 = mu / n.stn[i] + s2 * (g2 + n.stn[i]);
+                const double aa = s1 + s2, bb = s2 - s1, gt = sd.w_nu - zh1 - zh2;
+                nb[N_D + i] = 4.0 * s1 * s2 / aa;
+                nb[N_AA + i] = aa; nb[N_BB + i] = bb; nb[N_GT + i] = gt;
+                nb[N_RHO + i] = (zh1 - zh2) - (bb / aa) * gt;
+            }
+            // dynamics residual e_k
+            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
+            const double *pn = s.it + (size_t)(k + 1) * IT_N;
+            const double tf = s.itg[G_TF];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                double acc = Sg[i] * tf + xi[i] + n.nu[i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += A[i * 7 + j] * n.x[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += Bn[i * 3 + j] * n.u[j] + Bp[i * 3 + j] * pn[I_U + j];
+                nb[N_E + i] = pn[I_X + i] - acc;
+            }
+        }
+        if (k == K - 1) {
+            // terminal node: soft Hessian / gradient + the five rank-1 barrier terms
+            double cv, g6[6];
+            vt_reduced(n.x, sd.vt_des, cv, g6, sd.Hv);
+            sd.cv = cv;
+            for (int i = 0; i < 7; ++i) sd.avt[i] = (i < 6) ? g6[i] : 0.0;
+            const double lvt = s.itg[G_LVT];
+            double sig[6], zh[6];
+            for (int j = 0; j < 6; ++j) {
+                double gj = -sd.bT[j];
+                for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * n.x[i];
+                const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
+                sig[j] = zj / sj; zh[j] = mu / sj + sig[j] * (gj + sj);
+            }
+            const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
+            const double grf = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax;
+            const double sigrf = zrf / srf, zhrf = mu / srf + sigrf * (grf + srf);
+            for (int i = 0; i < 49; ++i) sd.WxKsoft[i] = Wx[i];
+            for (int i = 0; i < 3; ++i) sd.WxKsoft[i * 8] += 2.0 * (n.zrmax + zrf);
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) sd.WxKsoft[i * 7 + j] += lvt * sd.Hv[i * 6 + j];
+            for (int i = 0; i < 7; ++i) sd.gxKsoft[i] = gx[i];
+            const int rows[NTERM] = {0, 1, 3, 5, -1};
+            for (int t = 0; t < NTERM; ++t) {
+                if (rows[t] >= 0) for (int i = 0; i < 7; ++i) sd.ta[t][i] = sd.aT[rows[t]][i];
+                else for (int i = 0; i < 7; ++i) sd.ta[t][i] = (i < 3) ? 2.0 * n.x[i] : 0.0;
+            }
+            sd.tw[0] = sig[0]; sd.tgh[0] = zh[0];
+            sd.tw[1] = sig[1] + sig[2]; sd.tgh[1] = zh[1] - zh[2];
+            sd.tw[2] = sig[3] + sig[4]; sd.tgh[2] = zh[3] - zh[4];
+            sd.tw[3] = sig[5]; sd.tgh[3] = zh[5];
+            sd.tw[4] = sig_rmax + sigrf; sd.tgh[4] = zh_rmax + zhrf;
+            // Hessian used inside the recursion: capped share of the rank-1 weights + AL term for vt
+            for (int i = 0; i < 49; ++i) sd.WxK[i] = sd.WxKsoft[i];
+            for (int t = 0; t < NTERM; ++t) {
+                const double wi = fmin(sd.tw[t], kTermCap);
+                sd.twin[t] = wi;
+                for (int i = 0; i < 7; ++i)
+                    for (int j = 0; j < 7; ++j) sd.WxK[i * 7 + j] += wi * sd.ta[t][i] * sd.ta[t][j];
+            }
+            double hn = 0.0, an = 0.0;
+            for (int i = 0; i < 36; ++i) hn += sd.Hv[i] * sd.Hv[i];
+            for (int i = 0; i < 6; ++i) an += g6[i] * g6[i];
+            sd.gam = (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
+            for (int i = 0; i < 7; ++i)
+                for (int j = 0; j < 7; ++j) sd.WxK[i * 7 + j] += sd.gam * sd.avt[i] * sd.avt[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 49; ++i) nb[N_WX + i] = Wx[i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) nb[N_GX + i] = gx[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nb[N_GU + i] = gu[i];
+    }
+    if (lane == 0) {
+        const double tf = s.itg[G_TF];
+        double W = 2.0 * sd.w_tr + delta_w, g = 1.0 + 2.0 * sd.w_tr * (tf - sd.tfbar);
+        const double gv[2] = {-tf - sd.b_tf[0], tf - sd.b_tf[1]};
+        for (int j = 0; j < 2; ++j) {
+            const double sj = s.itg[G_STF + j], zj = s.itg[G_ZTF + j];
+            const double sig = zj / sj, zh = mu / sj + sig * (gv[j] + sj);
+            W += sig; g += (j == 0 ? -zh : zh);
+        }
+        sd.Wtf = W; sd.gtf = g;
+    }
+    (void)wtf_part;
+    __syncthreads();
+}
+
+// ---- tiny dense helpers on LDS matrices --------------------------------------------------------
+// out(i,j) (op)= sum_l A[i*ar + l*ac] * B[l*br + j*bc],  i<M, j<N, l<Kd ; op: 0 assign, 1 add, -1 subtract
+__device__ __forceinline__ void mm(double *out, int ldo, const double *A, int ar, int ac, const double *B, int br,
+                                   int bc, int M, int N, int Kd, int op, int lane)
+{
+    for (int e = lane; e < M * N; e += 64) {
+        const int i = e / N, j = e - i * N;
+        double acc = 0.0;
+        for (int l = 0; l < Kd; ++l) acc += A[i * ar + l * ac] * B[l * br + j * bc];
+        double *o = out + i * ldo + j;
+        *o = (op == 0) ? acc : (op > 0 ? *o + acc : *o - acc);
+    }
+    __syncthreads();
+}
+
+// in-place lower Cholesky of an n x n LDS matrix (row-major, ld = n); returns false if not PD
+__device__ bool chol_lds(double *M, int n, int lane, int *flag)
+{
+    if (lane == 0) *flag = 0;
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        if (lane == 0) {
+            const double d = M[p * n + p];
+            if (!(d > 0.0)) *flag = 1;
+            M[p * n + p] = sqrt(d > 0.0 ? d : 1.0);
+        }
+        __syncthreads();
+        if (lane > p && lane < n) M[lane * n + p] /= M[p * n + p];
+        __syncthreads();
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            if (j > p && j <= i) M[i * n + j] -= M[i * n + p] * M[j * n + p];
+        }
+        __syncthreads();
+    }
+    // zero the strict upper triangle so that L can be used as a full matrix
+    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; if (j > i) M[e] = 0.0; }
+    __syncthreads();
+    return *flag == 0;
+}
+
+// X <- L^-1 X for an n x m block (columns independent: one lane per column)
+__device__ __forceinline__ void trsm_lower(const double *L, int n, double *X, int ldx, int m, int lane)
+{
+    if (lane < m) {
+        for (int p = 0; p < n; ++p) {
+            double sacc = X[p * ldx + lane];
+            for (int q = 0; q < p; ++q) sacc -= L[p * n + q] * X[q * ldx + lane];
+            X[p * ldx + lane] = sacc / L[p * n + p];
+        }
+    }
+    __syncthreads();
+}
+
+// symmetric 3x3 inverse with positive-definiteness test (leading minors)
+__device__ bool inv3_spd(const double *Q, double *Qi)
+{
+    const double a = Q[0], b = Q[1], c = Q[2], d = Q[4], e = Q[5], f = Q[8];
+    const double m2 = a * d - b * b;
+    const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
+    if (!(a > 0.0) || !(m2 > 0.0) || !(det > 0.0)) return false;
+    const double id = 1.0 / det;
+    Qi[0] = (d * f - e * e) * id; Qi[1] = (c * e - b * f) * id; Qi[2] = (b * e - c * d) * id;
+    Qi[3] = Qi[1]; Qi[4] = (a * f - c * c) * id; Qi[5] = (b * c - a * e) * id;
+    Qi[6] = Qi[2]; Qi[7] = Qi[5]; Qi[8] = (a * d - b * b) * id;
+    return true;
+}
+
+struct Scratch {   // LDS working set of the recursion
+    double Pn[49], M[49], Wl[49], Pt[49], A[49], Wx[49], PtA[49], tmp[49];
+    double Bn[21], Bpm[21], Bh[21], PtBh[21], WxBp[21], Quy[21], QiQuy[21];
+    double Wu[9], Quu[9], Qi[9], D[8];
+    // channel vectors: [channel][8]
+    double p[NCH][8], v[NCH][8], w[NCH][8], t[NCH][8], y[NCH][8], yh[NCH][8], u[NCH][4], qu[NCH][4], gx[NCH][8], aff[NCH][8], rho[NCH][8], gu[NCH][4];
+};
+
+// Backward Riccati sweep: factorisation (oracle/nlp_ipm.py riccati_factor).  Returns false on breakdown.
+__device__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane)
+{
+    const int K = s.K;
+    for (int k = K - 1; k >= 0; --k) {
+        const double *nb = s.nb + (size_t)k * NB_N;
+        double *fac = s.fac + (size_t)k * FAC_N;
+        // stage operands -> LDS
+        for (int e = lane; e < 49; e += 64) {
+            w.Wx[e] = (k == K - 1) ? sd.WxK[e] : nb[N_WX + e];
+            w.A[e] = (k <= K - 2) ? s.A(k)[e] : 0.0;
+        }
+        if (lane < 21) {
+            w.Bpm[lane] = (k >= 1) ? s.Bp(k - 1)[lane] : 0.0;
+            w.Bn[lane] = (k <= K - 2) ? s.Bn(k)[lane] : 0.0;
+        }
+        if (lane < 9) w.Wu[lane] = nb[N_WU + lane];
+        if (lane < 7) w.D[lane] = (k <= K - 2) ? nb[N_D + lane] : 0.0;
+        __syncthreads();
+        if (k <= K - 2) {
+            for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.M[e] = w.Pn[e] + (i == j ? w.D[i] : 0.0); w.Wl[e] = w.Pn[e]; }
+            __syncthreads();
+            if (!chol_lds(w.M, 7, lane, &sd.flag)) return false;
+            trsm_lower(w.M, 7, w.Wl, 7, 7, lane);                                   // Wl = L^-1 Pn
+            for (int e = lane; e < 49; e += 64) w.Pt[e] = w.Pn[e];
+            __syncthreads();
+            mm(w.Pt, 7, w.Wl, 1, 7, w.Wl, 7, 1, 7, 7, 7, -1, lane);                 // Pt = Pn - Wl^T Wl
+            for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.tmp[e] = 0.5 * (w.Pt[e] + w.Pt[j * 7 + i]); }
+            __syncthreads();
+            for (int e = lane; e < 49; e += 64) { w.Pt[e] = w.tmp[e]; fac[F_L + e] = w.M[e]; fac[F_WL + e] = w.Wl[e]; fac[F_PT + e] = w.tmp[e]; }
+            if (lane < 21) w.Bh[lane] = w.Bn[lane];
+            __syncthreads();
+            mm(w.Bh, 3, w.A, 7, 1, w.Bpm, 3, 1, 7, 3, 7, 1, lane);                  // Bh = A Bpm + Bn
+            mm(w.PtA, 7, w.Pt, 7, 1, w.A, 7, 1, 7, 7, 7, 0, lane);                  // Pt A
+            mm(w.PtBh, 3, w.Pt, 7, 1, w.Bh, 3, 1, 7, 3, 7, 0, lane);                // Pt Bh
+        } else {
+            for (int e = lane; e < 49; e += 64) { w.Pt[e] = 0.0; w.PtA[e] = 0.0; }
+            if (lane < 21) { w.Bh[lane] = 0.0; w.PtBh[lane] = 0.0; }
+            __syncthreads();
+        }
+        mm(w.WxBp, 3, w.Wx, 7, 1, w.Bpm, 3, 1, 7, 3, 7, 0, lane);                   // Wx Bpm
+        if (lane < 9) w.Quu[lane] = w.Wu[lane];
+        __syncthreads();
+        mm(w.Quu, 3, w.Bpm, 1, 3, w.WxBp, 3, 1, 3, 3, 7, 1, lane);                  // + Bpm^T Wx Bpm
+        mm(w.Quu, 3, w.Bh, 1, 3, w.PtBh, 3, 1, 3, 3, 7, 1, lane);                   // + Bh^T Pt Bh
+        // Quy = Bpm^T Wx + Bh^T Pt A   (3x7)
+        mm(w.Quy, 7, w.Bpm, 1, 3, w.Wx, 7, 1, 3, 7, 7, 0, lane);
+        mm(w.Quy, 7, w.Bh, 1, 3, w.PtA, 7, 1, 3, 7, 7, 1, lane);
+        // Pn <- Wx + A^T Pt A
+        for (int e = lane; e < 49; e += 64) w.Pn[e] = w.Wx[e];
+        __syncthreads();
+        mm(w.Pn, 7, w.A, 1, 7, w.PtA, 7, 1, 7, 7, 7, 1, lane);
+        if (lane == 0) sd.flag = inv3_spd(w.Quu, w.Qi) ? 0 : 1;
+        __syncthreads();
+        if (sd.flag) return false;
+        mm(w.QiQuy, 7, w.Qi, 3, 1, w.Quy, 7, 1, 3, 7, 3, 0, lane);                  // Qi Quy
+        mm(w.Pn, 7, w.Quy, 1, 7, w.QiQuy, 7, 1, 7, 7, 3, -1, lane);                 // - Quy^T Qi Quy
+        for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.tmp[e] = 0.5 * (w.Pn[e] + w.Pn[j * 7 + i]); }
+        __syncthreads();
+        for (int e = lane; e < 49; e += 64) { w.Pn[e] = w.tmp[e]; fac[F_P + e] = w.tmp[e]; }
+        if (lane < 9) fac[F_QI + lane] = w.Qi[lane];
+        if (lane < 21) { fac[F_QUY + lane] = w.Quy[lane]; fac[F_BH + lane] = w.Bh[lane]; }
+        __syncthreads();
+    }
+    return true;
+}
+
+// load stage operands needed by the linear-term sweeps into LDS
+__device__ __forceinline__ void load_sweep_stage(const Sat &s, Scratch &w, int k, int lane)
+{
+    const int K = s.K;
+    const double *fac = s.fac + (size_t)k * FAC_N;
+    for (int e = lane; e < 49; e += 64) {
+        w.A[e] = (k <= K - 2) ? s.A(k)[e] : 0.0;
+        w.M[e] = (k <= K - 2) ? fac[F_L + e] : 0.0;
+        w.Wl[e] = (k <= K - 2) ? fac[F_WL + e] : 0.0;
+        w.Pt[e] = (k <= K - 2) ? fac[F_PT + e] : 0.0;
+        w.Pn[e] = (k <= K - 2) ? s.fac[(size_t)(k + 1) * FAC_N + F_P + e] : 0.0;
+    }
+    if (lane < 21) {
+        w.Bpm[lane] = (k >= 1) ? s.Bp(k - 1)[lane] : 0.0;
+        w.Quy[lane] = fac[F_QUY + lane];
+        w.Bh[lane] = fac[F_BH + lane];
+    }
+    if (lane < 9) w.Qi[lane] = fac[F_QI + lane];
+    if (lane < 7) w.D[lane] = (k <= K - 2) ? s.nb[(size_t)k * NB_N + N_D + lane] : 0.0;
+}
+
+// Backward linear-term sweep for channels [c0, c1): lane group c handles channel c, lane r = row.
+// Channel data: 0 = rhs record; 1 = unit dtf (aff = Sigma); 2.. = unit terminal gradients.
+__device__ void sweep_backward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
+{
+    const int K = s.K;
+    const int c = lane >> 3, r = lane & 7;
+    const bool act = (c >= c0 && c < c1);
+    for (int k = K - 1; k >= 0; --k) {
+        load_sweep_stage(s, w, k, lane);
+        double *ch = s.ch + (size_t)k * CH_N;
+        // channel inputs
+        if (act && r < 7) {
+            double gx = 0.0, rho = 0.0, aff = 0.0;
+            if (c == 0) { gx = ch[C_RHS + R_GX + r]; if (k <= K - 2) { rho = ch[C_RHS + R_RHO + r]; aff = ch[C_RHS + R_AFF + r]; } }
+            else if (c == 1) { if (k <= K - 2) aff = s.Sig(k)[r]; }
+            else if (k == K - 1) gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
+            w.gx[c][r] = gx; w.rho[c][r] = rho; w.aff[c][r] = aff;
+            if (r < 3) w.gu[c][r] = (c == 0) ? ch[C_RHS + R_GU + r] : 0.0;
+            // v = rho + p_{k+1}   (p of the node above is still in w.p)
+            w.v[c][r] = (k <= K - 2) ? rho + w.p[c][r] : 0.0;
+        }
+        __syncthreads();
+        if (k <= K - 2) {
+            // w = L^-1 v  (one lane per channel), pt = p - Wl^T w, t = pt + Pt aff
+            if (act && r == 0) {
+                for (int p = 0; p < 7; ++p) {
+                    double sacc = w.v[c][p];
+                    for (int q = 0; q < p; ++q) sacc -= w.M[p * 7 + q] * w.w[c][q];
+                    w.w[c][p] = sacc / w.M[p * 7 + p];
+                }
+            }
+            __syncthreads();
+            if (act && r < 7) {
+                double acc = w.p[c][r];
+                for (int q = 0; q < 7; ++q) acc -= w.Wl[q * 7 + r] * w.w[c][q];
+                for (int q = 0; q < 7; ++q) acc += w.Pt[r * 7 + q] * w.aff[c][q];
+                w.t[c][r] = acc;
+            }
+        } else if (act && r < 7) w.t[c][r] = 0.0;
+        __syncthreads();
+        if (act && r < 3) {
+            double acc = w.gu[c][r];
+            for (int q = 0; q < 7; ++q) acc += w.Bpm[q * 3 + r] * w.gx[c][q] + w.Bh[q * 3 + r] * w.t[c][q];
+            w.qu[c][r] = acc;
+        }
+        __syncthreads();
+        if (act && r < 3) {
+            w.u[c][r] = w.Qi[r * 3] * w.qu[c][0] + w.Qi[r * 3 + 1] * w.qu[c][1] + w.Qi[r * 3 + 2] * w.qu[c][2];
+            ch[C_QU + c * 3 + r] = w.qu[c][r];
+        }
+        __syncthreads();
+        if (act && r < 7) {
+            double acc = w.gx[c][r];
+            for (int q = 0; q < 7; ++q) acc += w.A[q * 7 + r] * w.t[c][q];
+            for (int q = 0; q < 3; ++q) acc -= w.Quy[q * 7 + r] * w.u[c][q];
+            w.p[c][r] = acc;
+            ch[C_P + c * 7 + r] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// Forward sweep.  mode 0: channels [c0,c1) accumulate the border coefficients (Sigma.lam, x_K).
+// mode 1: single combined channel (group 0) with p, qu, aff combined by sol[]; adds the result to the direction.
+__device__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int mode, int lane)
+{
+    const int K = s.K;
+    const int c = lane >> 3, r = lane & 7;
+    const bool act = (mode == 0) ? (c >= c0 && c < c1) : (c == 0);
+    if (act && r < 7) w.y[c][r] = 0.0;
+    double siglam = 0.0;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        load_sweep_stage(s, w, k, lane);
+        const double *ch = s.ch + (size_t)k * CH_N;
+        const double *chn = s.ch + (size_t)(k + 1) * CH_N;
+        if (act) {
+            if (r < 3) {
+                double q = 0.0;
+                if (mode == 0) q = ch[C_QU + c * 3 + r];
+                else { q = ch[C_QU + r]; for (int j = 0; j < NBD; ++j) q += sd.sol[j] * ch[C_QU + (1 + j) * 3 + r]; }
+                w.qu[c][r] = q;
+            }
+            if (r < 7 && k <= K - 2) {
+                double pn = 0.0, aff = 0.0, rho = 0.0;
+                if (mode == 0) {
+                    pn = chn[C_P + c * 7 + r];
+                    if (c == 0) { aff = ch[C_RHS + R_AFF + r]; rho = ch[C_RHS + R_RHO + r]; }
+                    else if (c == 1) aff = s.Sig(k)[r];
+                } else {
+                    pn = chn[C_P + r];
+                    for (int j = 0; j < NBD; ++j) pn += sd.sol[j] * chn[C_P + (1 + j) * 7 + r];
+                    aff = ch[C_RHS + R_AFF + r] + sd.sol[0] * s.Sig(k)[r];
+                    rho = ch[C_RHS + R_RHO + r];
+                }
+                w.p[c][r] = pn; w.aff[c][r] = aff; w.rho[c][r] = rho;
+            }
+        }
+        __syncthreads();
+        if (act && r < 3) {
+            double acc = w.qu[c][r];
+            for (int q = 0; q < 7; ++q) acc += w.Quy[r * 7 + q] * w.y[c][q];
+            w.t[c][r] = acc;     // Quy y + qu
+        }
+        __syncthreads();
+        if (act && r < 3) w.u[c][r] = -(w.Qi[r * 3] * w.t[c][0] + w.Qi[r * 3 + 1] * w.t[c][1] + w.Qi[r * 3 + 2] * w.t[c][2]);
+        __syncthreads();
+        double xr = 0.0;
+        if (act && r < 7) {
+            xr = w.y[c][r];
+            for (int q = 0; q < 3; ++q) xr += w.Bpm[r * 3 + q] * w.u[c][q];
+            if (k == K - 1 && mode == 0) sd.xK[c][r] = xr;
+            if (k <= K - 2) {
+                double yh = w.aff[c][r];
+                for (int q = 0; q < 7; ++q) yh += w.A[r * 7 + q] * w.y[c][q];
+                for (int q = 0; q < 3; ++q) yh += w.Bh[r * 3 + q] * w.u[c][q];
+                w.yh[c][r] = yh;
+            }
+        }
+        __syncthreads();
+        if (k <= K - 2) {
+            if (act && r < 7) {
+                double acc = w.rho[c][r] + w.p[c][r];
+                for (int q = 0; q < 7; ++q) acc += w.Pn[r * 7 + q] * w.yh[c][q];
+                w.v[c][r] = acc;
+            }
+            __syncthreads();
+            if (act && r == 0) {
+                // nu = -L^-T L^-1 v
+                for (int p = 0; p < 7; ++p) {
+                    double sacc = w.v[c][p];
+                    for (int q = 0; q < p; ++q) sacc -= w.M[p * 7 + q] * w.w[c][q];
+                    w.w[c][p] = sacc / w.M[p * 7 + p];
+                }
+                for (int p = 6; p >= 0; --p) {
+                    double sacc = w.w[c][p];
+                    for (int q = p + 1; q < 7; ++q) sacc -= w.M[q * 7 + p] * w.t[c][q];
+                    w.t[c][p] = sacc / w.M[p * 7 + p];
+                }
+            }
+            __syncthreads();
+        }
+        if (act && r < 7) {
+            double nu = 0.0, lam = 0.0;
+            if (k <= K - 2) {
+                nu = -w.t[c][r];
+                lam = w.D[r] * nu + w.rho[c][r];
+                siglam += s.Sig(k)[r] * lam;
+            }
+            if (mode == 1) {
+                double *d = s.dr + (size_t)k * IT_N;
+                d[I_X + r] += xr;
+                if (r < 3) d[I_U + r] += w.u[c][r];
+                if (k <= K - 2) { d[I_NU + r] += nu; d[I_LAM + r] += lam; }
+            }
+        }
+        __syncthreads();
+        if (act && r < 7 && k <= K - 2) w.y[c][r] = w.yh[c][r] - w.t[c][r];
+        __syncthreads();
+    }
+    if (mode == 0) {
+        // reduce Sigma.lam over the 8 lanes of each group
+        siglam += __shfl_xor(siglam, 1, 8);
+        siglam += __shfl_xor(siglam, 2, 8);
+        siglam += __shfl_xor(siglam, 4, 8);
+        if (act && r == 0) sd.siglam[c] = siglam;
+    }
+    __syncthreads();
+}
+
+// Border matrix from the unit channels (1..7), LU with partial pivoting by lane 0.
+__device__ bool border_factor(SatData &sd, int lane)
+{
+    if (lane == 0) {
+        double wex[NTERM];
+        for (int t = 0; t < NTERM; ++t) wex[t] = sd.tw[t] - sd.twin[t];
+        for (int i = 0; i < NBD; ++i)
+            for (int j = 0; j < NBD; ++j) sd.Mb[i][j] = 0.0;
+        sd.Mb[0][0] = sd.Wtf;
+        for (int c = 1; c <= NBD; ++c) sd.Mb[0][c - 1] -= sd.siglam[c];
+        for (int i = 0; i < 1 + NTERM; ++i) {
+            const double *a = (i == 0) ? sd.avt : sd.ta[i - 1];
+            for (int c = 1; c <= NBD; ++c) {
+                double acc = 0.0;
+                for (int q = 0; q < 7; ++q) acc += a[q] * sd.xK[c][q];
+                sd.Mb[1 + i][c - 1] = acc;
+            }
+        }
+        for (int t = 0; t < NTERM; ++t) {
+            for (int j = 0; j < NBD; ++j) sd.Mb[2 + t][j] *= wex[t];
+            sd.Mb[2 + t][2 + t] -= 1.0;
+        }
+        int ok = 1;
+        for (int p = 0; p < NBD; ++p) {
+            int piv = p; double best = fabs(sd.Mb[p][p]);
+            for (int i = p + 1; i < NBD; ++i) if (fabs(sd.Mb[i][p]) > best) { best = fabs(sd.Mb[i][p]); piv = i; }
+            sd.piv[p] = piv;
+            if (!(best > 0.0)) { ok = 0; break; }
+            if (piv != p) for (int j = 0; j < NBD; ++j) { const double t = sd.Mb[p][j]; sd.Mb[p][j] = sd.Mb[piv][j]; sd.Mb[piv][j] = t; }
+            for (int i = p + 1; i < NBD; ++i) {
+                const double m = sd.Mb[i][p] / sd.Mb[p][p];
+                sd.Mb[i][p] = m;
+                for (int j = p + 1; j < NBD; ++j) sd.Mb[i][j] -= m * sd.Mb[p][j];
+            }
+        }
+        sd.flag = ok ? 0 : 1;
+    }
+    __syncthreads();
+    return sd.flag == 0;
+}
+
+// Right-hand side of the border system from channel 0, then solve with the stored LU.
+__device__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const double *gex, int lane)
+{
+    if (lane == 0) {
+        double rb[NBD];
+        rb[0] = -gtf_rhs + sd.siglam[0];
+        for (int i = 0; i < 1 + NTERM; ++i) {
+            const double *a = (i == 0) ? sd.avt : sd.ta[i - 1];
+            double acc = 0.0;
+            for (int q = 0; q < 7; ++q) acc += a[q] * sd.xK[0][q];
+            rb[1 + i] = -acc;
+        }
+        rb[1] += rvt_rhs;
+        for (int t = 0; t < NTERM; ++t) rb[2 + t] = rb[2 + t] * (sd.tw[t] - sd.twin[t]) - gex[t];
+        // all row interchanges first (the stored multipliers are in final row order), then L, then U
+        for (int p = 0; p < NBD; ++p) {
+            const int piv = sd.piv[p];
+            if (piv != p) { const double t = rb[p]; rb[p] = rb[piv]; rb[piv] = t; }
+        }
+        for (int p = 0; p < NBD; ++p)
+            for (int i = p + 1; i < NBD; ++i) rb[i] -= sd.Mb[i][p] * rb[p];
+        for (int p = NBD - 1; p >= 0; --p) {
+            double acc = rb[p];
+            for (int j = p + 1; j < NBD; ++j) acc -= sd.Mb[p][j] * sd.sol[j];
+            sd.sol[p] = acc / sd.Mb[p][p];
+        }
+    }
+    __syncthreads();
+}
+
+// Residual of the reduced KKT system at the current direction -> rhs record of channel 0
+// (oracle/nlp_ipm.py reduced_residual).  Stage-parallel.  Returns gtf_rhs, rvt_rhs, gterm[] via sd.red / gterm.
+__device__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
+{
+    const int K = s.K;
+    double gtf_part = 0.0;
+    const double dtf = s.drg[G_TF];
+    for (int k = lane; k < K; k += 64) {
+        const double *nb = s.nb + (size_t)k * NB_N;
+        const double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        double *rec = s.ch + (size_t)k * CH_N + C_RHS;
+        double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            lt[i] = (k <= K - 2) ? p[I_LAM + i] + d[I_LAM + i] : 0.0;
+            ltm[i] = (k >= 1) ? (p - IT_N)[I_LAM + i] + (d - IT_N)[I_LAM + i] : 0.0;
+        }
+        double gx[7], gu[3];
+        if (k >= 1) {
+            const double *W = (k == K - 1) ? sd.WxKsoft : nb + N_WX;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                double acc = ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]) + ltm[i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += W[i * 7 + j] * d[I_X + j];
+                gx[i] = acc;
+            }
+            if (k == K - 1) {
+                const double lvt = s.itg[G_LVT] + s.drg[G_LVT];
+                for (int i = 0; i < 7; ++i) gx[i] += sd.avt[i] * lvt;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) gx[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = nb[N_GU + i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += nb[N_WU + i * 3 + j] * d[I_U + j];
+            gu[i] = acc;
+        }
+        if (k >= 1) {
+            const double *Bp = s.Bp(k - 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += Bp[i * 3 + j] * ltm[i];
+                gu[j] -= acc;
+            }
+        }
+        if (k <= K - 2) {
+            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k);
+            const double *dn = d + IT_N;
+            if (k >= 1) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) acc += A[i * 7 + j] * lt[i];
+                    gx[j] -= acc;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += Bn[i * 3 + j] * lt[i];
+                gu[j] -= acc;
+            }
+            double sl = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                rec[R_RHO + i] = nb[N_RHO + i] + nb[N_D + i] * d[I_NU + i] - lt[i];
+                double acc = dn[I_X + i] - Sg[i] * dtf - d[I_NU + i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc -= A[i * 7 + j] * d[I_X + j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc -= Bn[i * 3 + j] * d[I_U + j] + Bp[i * 3 + j] * dn[I_U + j];
+                rec[R_AFF + i] = -nb[N_E + i] - acc;
+                sl += Sg[i] * lt[i];
+            }
+            gtf_part -= sl;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rec[R_GX + i] = gx[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
+    }
+    gtf_rhs = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
+    const double *dK = s.dr + (size_t)(K - 1) * IT_N;
+    double av = 0.0;
+    for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
+    rvt_rhs = -sd.cv - av;
+    for (int t = 0; t < NTERM; ++t) {
+        double acc = 0.0;
+        for (int i = 0; i < 7; ++i) acc += sd.ta[t][i] * dK[I_X + i];
+        gterm[t] = sd.tgh[t] + sd.tw[t] * acc;
+    }
+    __syncthreads();
+    // terminal-node rhs completion: capped share of the rank-1 gradient terms and the AL shift
+    if (lane == 0) {
+        double *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
+        for (int t = 0; t < NTERM; ++t) {
+            const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
+        }
+        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_rhs * sd.avt[i];
+    }
+    __syncthreads();
+}
+
+// dt, ds, dz by back-substitution (oracle finish_direction) and the fraction-to-the-boundary step.
+__device__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
+{
+    const int K = s.K;
+    double amax = 1.0;
+#define LIM(v, dv) { const double v_ = (v), d_ = (dv); if (d_ < 0.0) amax = fmin(amax, -tau * v_ / d_); }
+    for (int k = lane; k < K; k += 64) {
+        NodeVals n;
+        load_node(s, k, 0.0, n);
+        const double *nb = s.nb + (size_t)k * NB_N;
+        double *d = s.dr + (size_t)k * IT_N;
+        {
+            const double g = n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u;
+            const double sig = n.zu / n.su, zh = mu / n.su + sig * (g + n.su);
+            const double dg = 2.0 * (n.u[0] * d[I_U] + n.u[1] * d[I_U + 1] + n.u[2] * d[I_U + 2]);
+            d[I_SU] = -(g + n.su) - dg; d[I_ZU] = zh + sig * dg - n.zu;
+            LIM(n.su, d[I_SU]); LIM(n.zu, d[I_ZU]);
+        }
+        if (k >= 1) {
+            const double g = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rmax;
+            const double sig = n.zrmax / n.srmax, zh = mu / n.srmax + sig * (g + n.srmax);
+            const double dg = 2.0 * (n.x[0] * d[I_X] + n.x[1] * d[I_X + 1] + n.x[2] * d[I_X + 2]);
+            d[I_SRMAX] = -(g + n.srmax) - dg; d[I_ZRMAX] = zh + sig * dg - n.zrmax;
+            LIM(n.srmax, d[I_SRMAX]); LIM(n.zrmax, d[I_ZRMAX]);
+        }
+        if (k >= 1 && k <= K - 2) {
+            const double *rb = s.rbh + (size_t)k * 3;
+            const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
+            const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
+            const double dg = -(rb[0] * d[I_X] + rb[1] * d[I_X + 1] + rb[2] * d[I_X + 2]);
+            d[I_SRMIN] = -(g + n.srmin) - dg; d[I_ZRMIN] = zh + sig * dg - n.zrmin;
+            LIM(n.srmin, d[I_SRMIN]); LIM(n.zrmin, d[I_ZRMIN]);
+        }
+        if (k <= K - 2) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const double dnu = d[I_NU + i];
+                const double dt = (-nb[N_GT + i] - nb[N_BB + i] * dnu) / nb[N_AA + i];
+                d[I_T + i] = dt;
+                const double g1 = n.nu[i] - n.t[i], g2 = -n.nu[i] - n.t[i];
+                const double s1 = n.ztp[i] / n.stp[i], s2 = n.ztn[i] / n.stn[i];
+                const double zh1 = mu / n.stp[i] + s1 * (g1 + n.stp[i]), zh2 = mu / n.stn[i] + s2 * (g2 + n.stn[i]);
+                const double dg1 = dnu - dt, dg2 = -dnu - dt;
+                d[I_STP + i] = -(g1 + n.stp[i]) - dg1; d[I_ZTP + i] = zh1 + s1 * dg1 - n.ztp[i];
+                d[I_STN + i] = -(g2 + n.stn[i]) - dg2; d[I_ZTN + i] = zh2 + s2 * dg2 - n.ztn[i];
+                LIM(n.stp[i], d[I_STP + i]); LIM(n.ztp[i], d[I_ZTP + i]);
+                LIM(n.stn[i], d[I_STN + i]); LIM(n.ztn[i], d[I_ZTN + i]);
+            }
+        }
+        if (k == K - 1) {
+            for (int j = 0; j < 6; ++j) {
+                double gj = -sd.bT[j], dg = 0.0;
+                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * n.x[i]; dg += sd.aT[j][i] * d[I_X + i]; }
+                const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
+                const double sig = zj / sj, zh = mu / sj + sig * (gj + sj);
+                s.drg[G_STERM + j] = -(gj + sj) - dg; s.drg[G_ZTERM + j] = zh + sig * dg - zj;
+                LIM(sj, s.drg[G_STERM + j]); LIM(zj, s.drg[G_ZTERM + j]);
+            }
+            const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
+            const double g = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax;
+            const double sig = zrf / srf, zh = mu / srf + sig * (g + srf);
+            const double dg = 2.0 * (n.x[0] * d[I_X] + n.x[1] * d[I_X + 1] + n.x[2] * d[I_X + 2]);
+            s.drg[G_SRF] = -(g + srf) - dg; s.drg[G_ZRF] = zh + sig * dg - zrf;
+            LIM(srf, s.drg[G_SRF]); LIM(zrf, s.drg[G_ZRF]);
+        }
+    }
+    if (lane == 0) {
+        const double tf = s.itg[G_TF], dtf = s.drg[G_TF];
+        const double gv[2] = {-tf - sd.b_tf[0], tf - sd.b_tf[1]}, dgv[2] = {-dtf, dtf};
+        for (int j = 0; j < 2; ++j) {
+            const double sj = s.itg[G_STF + j], zj = s.itg[G_ZTF + j];
+            const double sig = zj / sj, zh = mu / sj + sig * (gv[j] + sj);
+            s.drg[G_STF + j] = -(gv[j] + sj) - dgv[j]; s.drg[G_ZTF + j] = zh + sig * dgv[j] - zj;
+            LIM(sj, s.drg[G_STF + j]); LIM(zj, s.drg[G_ZTF + j]);
+        }
+    }
+#undef LIM
+    amax = wave_min(amax);
+    __syncthreads();
+    return amax;
+}
+
+// iterate <- iterate + a * direction, slack reset and multiplier safeguard (stage-parallel)
+__device__ void apply_step(const Sat &s, SatData &sd, double a, double mu, int lane)
+{
+    const int K = s.K;
+#define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
+                             z_ = fmax(fmin(z_, kKappaSigma * mu / s_), mu / (kKappaSigma * s_)); (sv) = s_; (zv) = z_; }
+    for (int k = lane; k < K; k += 64) {
+        double *p = s.it + (size_t)k * IT_N;
+        const double *d = s.dr + (size_t)k * IT_N;
+        for (int i = 0; i < IT_N - 1; ++i) p[i] += a * d[i];
+        const double *x = p + I_X, *u = p + I_U;
+        SAFE(p[I_SU], p[I_ZU], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u);
+        if (k >= 1) SAFE(p[I_SRMAX], p[I_ZRMAX], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rmax);
+        if (k >= 1 && k <= K - 2) {
+            const double *rb = s.rbh + (size_t)k * 3;
+            SAFE(p[I_SRMIN], p[I_ZRMIN], -(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin);
+        }
+        if (k <= K - 2) {
+            for (int i = 0; i < 7; ++i) {
+                SAFE(p[I_STP + i], p[I_ZTP + i], p[I_NU + i] - p[I_T + i]);
+                SAFE(p[I_STN + i], p[I_ZTN + i], -p[I_NU + i] - p[I_T + i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 0; i < GL_N; ++i) s.itg[i] += a * s.drg[i];
+        const double *x = s.it + (size_t)(K - 1) * IT_N + I_X;
+        for (int j = 0; j < 6; ++j) {
+            double gj = -sd.bT[j];
+            for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
+            SAFE(s.itg[G_STERM + j], s.itg[G_ZTERM + j], gj);
+        }
+        SAFE(s.itg[G_SRF], s.itg[G_ZRF], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax);
+        const double tf = s.itg[G_TF];
+        SAFE(s.itg[G_STF], s.itg[G_ZTF], -tf - sd.b_tf[0]);
+        SAFE(s.itg[G_STF + 1], s.itg[G_ZTF + 1], tf - sd.b_tf[1]);
+    }
+#undef SAFE
+    __syncthreads();
+}
+
+// a satellite whose discretisation failed reports that code instead of the solver's
+__global__ void merge_status_kernel(int S, const int32_t *dstat, int32_t *status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S && dstat[i] != 0) status[i] = dstat[i];
+}
+static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32_t *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(merge_status_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, dstat, status);
+}
+
+__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
+{
+    __shared__ SatData sd;
+    __shared__ Scratch w;
+    const int lane = threadIdx.x;
+    const int sat = blockIdx.x;
+    if (sat >= a.S) return;
+    const int K = a.K;
+    Sat s;
+    s.K = K;
+    s.stage = a.stage + (size_t)sat * (K - 1) * MPCX_STAGE_DOUBLES;
+    s.xbar = a.xbar + (size_t)sat * 7 * K;
+    s.ubar = a.ubar + (size_t)sat * 3 * K;
+    double *ws = a.ws + (size_t)sat * a.ws_stride;
+    s.it = ws; ws += (size_t)K * IT_N;
+    s.dr = ws; ws += (size_t)K * IT_N;
+    s.nb = ws; ws += (size_t)K * NB_N;
+    s.fac = ws; ws += (size_t)K * FAC_N;
+    s.ch = ws; ws += (size_t)K * CH_N;
+    s.itg = ws; ws += GL_N;
+    s.drg = ws; ws += GL_N;
+    s.rbh = ws;
+    const SolveOpts &o = a.o;
+
+    // ---- problem constants (constraint terms) and the initial iterate ----
+    if (lane == 0) {
+        double xK[7];
+        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
+        build_terminal(xK, a.consts[(size_t)sat * MPCX_NCONST + MPCX_C_MU], a.r_des[sat], o, sd);
+        sd.tfbar = a.tfbar[sat];
+    }
+    __syncthreads();
+    for (int k = lane; k < K; k += 64) {
+        double x[7], u[3];
+        for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * K + k];
+        for (int i = 0; i < 3; ++i) u[i] = s.ubar[(size_t)i * K + k];
+        const double rn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        double *rb = s.rbh + (size_t)k * 3;
+        for (int i = 0; i < 3; ++i) rb[i] = x[i] / rn;           // optimizer.py:129-130
+        double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        for (int i = 0; i < IT_N; ++i) { p[i] = 0.0; d[i] = 0.0; }
+        for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
+        for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
+        // slacks pushed into the interior (bound_push), multipliers 1
+        for (int i = 0; i < 7; ++i) { p[I_STP + i] = kBoundPush; p[I_STN + i] = kBoundPush; p[I_ZTP + i] = 1.0; p[I_ZTN + i] = 1.0; }
+        p[I_SU] = fmax(-(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u), kBoundPush * fmax(1.0, fabs(sd.b_u))); p[I_ZU] = 1.0;
+        p[I_SRMAX] = fmax(-(rn * rn - sd.b_rmax), kBoundPush * fmax(1.0, fabs(sd.b_rmax))); p[I_ZRMAX] = 1.0;
+        p[I_SRMIN] = fmax(-(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin), kBoundPush * fmax(1.0, fabs(sd.b_rmin))); p[I_ZRMIN] = 1.0;
+    }
+    if (lane == 0) {
+        for (int i = 0; i < GL_N; ++i) { s.itg[i] = 0.0; s.drg[i] = 0.0; }
+        double xK[7];
+        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
+        for (int j = 0; j < 6; ++j) {
+            double gj = -sd.bT[j];
+            for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * xK[i];
+            s.itg[G_STERM + j] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[G_ZTERM + j] = 1.0;
+        }
+        const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
+        s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = 1.0;
+        const double tf = sd.tfbar;
+        s.itg[G_TF] = tf;
+        s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = 1.0;
+        s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = 1.0;
+    }
+    __syncthreads();
+
+    double mu = 0.1;
+    int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
+    double E0 = 0.0;
+    for (int iter = 0;; ++iter) {
+        it_count = iter;
+        ResAcc r0;
+        eval_residual(s, sd, 0.0, 0.0, lane, r0);
+        E0 = scaled_error(r0, K);
+        if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
+        if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
+        n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
+        if (n_acc >= o.acc_iter) { status = MPCX_ST_ACCEPTABLE; break; }
+        if (iter >= o.max_iter) { status = (E0 <= o.acc_tol) ? MPCX_ST_ACCEPTABLE : MPCX_ST_MAXITER; break; }
+        // monotone barrier update (ipopt: kappa_eps 10, kappa_mu 0.2, theta_mu 1.5)
+        for (int guard = 0; guard < 64; ++guard) {
+            ResAcc rm;
+            eval_residual(s, sd, 0.0, mu, lane, rm);
+            if (scaled_error(rm, K) <= 10.0 * mu && mu > o.tol / 10.0) mu = fmax(o.tol / 10.0, fmin(0.2 * mu, pow(mu, 1.5)));
+            else break;
+        }
+        // Newton direction, with Hessian regularisation retries on breakdown
+        bool have_dir = false;
+        double delta_w = 0.0;
+        for (int trial = 0; trial < 10 && !have_dir; ++trial) {
+            newton_blocks(s, sd, mu, delta_w, lane);
+            bool ok = riccati_factor(s, sd, w, lane);
+            if (ok) {
+                // unit channels 1..7: backward vectors + border coefficients
+                for (int e = lane; e < NCH * 8; e += 64) ((double *)w.p)[e] = 0.0;
+                __syncthreads();
+                // direction := (0, ..., -lam, -lam_vt) so that the first residual carries no multipliers
+                for (int k = lane; k < K; k += 64) {
+                    double *d = s.dr + (size_t)k * IT_N;
+                    const double *p = s.it + (size_t)k * IT_N;
+                    for (int i = 0; i < IT_N; ++i) d[i] = 0.0;
+                    if (k <= K - 2) for (int i = 0; i < 7; ++i) d[I_LAM + i] = -p[I_LAM + i];
+                }
+                if (lane == 0) { for (int i = 0; i < GL_N; ++i) s.drg[i] = 0.0; s.drg[G_LVT] = -s.itg[G_LVT]; }
+                __syncthreads();
+                const int passes = 1 + ((delta_w == 0.0) ? o.n_refine : 0);
+                for (int pass = 0; pass < passes && ok; ++pass) {
+                    double gtf_rhs, rvt_rhs, gterm[NTERM], gex[NTERM];
+                    reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                    for (int t = 0; t < NTERM; ++t) {
+                        const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+                        gex[t] = gterm[t] * (1.0 - share);
+                    }
+                    for (int e = lane; e < NCH * 8; e += 64) ((double *)w.p)[e] = 0.0;
+                    __syncthreads();
+                    if (pass == 0) {
+                        sweep_backward(s, sd, w, 0, NCH, lane);
+                        sweep_forward(s, sd, w, 0, NCH, 0, lane);
+                        ok = border_factor(sd, lane);
+                        if (!ok) break;
+                    } else {
+                        sweep_backward(s, sd, w, 0, 1, lane);
+                        sweep_forward(s, sd, w, 0, 1, 0, lane);
+                    }
+                    border_solve(sd, gtf_rhs, rvt_rhs, gex, lane);
+                    sweep_forward(s, sd, w, 0, 1, 1, lane);
+                    if (lane == 0) { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
+                    __syncthreads();
+                }
+            }
+            if (ok) {
+                // finite check on the direction
+                double bad = 0.0;
+                for (int k = lane; k < K; k += 64) {
+                    const double *d = s.dr + (size_t)k * IT_N;
+                    for (int i = 0; i < I_STP; ++i) if (!(fabs(d[i]) < 1e300)) bad = 1.0;
+                }
+                if (!(fabs(s.drg[G_TF]) < 1e300)) bad = 1.0;
+                ok = (wave_max(bad) == 0.0);
+            }
+            if (ok) have_dir = true;
+            else delta_w = (delta_w == 0.0) ? 1e-4 : delta_w * 10.0;
+        }
+        if (!have_dir) { status = MPCX_ST_NUMERIC; break; }
+        const double tau = fmax(0.99, 1.0 - mu);
+        double alpha = finish_direction(s, sd, mu, tau, lane);
+        // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
+        ResAcc rc;
+        eval_residual(s, sd, 0.0, mu, lane, rc);
+        const double rn0 = sqrt(rc.sq);
+        const int nzc = n_ineq(K);
+        for (int ls = 0; ls < 30; ++ls) {
+            ResAcc rt;
+            eval_residual(s, sd, alpha, mu, lane, rt);
+            const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
+            const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
+            if (dec && cen) break;
+            alpha *= 0.5;
+        }
+        apply_step(s, sd, alpha, mu, lane);
+    }
+
+    // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----
+    for (int k = lane; k < K; k += 64) {
+        const double *p = s.it + (size_t)k * IT_N;
+        for (int i = 0; i < 7; ++i) {
+            a.X[(size_t)sat * 7 * K + (size_t)i * K + k] = p[I_X + i];
+            a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
+        }
+        for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * K + (size_t)i * K + k] = p[I_U + i];
+    }
+    if (lane == 0) {
+        a.tf_out[sat] = s.itg[G_TF];
+        a.status[sat] = status;
+        a.iters[sat] = it_count;
+        a.kkt[sat] = E0;
+    }
+}
+
+}  // namespace mpcx
+
+using namespace mpcx;
+
+static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
+{
+    SolveOpts d;
+    d.min_mass = o->min_mass; d.u_max = o->u_max; d.r_min = o->r_min; d.r_max = o->r_max; d.eps_r = o->eps_r;
+    d.eps_vr = o->eps_vr; d.eps_vn = o->eps_vn; d.tf_max = o->tf_max; d.w_nu = o->w_nu; d.w_tr = o->w_tr;
+    d.tol = o->tol; d.acc_tol = o->acceptable_tol; d.max_iter = o->max_iter; d.acc_iter = o->acceptable_iter;
+    d.n_refine = o->n_refine; d.pad = 0;
+    return d;
+}
+
+extern "C" void mpcx_default_solve_opts(mpcx_solve_opts *o)
+{
+    // reference defaults: optimizer.py:178-188; ipopt defaults: tol 1e-8, acceptable_tol 1e-6
+    o->min_mass = 0.1; o->u_max = 5.0; o->r_min = 0.99; o->r_max = 5.0; o->eps_r = 0.01;
+    o->eps_vr = 1e-5; o->eps_vn = 1e-5; o->tf_max = 5.0; o->w_nu = 1000.0; o->w_tr = 0.002;
+    o->tol = 1e-8; o->acceptable_tol = 1e-6; o->max_iter = 200; o->acceptable_iter = 10; o->n_refine = 1;
+}
+
+extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
+{
+    return (size_t)S * ws_doubles(K) * sizeof(double);
+}
+
+extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *stage, const double *xbar,
+                                    const double *ubar, const double *tf, const double *consts,
+                                    const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
+                                    double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                    void *workspace, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "solve: need S>=1, K>=3 and options");
+    if (!workspace) return ctx_fail(ctx, MPCX_E_BADARG, "solve: workspace of mpcx_solve_workspace_bytes(S,K) required");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    SolveArgs a;
+    a.S = S; a.K = K; a.stage = stage; a.xbar = xbar; a.ubar = ubar; a.tfbar = tf; a.consts = consts; a.r_des = r_des;
+    a.o = to_dev_opts(opts);
+    a.X = X; a.U = U; a.NU = NU; a.tf_out = tf_out; a.kkt = kkt; a.status = status; a.iters = iters;
+    a.ws = (double *)workspace; a.ws_stride = ws_doubles(K);
+    hipLaunchKernelGGL(solve_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, a);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                                       const double *tf, const double *consts, const double *r_des, int flags,
+                                       double max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                                       double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                       void *workspace, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (!workspace) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_step: workspace of mpcx_mpc_step_workspace_bytes(S,K) required");
+    // workspace = [stage records | int32 discretize status | solver workspace]
+    double *stage = (double *)workspace;
+    const size_t nstage = (size_t)S * (K - 1) * MPCX_STAGE_DOUBLES;
+    int32_t *dstat = (int32_t *)(stage + nstage);
+    double *sws = stage + nstage + ((size_t)S + 1) / 2 + 1;
+    int rc = mpcx_discretize_stages_dev(ctx, S, K, K, xbar, ubar, tf, consts, flags, max_step, stage, dstat, stream);
+    if (rc) return rc;
+    rc = mpcx_solve_batch_dev(ctx, S, K, stage, xbar, ubar, tf, consts, r_des, opts, X, U, NU, tf_out, status, iters,
+                              kkt, sws, stream);
+    if (rc) return rc;
+    merge_status_kernel_launch(S, dstat, status, (hipStream_t)stream);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" size_t mpcx_mpc_step_workspace_bytes(int S, int K)
+{
+    return ((size_t)S * (K - 1) * MPCX_STAGE_DOUBLES + ((size_t)S + 1) / 2 + 1) * sizeof(double) +
+           mpcx_solve_workspace_bytes(S, K);
+}
+
+extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                                   const double *tf, const double *consts, const double *r_des, int flags,
+                                   double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
+                                   double *tf_out, int32_t *status, int32_t *iters, double *kkt)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_step: need S>=1, K>=3 and options");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes(S, K));
+    if (!ws) return MPCX_E_NOMEM;
+    DeviceArena ar(ctx);
+    double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
+    double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K);
+    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = ar.alloc<double>(S), *dk = ar.alloc<double>(S);
+    int32_t *dst = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S);
+    if (ar.failed()) return ar.code();
+    int rc = mpcx_mpc_step_batch_dev(ctx, S, K, dx, du, dtf, dc, drd, flags, max_step, opts, dX, dU, dNU, dtfo, dst,
+                                     dit, dk, ws, ctx->stream);
+    if (rc) return rc;
+    ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
+    ar.download(tf_out, dtfo, S); ar.download(status, dst, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
+    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ar.failed() ? ar.code() : MPCX_OK;
+}
+
+extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,
+                                const double *Sigma, const double *xi, const double *xbar, const double *ubar,
+                                const double *tf, const double *consts, const double *r_des,
+                                const mpcx_solve_opts *opts, double *X, double *U, double *NU, double *tf_out,
+                                int32_t *status, int32_t *iters, double *kkt)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "solve: need S>=1, K>=3 and options");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    // pack the reference-shaped arrays into stage records on the host (tiny, O(S K) copies)
+    const size_t n = (size_t)S * (K - 1);
+    std::vector<double> st(n * MPCX_STAGE_DOUBLES);
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < K - 1; ++k) {
+            double *r = &st[((size_t)s * (K - 1) + k) * MPCX_STAGE_DOUBLES];
+            const size_t b = (size_t)s * (K - 1) + k;
+            for (int e = 0; e < 49; ++e) r[e] = A[b * 49 + e];
+            for (int e = 0; e < 21; ++e) { r[49 + e] = Bn[b * 21 + e]; r[70 + e] = Bp[b * 21 + e]; }
+            for (int i = 0; i < 7; ++i) {
+                r[91 + i] = Sigma[(size_t)s * 7 * (K - 1) + (size_t)i * (K - 1) + k];
+                r[98 + i] = xi[(size_t)s * 7 * (K - 1) + (size_t)i * (K - 1) + k];
+            }
+        }
+    void *ws = ctx_workspace(ctx, mpcx_solve_workspace_bytes(S, K));
+    if (!ws) return MPCX_E_NOMEM;
+    DeviceArena ar(ctx);
+    double *dst_ = ar.upload(st.data(), st.size());
+    double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
+    double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K);
+    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = ar.alloc<double>(S), *dk = ar.alloc<double>(S);
+    int32_t *dstat = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S);
+    if (ar.failed()) return ar.code();
+    int rc = mpcx_solve_batch_dev(ctx, S, K, dst_, dx, du, dtf, dc, drd, opts, dX, dU, dNU, dtfo, dstat, dit, dk, ws,
+                                  ctx->stream);
+    if (rc) return rc;
+    ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
+    ar.download(tf_out, dtfo, S); ar.download(status, dstat, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
+    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ar.failed() ? ar.code() : MPCX_OK;
+}

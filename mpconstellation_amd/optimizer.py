@@ -1,0 +1,171 @@
+"""Optimizer: drop-in for the reference class of the same name (reference optimizer.py:12-613).
+solve_OPT runs discretize -> constraint terms -> interior-point solve on the MI355X through libmpcx.so
+(mpcx_mpc_step_batch); there is no pyomo model and no ipopt subprocess, and no host fallback."""
+import numpy as np
+
+from . import _ffi
+
+DEFAULT_OPTIONS = {'min_mass': 0.1, 'u_lim': [0, 5], 'r_lim': [0.99, 5], 'r_des': 1, 'eps_r': 0.01,
+                   'eps_vr': 0.00001, 'eps_vn': 0.00001, 'eps_vt': 0.00001, 'tf_max': 5, 'w_nu': 1000, 'w_tr': 0.002}
+
+
+class SolveResult:
+    """What the reference keeps in self.model (a pyomo object) reduced to what its callers read."""
+
+    def __init__(self, X, U, NU, tf, status, iters, kkt):
+        self.X, self.U, self.NU, self.tf, self.status, self.iters, self.kkt = X, U, NU, tf, status, iters, kkt
+
+
+def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0,
+                   **solver):
+    """S independent satellite-MPC-steps (discretize + solve) on the device.
+    xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays."""
+    xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
+    S, _, K = xbar.shape
+    if xbar.shape[1] != 7 or ubar.shape != (S, 3, K):
+        raise ValueError("expected xbar (S,7,K) and ubar (S,3,K)")
+    tf = _ffi.as_f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (S,)))
+    r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
+    consts = _ffi.as_f64(consts)
+    opts = _ffi.make_solve_opts(options, **solver)
+    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); tfo = np.empty(S); kkt = np.empty(S)
+    status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
+    lib = _ffi.load(); ctx = _ffi.context(device)
+    import ctypes as C
+    rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
+                                 _ffi.dptr(r_des), _ffi.FLAG_J2 if include_J2 else 0, float(max_step), C.byref(opts),
+                                 _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
+                                 _ffi.iptr(iters), _ffi.dptr(kkt))
+    _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
+    return SolveResult(X, U, NU, tfo, status, iters, kkt)
+
+
+def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, **solver):
+    """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""
+    xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
+    S, _, K = xbar.shape
+    arrs = [_ffi.as_f64(a) for a in (A, Bp, Bn, Sigma, xi)]
+    tf = _ffi.as_f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (S,)))
+    r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
+    consts = _ffi.as_f64(consts)
+    opts = _ffi.make_solve_opts(options, **solver)
+    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); tfo = np.empty(S); kkt = np.empty(S)
+    status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
+    lib = _ffi.load(); ctx = _ffi.context(device)
+    import ctypes as C
+    rc = lib.mpcx_solve_batch(ctx, S, K, *[_ffi.dptr(a) for a in arrs], _ffi.dptr(xbar), _ffi.dptr(ubar),
+                              _ffi.dptr(tf), _ffi.dptr(consts), _ffi.dptr(r_des), C.byref(opts), _ffi.dptr(X),
+                              _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status), _ffi.iptr(iters),
+                              _ffi.dptr(kkt))
+    _ffi.check(rc, ctx, "mpcx_solve_batch")
+    return SolveResult(X, U, NU, tfo, status, iters, kkt)
+
+
+class Optimizer:
+    def __init__(self, x_bar, u_bar, nu_bar, tf, d, f, scale, verbose=True, shared_tf=None):
+        """Same arguments as the reference (optimizer.py:13-39).  With more than one satellite the
+        reference couples all of them through a single tf variable (:287); that mode is not implemented:
+        pass shared_tf=False to solve the satellites as independent problems (own tf each)."""
+        self.x_bar, self.u_bar, self.nu_bar = x_bar, u_bar, nu_bar
+        self.tf, self.d, self.f, self.scale = tf, d, f, scale
+        self.const = scale.get_normalized_constants()
+        self._N = len(x_bar)
+        self._K = x_bar[0].shape[1]
+        self.verbose = verbose
+        if self._N > 1 and shared_tf is not False:
+            raise NotImplementedError("one tf shared by several satellites (optimizer.py:287) is not implemented; "
+                                      "pass shared_tf=False for independent per-satellite problems")
+        self.result = None
+
+    @staticmethod
+    def skew(x):
+        return np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]])
+
+    def init_options(self, options):
+        return {**DEFAULT_OPTIONS, **options}
+
+    def get_constraint_terms(self):
+        """Host-side mirror of optimizer.py:80-170 (same keys, same per-satellite lists), including the
+        expression forms of :121-125 as written.  The device recomputes these terms inside the solve."""
+        keys = ['rbar_hat', 'ubar_hat', 'rf_hat', 'Vc', 'DrVc', 'DrVc_rbar', 'Vt', 'DrVt_DvVt', 'DrVt_DvVt_bar',
+                'Vr', 'DrVr_DvVr', 'DrVr_DvVr_bar', 'Vn', 'DrVn_DvVn', 'DrVn_DvVn_bar']
+        out = {k: [] for k in keys}
+        I = np.eye(3)
+        for i in range(self._N):
+            r = self.x_bar[i][0:3, -1]; v = self.x_bar[i][3:6, -1]
+            rv = np.concatenate([r, v])
+            rn = np.linalg.norm(r); h = np.cross(r, v); hn = np.linalg.norm(h)
+            r_hat = r / rn; h_hat = h / hn; t_hat = np.cross(h_hat, r_hat)
+            Dr_h = ((hn ** -1 * I) - (hn ** -3 * np.outer(h, h))) @ (-self.skew(v))
+            Dv_h = (hn ** -1 * I) - (hn ** -3 * np.outer(h, h)) @ (self.skew(r))
+            Dr_r = (rn ** -1 * I) - (rn ** -3 * np.outer(r, r))
+            Dr_t = (-self.skew(r_hat) @ Dr_h) + (self.skew(h_hat) @ Dr_r)
+            Dv_t = -self.skew(r_hat) @ Dv_h
+            rb = self.x_bar[i][0:3, :-1]
+            out['rbar_hat'].append(rb / np.linalg.norm(rb, axis=0))
+            ub = self.u_bar[i]; un = np.linalg.norm(ub, axis=0)
+            uh = np.zeros(ub.shape); m = un <= np.finfo(float).eps
+            with np.errstate(all='ignore'):
+                uh[:, m] = ub[:, m] / un[m]
+            out['ubar_hat'].append(uh)
+            out['rf_hat'].append(r_hat)
+            out['Vc'].append(np.sqrt(self.const.MU / rn))
+            DrVc = (-1 / 2) * (self.const.MU ** 0.5) * (rn ** (-5 / 2)) * r
+            out['DrVc'].append(DrVc); out['DrVc_rbar'].append(np.dot(DrVc, r))
+            out['Vt'].append(np.dot(v, t_hat))
+            g = np.concatenate([np.dot(v, Dr_t), np.dot(t_hat, I) + np.dot(v, Dv_t)])
+            out['DrVt_DvVt'].append(g); out['DrVt_DvVt_bar'].append(np.dot(g, rv))
+            out['Vr'].append(np.dot(v, r_hat))
+            g = np.concatenate([np.dot(v, Dr_r), np.dot(r_hat, I)])
+            out['DrVr_DvVr'].append(g); out['DrVr_DvVr_bar'].append(np.dot(g, rv))
+            out['Vn'].append(np.dot(v, h_hat))
+            g = np.concatenate([np.dot(v, Dr_h), np.dot(h_hat, I) + np.dot(v, Dv_h)])
+            out['DrVn_DvVn'].append(g); out['DrVn_DvVn_bar'].append(np.dot(g, rv))
+        return out
+
+    def solve_OPT(self, input_options={}, **solver):
+        """Transcribe-and-solve replacement (optimizer.py:219-613).  Extra keyword arguments are solver
+        controls (tol, acceptable_tol, max_iter, acceptable_iter, n_refine)."""
+        options = self.init_options(input_options)
+        if getattr(self.f, "__name__", "") != "satellite_dynamics":
+            raise NotImplementedError("only Simulator.satellite_dynamics is implemented on the device")
+        self.d._check_modes()
+        xbar = np.stack([np.asarray(x, dtype=np.float64) for x in self.x_bar])
+        ubar = np.stack([np.asarray(u, dtype=np.float64) for u in self.u_bar])
+        consts = np.tile(self.const.as_vector(), (self._N, 1))
+        self.result = mpc_step_batch(xbar, ubar, self.tf, consts, options['r_des'], options,
+                                     include_J2=self.d.include_J2, max_step=self.d.ivp_max_step,
+                                     device=getattr(self.d, "device", 0), **solver)
+        self.status = self.result.status
+        bad = [int(c) for c in self.result.status if c not in (0, 7)]
+        if bad and self.verbose:
+            print(f"WARNING: solve_OPT status {[_ffi.STATUS_TEXT.get(c, c) for c in bad]}")
+        return None
+
+    def get_solved_trajectory(self, s):
+        return self.result.X[s].copy()
+
+    def get_solved_tf(self, s):
+        return float(self.result.tf[s])
+
+    def get_solved_u(self, s):
+        return self.result.U[s].copy()
+
+    def get_solved_nu(self, s):
+        return self.result.NU[s].copy()
+
+    @staticmethod
+    def plot_normalized_thrust(x, u):
+        """Thrust in the RTN frame (optimizer.py:47-77); needs matplotlib."""
+        import matplotlib.pyplot as plt
+        u_rtn = np.zeros(u.shape)
+        for i in range(u.shape[1]):
+            r = x[0:3, i]; v = x[3:6, i]
+            r_hat = r / np.linalg.norm(r); h = np.cross(r, v); h_hat = h / np.linalg.norm(h)
+            R = np.vstack([r_hat, np.cross(h_hat, r_hat), h_hat])
+            u_rtn[:, i] = R @ u[:, i]
+        fig, ax = plt.subplots()
+        t = np.linspace(0, 1, u.shape[1])
+        for row, lab in zip(u_rtn, "rtn"):
+            ax.plot(t, row, label=lab)
+        ax.set_title('Normalized Thrust Commands'); plt.legend(); plt.show()

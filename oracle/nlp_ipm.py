@@ -1,0 +1,506 @@
+"""oracle/nlp_ipm.py -- CPU restatement of the solve half of the hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and
+only as the checker; the product (mpconstellation_amd/, libmpcx.so) never does.
+
+What is restated
+----------------
+* The NLP that Optimizer.solve_OPT transcribes with pyomo (reference optimizer.py:254-603):
+  variables :267-270,287; objective :300-325,355; dynamics/initial state :327-345,357,361; final
+  mass :351-352,363; thrust ball :379-381; radial min/max :384-395; final radius :398-403; radial /
+  normal velocity windows :406-416,432-446,466-467; exact tangential-velocity equality :492-517,577;
+  L1 slack of the virtual control :579-585; tf range :588; option defaults :178-188.
+* The solver it hands that NLP to is ipopt (third-party, unpinned, not installed here).  What is
+  restated of ipopt is its published primal-dual interior-point scheme (Waechter & Biegler, Math.
+  Prog. 106, 2006): slack form of the inequalities, relaxation of every bound by 1e-8*max(1,|b|)
+  (bound_relax_factor), slack/multiplier initialisation (bound_push 1e-2, multipliers 1),
+  fraction-to-the-boundary rule tau = max(0.99, 1-mu), monotone barrier update
+  mu <- max(tol/10, min(0.2 mu, mu^1.5)) once E_mu <= 10 mu, the scaled optimality error E_0 with
+  s_max = 100 and tol = 1e-8, multiplier safeguard kappa_Sigma = 1e10.
+
+PARITY UNPINNED at this boundary: the reference's own tests hold no numbers for solve_OPT and
+ipopt cannot be run here, so nothing below is checked against ipopt output.  It is checked by
+KKT residuals, by an independent dense Newton/KKT solve, and against scipy trust-constr on the
+full (un-eliminated, polynomial) NLP -- see tests/test_oracle_solver.py.
+
+Deliberate differences from ipopt's path (none changes the NLP or its KKT points)
+* start: the reference trajectory (x_bar, u_bar, nu=0, tf_bar); ipopt starts from zeros because
+  pyomo Vars carry no initial value.
+* the quartic equality (v.t)^2 = vt_des^2 |t|^2, t = (r x v) x r, equals |h|^2 (|h|^2 - vt_des^2 |r|^2)
+  with h = r x v; it is imposed as |v|^2 - (r.v)^2/|r|^2 - vt_des^2 = 0, which has the same zero set
+  for h != 0, r != 0 (see vt_poly / vt_reduced below and the test that compares them).
+* globalisation: backtracking on the 2-norm of the perturbed KKT residual with one step length for
+  primal and dual variables plus a N_-inf(1e-3) centrality neighbourhood, instead of ipopt's filter.
+* x_0 is eliminated (it is fixed by an equality), nu_{K-1}, t_{K-1} (which enter no dynamics row) are
+  reported as 0.
+* linear algebra: stage-wise Riccati recursion (see riccati_factor_solve) instead of MUMPS.
+"""
+import numpy as np
+
+DEFAULT_OPTIONS = dict(min_mass=0.1, u_lim=[0, 5], r_lim=[0.99, 5], r_des=1, eps_r=0.01, eps_vr=0.00001,
+                       eps_vn=0.00001, eps_vt=0.00001, tf_max=5, w_nu=1000, w_tr=0.002)   # optimizer.py:178-188
+
+ST_OK, ST_MAXITER, ST_NUMERIC, ST_ACCEPTABLE = 0, 5, 6, 7
+BOUND_RELAX = 1e-8
+BOUND_PUSH = 1e-2
+KAPPA_SIGMA = 1e10
+GAMMA_NBHD = 1e-3
+TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
+N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
+
+
+def vt_poly(r, v, vt_des):
+    """optimizer.py:492-517 as written: (v.t)^2 - vt_des^2 |t|^2 with h = r x v, t = h x r."""
+    h = np.cross(r, v); t = np.cross(h, r)
+    return (v @ t) ** 2 - vt_des ** 2 * (t @ t)
+
+
+def vt_reduced(r, v, vt_des):
+    """c~ = |v|^2 - (r.v)^2/|r|^2 - vt_des^2 with gradient (6,) and Hessian (6,6)."""
+    q = r @ r; rv = r @ v
+    c = v @ v - rv * rv / q - vt_des ** 2
+    gr = -2 * rv * v / q + 2 * rv * rv * r / q ** 2
+    gv = 2 * v - 2 * rv * r / q
+    I = np.eye(3)
+    Hvv = 2 * I - 2 * np.outer(r, r) / q
+    Hrr = (-2 * np.outer(v, v) / q + 4 * rv * (np.outer(v, r) + np.outer(r, v)) / q ** 2
+           + 2 * rv * rv * I / q ** 2 - 8 * rv * rv * np.outer(r, r) / q ** 3)
+    Hrv = -2 * np.outer(v, r) / q - 2 * rv * I / q + 4 * rv * np.outer(r, r) / q ** 2
+    return c, np.concatenate([gr, gv]), np.block([[Hrr, Hrv], [Hrv.T, Hvv]])
+
+
+class MpcProblem:
+    """One satellite's SCP subproblem.  stage = dict(A (K-1,7,7), Bp, Bn (K-1,7,3), Sigma, xi (7,K-1));
+    terms = output of Optimizer.get_constraint_terms for this satellite (optimizer.py:80-170)."""
+
+    def __init__(self, xbar, ubar, tfbar, mu_grav, stage, terms, options=None):
+        o = {**DEFAULT_OPTIONS, **(options or {})}
+        self.o = o
+        self.xbar = np.array(xbar, dtype=float); self.ubar = np.array(ubar, dtype=float)
+        self.tfbar = float(tfbar)
+        self.K = K = self.xbar.shape[1]
+        self.A, self.Bp, self.Bn = stage["A"], stage["Bp"], stage["Bn"]
+        self.Sig, self.xi = stage["Sigma"], stage["xi"]
+        self.vt_des = np.sqrt(mu_grav / o["r_des"])                   # optimizer.py:283
+        rl = lambda b: b + BOUND_RELAX * max(1.0, abs(b))
+        self.b_u = rl(o["u_lim"][1] ** 2)                             # :379-381
+        self.b_rmax = rl(o["r_lim"][1] ** 2)                          # :393-395
+        self.b_rmin = rl(-o["r_lim"][0])                              # :384-391  (-rhat.r <= -r_min)
+        self.rbar_hat = np.array(terms["rbar_hat"])                   # (3,K-1)
+        aT = np.zeros((6, 7)); bT = np.zeros(6)
+        aT[0, :3] = -np.asarray(terms["rf_hat"]); bT[0] = rl(-(o["r_des"] - o["eps_r"]))      # :398-402
+        for row, (V, D, Db, eps) in zip((1, 3), (("Vr", "DrVr_DvVr", "DrVr_DvVr_bar", "eps_vr"),
+                                                 ("Vn", "DrVn_DvVn", "DrVn_DvVn_bar", "eps_vn"))):
+            g = np.asarray(terms[D]); c0 = terms[V] - terms[Db]
+            aT[row, :6] = g; bT[row] = rl(o[eps] - c0)                # :406-410 / :436-440
+            aT[row + 1, :6] = -g; bT[row + 1] = rl(o[eps] + c0)       # :412-416 / :442-446
+        aT[5, 6] = -1.0; bT[5] = rl(-o["min_mass"])                   # :351-352
+        self.aT, self.bT = aT, bT
+        self.b_rfmax = rl((o["r_des"] + o["eps_r"]) ** 2)             # :403
+        self.b_tf = np.array([rl(0.0), rl(o["tf_max"])])              # :588
+        self.w_tr, self.w_nu = o["w_tr"], o["w_nu"]
+
+    # ---- NLP functions ------------------------------------------------------------------
+    def objective(self, X, U, T, tf):                                 # :300-325
+        return tf + self.w_nu * T.sum() + self.w_tr * (((X - self.xbar) ** 2).sum()
+                                                       + ((U - self.ubar) ** 2).sum() + (tf - self.tfbar) ** 2)
+
+    def dyn_residual(self, X, U, NU, tf):                             # :327-342
+        K = self.K
+        e = np.zeros((7, K - 1))
+        for k in range(K - 1):
+            e[:, k] = X[:, k + 1] - (self.A[k] @ X[:, k] + self.Bn[k] @ U[:, k] + self.Bp[k] @ U[:, k + 1]
+                                     + self.Sig[:, k] * tf + self.xi[:, k] + NU[:, k])
+        return e
+
+    def ineq(self, X, U, NU, T, tf):
+        """all inequality constraints in g(w) <= 0 form (relaxed bounds), keyed by family"""
+        K = self.K
+        return {
+            "u": (U ** 2).sum(0) - self.b_u,                                             # k = 0..K-1
+            "rmax": (X[:3, 1:] ** 2).sum(0) - self.b_rmax,                               # k = 1..K-1
+            "rmin": -(self.rbar_hat[:, 1:] * X[:3, 1:K - 1]).sum(0) - self.b_rmin,       # k = 1..K-2
+            "term": self.aT @ X[:, K - 1] - self.bT,
+            "rfmax": np.array([(X[:3, K - 1] ** 2).sum() - self.b_rfmax]),
+            "tp": NU - T, "tn": -NU - T,                                                 # :579-585
+            "tf": np.array([-tf, tf]) - self.b_tf,
+        }
+
+
+class Iterate:
+    def copy(self):
+        n = Iterate(); n.__dict__.update(self.__dict__); return n
+
+
+def initial_iterate(P):
+    K = P.K; it = Iterate()
+    it.X = P.xbar.copy(); it.U = P.ubar.copy(); it.tf = P.tfbar
+    it.NU = np.zeros((7, K - 1)); it.T = np.zeros((7, K - 1))
+    it.lam = np.zeros((7, K - 1)); it.lam_vt = 0.0
+    g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
+    bnd = {"u": P.b_u, "rmax": P.b_rmax, "rmin": P.b_rmin, "term": P.bT, "rfmax": P.b_rfmax, "tp": 0.0,
+           "tn": 0.0, "tf": P.b_tf}
+    it.s = {k: np.maximum(-v, BOUND_PUSH * np.maximum(1.0, np.abs(bnd[k]))) for k, v in g.items()}
+    it.z = {k: np.ones_like(v) for k, v in g.items()}
+    return it
+
+
+def lagrangian_gradient(P, it, zz, with_lambda=True):
+    """gradient of f + lam^T c + zz^T g with respect to (x_k, u_k, tf, nu_k, t_k)"""
+    K = P.K; X, U = it.X, it.U
+    gx = 2 * P.w_tr * (X - P.xbar); gu = 2 * P.w_tr * (U - P.ubar); gtf = 1 + 2 * P.w_tr * (it.tf - P.tfbar)
+    cv, gv, Hv = vt_reduced(X[:3, K - 1], X[3:6, K - 1], P.vt_des)
+    if with_lambda:
+        lam = it.lam
+        for k in range(K - 1):
+            gx[:, k + 1] += lam[:, k]; gx[:, k] -= P.A[k].T @ lam[:, k]
+            gu[:, k] -= P.Bn[k].T @ lam[:, k]; gu[:, k + 1] -= P.Bp[k].T @ lam[:, k]
+            gtf -= P.Sig[:, k] @ lam[:, k]
+        gx[:6, K - 1] += it.lam_vt * gv
+    gu += 2 * U * zz["u"][None, :]
+    gx[:3, 1:] += 2 * X[:3, 1:] * zz["rmax"][None, :]
+    gx[:3, 1:K - 1] += -P.rbar_hat[:, 1:] * zz["rmin"][None, :]
+    gx[:, K - 1] += P.aT.T @ zz["term"]
+    gx[:3, K - 1] += 2 * X[:3, K - 1] * zz["rfmax"][0]
+    gtf += -zz["tf"][0] + zz["tf"][1]
+    gnu = zz["tp"] - zz["tn"] - (it.lam if with_lambda else 0.0)
+    gt = P.w_nu - zz["tp"] - zz["tn"]
+    return gx, gu, gtf, gnu, gt, cv, gv, Hv
+
+
+def residual_vectors(P, it, mu):
+    """the perturbed KKT residual F_mu as a list of arrays"""
+    gx, gu, gtf, gnu, gt, cv, _, _ = lagrangian_gradient(P, it, it.z)
+    g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
+    e = P.dyn_residual(it.X, it.U, it.NU, it.tf)
+    dual = [gx[:, 1:], gu, np.array([gtf]), gnu, gt]
+    prim = [e, np.array([cv])] + [g[k] + it.s[k] for k in g]
+    comp = [it.s[k] * it.z[k] - mu for k in g]
+    return dual, prim, comp
+
+
+def optimality_error(P, it, mu, s_max=100.0):
+    """ipopt's scaled E_mu (Waechter-Biegler eq. (5)-(6))"""
+    dual, prim, comp = residual_vectors(P, it, mu)
+    zsum = sum(np.abs(v).sum() for v in it.z.values()); nz = sum(v.size for v in it.z.values())
+    lsum = np.abs(it.lam).sum() + abs(it.lam_vt); nl = it.lam.size + 1
+    sd = max(s_max, (zsum + lsum) / (nz + nl)) / s_max
+    sc = max(s_max, zsum / nz) / s_max
+    d = max(np.abs(v).max() for v in dual); p = max(np.abs(v).max() for v in prim)
+    c = max(np.abs(v).max() for v in comp)
+    return max(d / sd, p, c / sc), d, p, c
+
+
+def residual_norm(P, it, mu):
+    dual, prim, comp = residual_vectors(P, it, mu)
+    return np.sqrt(sum((v ** 2).sum() for v in dual + prim + comp))
+
+
+# ------------------------------------------------------------------------------------------
+# Newton system: blocks, Riccati solve, dense cross-check
+# ------------------------------------------------------------------------------------------
+def newton_blocks(P, it, mu, delta_w=0.0):
+    """Reduced Newton/KKT system after eliminating slacks, inequality multipliers and t.
+    Unknowns: dx_k (k>=1), du_k, dtf, dnu_k, new multipliers lam_k and lam_vt."""
+    K = P.K; X, U = it.X, it.U
+    g = P.ineq(it.X, it.U, it.NU, it.T, it.tf); s, z = it.s, it.z
+    sig = {k: z[k] / s[k] for k in g}
+    zhat = {k: mu / s[k] + sig[k] * (g[k] + s[k]) for k in g}
+    gx, gu, gtf, gnu, gt, cv, gv, Hv = lagrangian_gradient(P, it, zhat, with_lambda=False)
+    Wx = np.zeros((K, 7, 7)); Wu = np.zeros((K, 3, 3))
+    for k in range(K):
+        Wx[k] = (2 * P.w_tr + delta_w) * np.eye(7)
+        Wu[k] = (2 * P.w_tr + delta_w + 2 * z["u"][k]) * np.eye(3) + sig["u"][k] * 4 * np.outer(U[:, k], U[:, k])
+    for k in range(1, K - 1):
+        r = X[:3, k]; rh = P.rbar_hat[:, k]
+        Wx[k][:3, :3] += (2 * z["rmax"][k - 1] * np.eye(3) + sig["rmax"][k - 1] * 4 * np.outer(r, r)
+                          + sig["rmin"][k - 1] * np.outer(rh, rh))
+    r = X[:3, K - 1]
+    WxK_soft = Wx[K - 1].copy()
+    WxK_soft[:3, :3] += 2 * (z["rmax"][K - 2] + z["rfmax"][0]) * np.eye(3)
+    WxK_soft[:6, :6] += it.lam_vt * Hv
+    a2r = np.zeros(7); a2r[:3] = 2 * r
+    # terminal rank-1 barrier terms (direction, weight, gradient coefficient)
+    term = [(P.aT[0], sig["term"][0], zhat["term"][0]),
+            (P.aT[1], sig["term"][1] + sig["term"][2], zhat["term"][1] - zhat["term"][2]),
+            (P.aT[3], sig["term"][3] + sig["term"][4], zhat["term"][3] - zhat["term"][4]),
+            (P.aT[5], sig["term"][5], zhat["term"][5]),
+            (a2r, sig["rmax"][K - 2] + sig["rfmax"][0], zhat["rmax"][K - 2] + zhat["rfmax"][0])]
+    # gx so far contains the full gradient coefficient of every terminal barrier term; take it out
+    gxK_soft = gx[:, K - 1].copy()
+    for a, w, gh in term: gxK_soft -= gh * a
+    a_ = sig["tp"] + sig["tn"]; b_ = sig["tn"] - sig["tp"]
+    D = 4 * sig["tp"] * sig["tn"] / a_
+    avt = np.zeros(7); avt[:6] = gv
+    return dict(Wx=Wx, Wu=Wu, WxK_soft=WxK_soft, gxK_soft=gxK_soft, term=term, Wtf=2 * P.w_tr + delta_w + sig["tf"].sum(),
+                D=D, rho=gnu - (b_ / a_) * gt, gx=gx, gu=gu, gtf=gtf, e=P.dyn_residual(it.X, it.U, it.NU, it.tf),
+                cv=cv, avt=avt, Hv=Hv, a_=a_, b_=b_, gt=gt, g=g, sig=sig, zhat=zhat)
+
+
+def riccati_factor(P, nb):
+    """Backward Riccati sweep in the shifted state y_k = x_k - Bp_{k-1} u_k (absorbs the first-order
+    hold), nu_k eliminated per stage by a 7x7 Cholesky.  Terminal Hessian: soft part + capped share of
+    the rank-1 barrier weights + augmented-Lagrangian term gamma a_vt a_vt^T (exact, see solve)."""
+    K = P.K; Wx, Wu, D = nb["Wx"], nb["Wu"], nb["D"]
+    WxK = nb["WxK_soft"].copy()
+    win = []
+    for a, w, gh in nb["term"]:
+        wi = min(w, TERM_CAP); win.append(wi)
+        WxK += wi * np.outer(a, a)
+    avt = nb["avt"]
+    gam = (1.0 + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt)
+    WxK += gam * np.outer(avt, avt)
+    F = dict(P=np.zeros((K, 7, 7)), L=np.zeros((K, 7, 7)), Wl=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
+             Quu_inv=np.zeros((K, 3, 3)), Quy=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)), win=win, gam=gam, WxK=WxK)
+    for k in range(K - 1, -1, -1):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        Wxk = WxK if k == K - 1 else Wx[k]
+        if k <= K - 2:
+            Pn = F["P"][k + 1]
+            L = np.linalg.cholesky(np.diag(D[:, k]) + Pn)            # raises LinAlgError when not PD
+            Wl = np.linalg.solve(L, Pn)
+            Pt = Pn - Wl.T @ Wl; Pt = 0.5 * (Pt + Pt.T)
+            Ah = P.A[k]; Bh = P.A[k] @ Bpm + P.Bn[k]
+            F["L"][k] = L; F["Wl"][k] = Wl
+        else:
+            Pt = np.zeros((7, 7)); Ah = np.zeros((7, 7)); Bh = np.zeros((7, 3))
+        Quu = Wu[k] + Bpm.T @ Wxk @ Bpm + Bh.T @ Pt @ Bh
+        Quy = Bpm.T @ Wxk + Bh.T @ Pt @ Ah
+        np.linalg.cholesky(Quu)
+        Qi = np.linalg.inv(Quu)
+        Pk = Wxk + Ah.T @ Pt @ Ah - Quy.T @ Qi @ Quy
+        F["P"][k] = 0.5 * (Pk + Pk.T); F["Pt"][k] = Pt; F["Quu_inv"][k] = Qi; F["Quy"][k] = Quy; F["Bh"][k] = Bh
+    return F
+
+
+def riccati_channel(P, nb, F, gx, gu, rho, aff):
+    """one linear-term sweep (backward + forward) for given gradients / affine dynamics terms"""
+    K = P.K; D = nb["D"]
+    p = np.zeros((K, 7)); qu = np.zeros((K, 3))
+    for k in range(K - 1, -1, -1):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        if k <= K - 2:
+            pt = p[k + 1] - F["Wl"][k].T @ np.linalg.solve(F["L"][k], rho[:, k] + p[k + 1])
+            t = pt + F["Pt"][k] @ aff[:, k]
+            Ah = P.A[k]
+        else:
+            t = np.zeros(7); Ah = np.zeros((7, 7))
+        qu[k] = gu[:, k] + Bpm.T @ gx[:, k] + F["Bh"][k].T @ t
+        p[k] = gx[:, k] + Ah.T @ t - F["Quy"][k].T @ (F["Quu_inv"][k] @ qu[k])
+    X = np.zeros((7, K)); U = np.zeros((3, K)); NU = np.zeros((7, K - 1)); LAM = np.zeros((7, K - 1))
+    y = np.zeros(7)
+    for k in range(K):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        u = -F["Quu_inv"][k] @ (F["Quy"][k] @ y + qu[k])
+        U[:, k] = u; X[:, k] = y + Bpm @ u
+        if k <= K - 2:
+            yh = P.A[k] @ y + F["Bh"][k] @ u + aff[:, k]
+            rhs = rho[:, k] + p[k + 1] + F["P"][k + 1] @ yh
+            nu = -np.linalg.solve(F["L"][k].T, np.linalg.solve(F["L"][k], rhs))
+            NU[:, k] = nu; LAM[:, k] = D[:, k] * nu + rho[:, k]
+            y = yh + nu
+    return X, U, NU, LAM
+
+
+def riccati_solve(P, nb, F, rhs):
+    """Solve the reduced KKT system for a right-hand side
+    rhs = dict(gx (7,K), gu (3,K), rho (7,K-1), aff (7,K-1), gtf, rvt, gterm (N_TERM,)).
+    The border unknowns are dtf, the multiplier of the vt row and, per terminal rank-1 barrier term,
+    zeta_j = w_excess_j a_j.dx_K + gterm_excess_j."""
+    K = P.K
+    Z7 = np.zeros((7, K)); Z3 = np.zeros((3, K)); Zn = np.zeros((7, K - 1))
+    term = nb["term"]; win = F["win"]; avt = nb["avt"]
+    gx0 = rhs["gx"].copy()
+    wex = []; gex = []
+    for j, (a, w, _) in enumerate(term):
+        share = win[j] / w if w > 0 else 1.0
+        gx0[:, K - 1] += rhs["gterm"][j] * share * a
+        wex.append(w - win[j]); gex.append(rhs["gterm"][j] * (1.0 - share))
+    gx0[:, K - 1] -= F["gam"] * rhs["rvt"] * avt                      # AL term: gamma (a.dx - rvt) a
+    chans = [riccati_channel(P, nb, F, gx0, rhs["gu"], rhs["rho"], rhs["aff"]),
+             riccati_channel(P, nb, F, Z7, Z3, Zn, P.Sig)]
+    vecs = [avt] + [a for (a, w, gh) in term]
+    for a in vecs:
+        g1 = Z7.copy(); g1[:, K - 1] = a
+        chans.append(riccati_channel(P, nb, F, g1, Z3, Zn, Zn))
+    nbd = 2 + N_TERM
+    Mb = np.zeros((nbd, nbd)); rb = np.zeros(nbd)
+    Mb[0, 0] = nb["Wtf"]
+    for c in range(1, 1 + nbd): Mb[0, c - 1] -= (P.Sig * chans[c][3]).sum()
+    rb[0] = -rhs["gtf"] + (P.Sig * chans[0][3]).sum()
+    for i, a in enumerate(vecs):
+        for c in range(1, 1 + nbd): Mb[1 + i, c - 1] += a @ chans[c][0][:, K - 1]
+        rb[1 + i] = -(a @ chans[0][0][:, K - 1])
+    rb[1] += rhs["rvt"]
+    for j in range(N_TERM):
+        Mb[2 + j, :] *= wex[j]; rb[2 + j] *= wex[j]
+        Mb[2 + j, 2 + j] -= 1.0; rb[2 + j] -= gex[j]
+    sol = np.linalg.solve(Mb, rb)
+    comb = lambda i: chans[0][i] + sum(sol[c - 1] * chans[c][i] for c in range(1, 1 + nbd))
+    return dict(X=comb(0), U=comb(1), NU=comb(2), lam=comb(3), tf=sol[0], lam_vt=sol[1])
+
+
+def reduced_residual(P, nb, it, d):
+    """right-hand side minus reduced-KKT-matrix times d, in the layout riccati_solve takes"""
+    K = P.K
+    dX, dU, dtf, dNU, dl, dlv = d["X"], d["U"], d["tf"], d["NU"], d["lam"], d["lam_vt"]
+    Wx, Wu = nb["Wx"], nb["Wu"]
+    gx = np.zeros((7, K)); gu = np.zeros((3, K))
+    for k in range(1, K):
+        if k == K - 1:
+            v = nb["WxK_soft"] @ dX[:, k] + nb["avt"] * (it.lam_vt + dlv)
+            grad = nb["gxK_soft"]
+        else:
+            v = Wx[k] @ dX[:, k]; grad = nb["gx"][:, k]
+        v = v + (it.lam[:, k - 1] + dl[:, k - 1])
+        if k <= K - 2: v = v - P.A[k].T @ (it.lam[:, k] + dl[:, k])
+        gx[:, k] = grad + v
+    gterm = np.array([gh + w * (a @ dX[:, K - 1]) for (a, w, gh) in nb["term"]])
+    gtf = nb["gtf"] + nb["Wtf"] * dtf
+    for k in range(K):
+        v = Wu[k] @ dU[:, k]
+        if k <= K - 2: v = v - P.Bn[k].T @ (it.lam[:, k] + dl[:, k])
+        if k >= 1: v = v - P.Bp[k - 1].T @ (it.lam[:, k - 1] + dl[:, k - 1])
+        gu[:, k] = nb["gu"][:, k] + v
+    rho = nb["rho"] + nb["D"] * dNU - (it.lam + dl)
+    aff = np.zeros((7, K - 1))
+    for k in range(K - 1):
+        gtf -= P.Sig[:, k] @ (it.lam[:, k] + dl[:, k])
+        aff[:, k] = -nb["e"][:, k] - (dX[:, k + 1] - P.A[k] @ dX[:, k] - P.Bn[k] @ dU[:, k]
+                                      - P.Bp[k] @ dU[:, k + 1] - P.Sig[:, k] * dtf - dNU[:, k])
+    rvt = -nb["cv"] - nb["avt"] @ dX[:, K - 1]
+    return dict(gx=gx, gu=gu, rho=rho, aff=aff, gtf=gtf, rvt=rvt, gterm=gterm)
+
+
+def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
+    nb = newton_blocks(P, it, mu, delta_w)
+    nb["lam_vt_cur"] = it.lam_vt
+    K = P.K
+    F = riccati_factor(P, nb)
+    zero = dict(X=np.zeros((7, K)), U=np.zeros((3, K)), NU=np.zeros((7, K - 1)), tf=0.0,
+                lam=-it.lam.copy(), lam_vt=-it.lam_vt)             # so that lam + dlam = 0: rhs has no multipliers
+    d = zero
+    for _ in range(1 + n_refine):
+        rhs = reduced_residual(P, nb, it, d)
+        c = riccati_solve(P, nb, F, rhs)
+        d = dict(X=d["X"] + c["X"], U=d["U"] + c["U"], NU=d["NU"] + c["NU"], tf=d["tf"] + c["tf"],
+                 lam=d["lam"] + c["lam"], lam_vt=d["lam_vt"] + c["lam_vt"])
+    return finish_direction(P, it, nb, d)
+
+
+def finish_direction(P, it, nb, d):
+    """back-substitution for dt, ds, dz"""
+    K = P.K; X, U = it.X, it.U
+    d["T"] = (-nb["gt"] - nb["b_"] * d["NU"]) / nb["a_"]
+    dg = {"u": (2 * U * d["U"]).sum(0),
+          "rmax": (2 * X[:3, 1:] * d["X"][:3, 1:]).sum(0),
+          "rmin": -(P.rbar_hat[:, 1:] * d["X"][:3, 1:K - 1]).sum(0),
+          "term": P.aT @ d["X"][:, K - 1],
+          "rfmax": np.array([(2 * X[:3, K - 1] * d["X"][:3, K - 1]).sum()]),
+          "tp": d["NU"] - d["T"], "tn": -d["NU"] - d["T"],
+          "tf": np.array([-d["tf"], d["tf"]])}
+    g, sig, zhat = nb["g"], nb["sig"], nb["zhat"]
+    d["s"] = {k: -(g[k] + it.s[k]) - dg[k] for k in g}
+    d["z"] = {k: zhat[k] + sig[k] * dg[k] - it.z[k] for k in g}
+    return d
+
+
+def newton_direction_dense(P, it, mu, delta_w=0.0):
+    """Independent cross-check of newton_direction: assemble the reduced KKT matrix densely
+    (terminal barrier terms inside the Hessian, no border, no AL term) and call LAPACK."""
+    nb = newton_blocks(P, it, mu, delta_w)
+    K = P.K
+    Wx = nb["Wx"].copy(); Wx[K - 1] = nb["WxK_soft"].copy()
+    gx = nb["gx"].copy()
+    for a, w, gh in nb["term"]: Wx[K - 1] += w * np.outer(a, a)
+    nx = 7 * (K - 1); nu_ = 3 * K; npr = nx + nu_ + 1; nd = 7 * (K - 1) + 1
+    M = np.zeros((npr + nd, npr + nd)); rhs = np.zeros(npr + nd)
+    ix = lambda k: slice(7 * (k - 1), 7 * k)
+    iu = lambda k: slice(nx + 3 * k, nx + 3 * k + 3)
+    itf = nx + nu_
+    il = lambda k: slice(npr + 7 * k, npr + 7 * k + 7)
+    ivt = npr + 7 * (K - 1)
+    for k in range(1, K): M[ix(k), ix(k)] = Wx[k]; rhs[ix(k)] = -gx[:, k]
+    for k in range(K): M[iu(k), iu(k)] = nb["Wu"][k]; rhs[iu(k)] = -nb["gu"][:, k]
+    M[itf, itf] = nb["Wtf"]; rhs[itf] = -nb["gtf"]
+    for k in range(K - 1):
+        J = np.zeros((7, npr)); J[:, ix(k + 1)] = np.eye(7)
+        if k >= 1: J[:, ix(k)] = -P.A[k]
+        J[:, iu(k)] = -P.Bn[k]; J[:, iu(k + 1)] = -P.Bp[k]; J[:, itf] = -P.Sig[:, k]
+        M[il(k), :npr] = J; M[:npr, il(k)] = J.T
+        M[il(k), il(k)] = -np.diag(1.0 / nb["D"][:, k])
+        rhs[il(k)] = -nb["e"][:, k] - nb["rho"][:, k] / nb["D"][:, k]
+    M[ivt, ix(K - 1)] = nb["avt"]; M[ix(K - 1), ivt] = nb["avt"]; rhs[ivt] = -nb["cv"]
+    sol = np.linalg.solve(M, rhs)
+    d = dict(X=np.zeros((7, K)), U=sol[nx:nx + nu_].reshape(K, 3).T.copy(), tf=sol[itf])
+    d["X"][:, 1:] = sol[:nx].reshape(K - 1, 7).T
+    lam_new = sol[npr:npr + 7 * (K - 1)].reshape(K - 1, 7).T
+    d["NU"] = (lam_new - nb["rho"]) / nb["D"]
+    d["lam"] = lam_new - it.lam; d["lam_vt"] = sol[ivt] - it.lam_vt
+    ev = np.linalg.eigvalsh(M)
+    d["inertia_ok"] = bool((ev > 0).sum() == npr and (ev < 0).sum() == nd)
+    return finish_direction(P, it, nb, d)
+
+
+# ------------------------------------------------------------------------------------------
+# Interior-point iteration
+# ------------------------------------------------------------------------------------------
+def step(it, d, a):
+    n = it.copy()
+    n.X = it.X + a * d["X"]; n.U = it.U + a * d["U"]; n.tf = it.tf + a * d["tf"]
+    n.NU = it.NU + a * d["NU"]; n.T = it.T + a * d["T"]
+    n.lam = it.lam + a * d["lam"]; n.lam_vt = it.lam_vt + a * d["lam_vt"]
+    n.s = {k: it.s[k] + a * d["s"][k] for k in it.s}
+    n.z = {k: it.z[k] + a * d["z"][k] for k in it.z}
+    return n
+
+
+def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=10, n_refine=1, dense=False,
+          verbose=False):
+    """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective)."""
+    it = initial_iterate(P)
+    mu = 0.1
+    n_acc = 0; status = ST_MAXITER; k_it = 0
+    for k_it in range(max_iter + 1):
+        E0 = optimality_error(P, it, 0.0)[0]
+        if verbose: print(f"it {k_it:3d} mu {mu:.1e} E0 {E0:.2e} tf {it.tf:.8f}")
+        if not np.isfinite(E0): status = ST_NUMERIC; break
+        if E0 <= tol: status = ST_OK; break
+        n_acc = n_acc + 1 if E0 <= acceptable_tol else 0
+        if n_acc >= acceptable_iter: status = ST_ACCEPTABLE; break
+        if k_it == max_iter: status = ST_ACCEPTABLE if E0 <= acceptable_tol else ST_MAXITER; break
+        while optimality_error(P, it, mu)[0] <= 10 * mu and mu > tol / 10:
+            mu = max(tol / 10, min(0.2 * mu, mu ** 1.5))
+        d = None; dw = 0.0
+        for trial in range(10):
+            try:
+                d = newton_direction_dense(P, it, mu, dw) if dense else newton_direction(P, it, mu, dw, n_refine if dw == 0 else 0)
+                if all(np.isfinite(d[k]).all() for k in ("X", "U", "NU")) and np.isfinite(d["tf"]): break
+                d = None
+            except np.linalg.LinAlgError:
+                d = None
+            dw = 1e-4 if dw == 0.0 else dw * 10
+        if d is None: status = ST_NUMERIC; break
+        tau = max(0.99, 1 - mu)
+        a = 1.0
+        for v, dv in ((it.s, d["s"]), (it.z, d["z"])):
+            for k in v:
+                neg = dv[k] < 0
+                if neg.any(): a = min(a, (-tau * v[k][neg] / dv[k][neg]).min())
+        r0 = residual_norm(P, it, mu)
+        for ls in range(30):
+            n = step(it, d, a)
+            prod = np.concatenate([(n.s[k] * n.z[k]).ravel() for k in n.s])
+            if residual_norm(P, n, mu) <= (1 - 1e-4 * a) * r0 and prod.min() >= GAMMA_NBHD * min(mu, prod.mean()):
+                break
+            a *= 0.5
+        it = step(it, d, a)
+        g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
+        for k in it.s:
+            it.s[k] = np.maximum(it.s[k], -g[k])                                        # slack reset
+            it.z[k] = np.maximum(np.minimum(it.z[k], KAPPA_SIGMA * mu / it.s[k]), mu / (KAPPA_SIGMA * it.s[k]))
+    K = P.K
+    NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
+    T = np.zeros((7, K)); T[:, :K - 1] = it.T
+    return dict(X=it.X, U=it.U, NU=NU, T=T, tf=it.tf, status=status, iters=k_it,
+                kkt=optimality_error(P, it, 0.0)[0], objective=P.objective(it.X, it.U, it.T, it.tf), iterate=it)
