@@ -143,6 +143,27 @@ int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, con
                             double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
                             void *workspace, void *stream);
 
+/* thrust laws of the reference's controllers (control.py) */
+#define MPCX_CTRL_ZERO 0        /* Controller.get_u_func            control.py:20-29  */
+#define MPCX_CTRL_CONSTANT 1    /* ConstantThrustController          control.py:37-53  ctrl_vec [S][3]      */
+#define MPCX_CTRL_TANGENTIAL 2  /* ConstantTangentialThrustController control.py:55-84 ctrl_vec [S] magnitude */
+#define MPCX_CTRL_SEQUENCE 3    /* SequenceController (FOH playback) control.py:86-143 ctrl_vec [S][3][Ku], end_tau [S] */
+
+/*
+ * Replaces Simulator.get_trajectory_ODE (simulator.py:164-189) for S satellites: scipy
+ * solve_ivp(RK45, rtol 1e-3, atol 1e-6, max_step, t_eval=linspace(0,1,n_eval)) of
+ * Simulator.satellite_dynamics (simulator.py:116-161, flags = MPCX_FLAG_DRAG|MPCX_FLAG_J2) under a
+ * thrust law u(y, tau).  y0 [S][7] normalised states, y_out [S][7][n_eval] (= sol.y per satellite).
+ */
+int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                         const double *consts, int flags, int ctrl_kind, const double *ctrl_vec, int Ku,
+                         const double *end_tau, double max_step, double *y_out, int32_t *status,
+                         int32_t *nsteps);
+int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                             const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
+                             int Ku, const double *end_tau, double max_step, double *y_out,
+                             int32_t *status, int32_t *nsteps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

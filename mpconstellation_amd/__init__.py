@@ -1,9 +1,15 @@
 """mpconstellation_amd -- MI355X-native batched constellation MPC (hot path of
-rgovindjee/mpconstellation: linearise/discretise + per-satellite finite-horizon solve)."""
+rgovindjee/mpconstellation: linearise/discretise + per-satellite finite-horizon solve, plus the
+nonlinear rollouts either side of it), behind the reference's Python API."""
 from .constants import Constants
 from .satellite import Satellite
 from .satellite_scale import SatelliteScale
 from .linearize_discretize import Discretizer
 from .optimizer import Optimizer, mpc_step_batch, solve_batch
+from .control import (Controller, ConstantThrustController, ConstantTangentialThrustController,
+                      SequenceController, OptimalController)
+from .simulator import Simulator, propagate_batch
 
-__all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer", "Optimizer", "mpc_step_batch", "solve_batch"]
+__all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer", "Optimizer", "mpc_step_batch", "solve_batch",
+           "Controller", "ConstantThrustController", "ConstantTangentialThrustController", "SequenceController",
+           "OptimalController", "Simulator", "propagate_batch"]

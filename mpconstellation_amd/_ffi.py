@@ -15,6 +15,7 @@ STATUS_TEXT = {
     5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
 }
 FLAG_DRAG, FLAG_J2 = 1, 2
+CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
 NCONST = 8
 STAGE_DOUBLES = 105
 
@@ -52,6 +53,10 @@ _SIGS = {
                                             C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpcx_discretize_stages_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                              C.c_int, C.c_double, _vp, _vp, _vp]),
+    "mpcx_propagate_batch": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp,
+                                       C.c_double, _dp, _ip, _ip]),
+    "mpcx_propagate_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp,
+                                           C.c_double, _vp, _vp, _vp, _vp]),
     "mpcx_default_solve_opts": (None, [_po]),
     "mpcx_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mpcx_mpc_step_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

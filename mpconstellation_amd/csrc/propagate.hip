@@ -1,0 +1,244 @@
+// propagate.hip -- batched nonlinear rollout on gfx950.
+//
+// Replaces Simulator.get_trajectory_ODE (reference simulator.py:164-189): scipy solve_ivp(RK45,
+// rtol 1e-3, atol 1e-6, max_step, t_eval = linspace(0,1,n_eval)) of Simulator.satellite_dynamics
+// (simulator.py:116-161) under one of the reference's thrust laws (control.py:8-143).  Samples come
+// from the RK45 dense-output interpolant exactly as scipy produces them.
+//
+// One lane per satellite: the 7-state system and its 7 RK stages live in registers; satellites of a
+// wave take their own adaptive step sequences under predicate.  It is a setup / SCP re-linearisation
+// kernel (7 x ~1000 steps per satellite), not bandwidth relevant.
+#include "mpcx_device.hpp"
+#include "mpcx_host.hpp"
+
+namespace mpcx {
+
+struct PropArgs {
+    int S, n_eval, flags, ctrl_kind, Ku;
+    double max_step;
+    const double *y0, *tf, *consts;
+    const double *ctrl_vec;   // CONSTANT: [S][3]; TANGENTIAL: [S] magnitudes; SEQUENCE: [S][3][Ku]
+    const double *end_tau;    // SEQUENCE: [S]
+    double *y_out;            // [S][7][n_eval]
+    int32_t *status, *nsteps;
+};
+
+struct Ctrl {
+    int kind, Ku;
+    double v[3];
+    const double *useq;
+    double end_tau;
+};
+
+// control.py thrust laws u(x, tau)
+__device__ __forceinline__ void ctrl_eval(const Ctrl &c, const double (&y)[7], double tau, double (&u)[3], int &err)
+{
+    if (c.kind == MPCX_CTRL_CONSTANT) { u[0] = c.v[0]; u[1] = c.v[1]; u[2] = c.v[2]; return; }
+    if (c.kind == MPCX_CTRL_TANGENTIAL) {                   // control.py:66-84
+        const double rn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+        double h[3] = {y[1] * y[5] - y[2] * y[4], y[2] * y[3] - y[0] * y[5], y[0] * y[4] - y[1] * y[3]};
+        const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+        const double rh[3] = {y[0] / rn, y[1] / rn, y[2] / rn}, hh[3] = {h[0] / hn, h[1] / hn, h[2] / hn};
+        const double t[3] = {hh[1] * rh[2] - hh[2] * rh[1], hh[2] * rh[0] - hh[0] * rh[2], hh[0] * rh[1] - hh[1] * rh[0]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = rh[i] * 0.0 + t[i] * c.v[0] + hh[i] * 0.0;
+        return;
+    }
+    if (c.kind == MPCX_CTRL_SEQUENCE) {                     // control.py:132-142
+        if (tau <= c.end_tau) { foh3(tau / c.end_tau, c.useq, c.Ku, u, err); return; }
+    }
+    u[0] = u[1] = u[2] = 0.0;
+}
+
+__device__ __forceinline__ void prop_rhs(const Ctrl &c, const SatConst &cst, int flags, double tf, double tau,
+                                         const double (&y)[7], double (&yd)[7], int &err)
+{
+    double u[3];
+    ctrl_eval(c, y, tau, u, err);
+    if (y[6] <= 0.0) err = MPCX_ST_MASS;
+    dynamics_unscaled(y, u, cst, flags, yd);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) yd[i] = tf * yd[i];
+}
+
+__device__ __forceinline__ double rms7(const double (&v)[7])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s += v[i] * v[i];
+    return sqrt(s) / sqrt(7.0);
+}
+
+__global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
+{
+    const int sat = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sat >= a.S) return;
+    SatConst cst; cst.load(a.consts + (size_t)sat * MPCX_NCONST);
+    const double tf = a.tf[sat];
+    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0;
+    if (a.ctrl_kind == MPCX_CTRL_CONSTANT) for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i];
+    else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
+    else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }
+    const int flags = a.flags, n_eval = a.n_eval;
+    const double rtol = 1e-3, atol = 1e-6, t_bound = 1.0;
+    int err = 0;
+    double y[7], f[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) y[i] = a.y0[(size_t)sat * 7 + i];
+    double t = 0.0;
+    prop_rhs(c, cst, flags, tf, t, y, f, err);
+    // select_initial_step (scipy common.py:68-134)
+    double h_abs;
+    {
+        double sc[7], a0[7], a1[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { sc[i] = atol + fabs(y[i]) * rtol; a0[i] = y[i] / sc[i]; a1[i] = f[i] / sc[i]; }
+        const double d0 = rms7(a0), d1 = rms7(a1);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, 1.0);
+        double y1[7], f1[7], dd[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
+        prop_rhs(c, cst, flags, tf, t + h0, y1, f1, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dd[i] = (f1[i] - f[i]) / sc[i];
+        const double d2 = rms7(dd) / h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+        h_abs = fmin(fmin(100.0 * h0, h1), fmin(1.0, a.max_step));
+    }
+    const double estep = (n_eval > 1) ? 1.0 / (double)(n_eval - 1) : 0.0;
+    int ei = 0, nsteps = 0;
+    bool rejected = false;
+    double *yo = a.y_out + (size_t)sat * 7 * n_eval;
+    for (int iter = 0; iter < 4000000; ++iter) {
+        if (t == t_bound) break;
+        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        if (!rejected) {
+            if (h_abs > a.max_step) h_abs = a.max_step;
+            else if (h_abs < min_step) h_abs = min_step;
+        }
+        if (!(h_abs >= min_step)) { err = MPCX_ST_STEP; break; }
+        double h = h_abs, t_new = t + h;
+        if (t_new - t_bound > 0.0) t_new = t_bound;
+        h = t_new - t;
+        const double h_try = fabs(h);
+        double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
+        prop_rhs(c, cst, flags, tf, t + RK_C[1] * h, yt, K1, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[2][0] + K1[i] * RK_A[2][1]) * h;
+        prop_rhs(c, cst, flags, tf, t + RK_C[2] * h, yt, K2, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[3][0] + K1[i] * RK_A[3][1] + K2[i] * RK_A[3][2]) * h;
+        prop_rhs(c, cst, flags, tf, t + RK_C[3] * h, yt, K3, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yt[i] = y[i] + (f[i] * RK_A[4][0] + K1[i] * RK_A[4][1] + K2[i] * RK_A[4][2] + K3[i] * RK_A[4][3]) * h;
+        prop_rhs(c, cst, flags, tf, t + RK_C[4] * h, yt, K4, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yt[i] = y[i] + (f[i] * RK_A[5][0] + K1[i] * RK_A[5][1] + K2[i] * RK_A[5][2] + K3[i] * RK_A[5][3] +
+                            K4[i] * RK_A[5][4]) * h;
+        prop_rhs(c, cst, flags, tf, t + RK_C[5] * h, yt, K5, err);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            yn[i] = y[i] + h * (f[i] * RK_B[0] + K1[i] * RK_B[1] + K2[i] * RK_B[2] + K3[i] * RK_B[3] + K4[i] * RK_B[4] +
+                                K5[i] * RK_B[5]);
+        prop_rhs(c, cst, flags, tf, t + h, yn, K6, err);
+        double ev[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const double e = f[i] * RK_E[0] + K1[i] * RK_E[1] + K2[i] * RK_E[2] + K3[i] * RK_E[3] + K4[i] * RK_E[4] +
+                             K5[i] * RK_E[5] + K6[i] * RK_E[6];
+            ev[i] = e * h / (atol + fmax(fabs(y[i]), fabs(yn[i])) * rtol);
+        }
+        const double en = rms7(ev);
+        if (en < 1.0) {
+            double factor = (en == 0.0) ? RK_MAX_FACTOR : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(en, -0.2));
+            if (rejected) factor = fmin(1.0, factor);
+            h_abs = h_try * factor;
+            rejected = false;
+            // dense output at the t_eval points in (t, t_new]  (scipy RkDenseOutput, rk.py:552-574)
+            while (ei < n_eval) {
+                const double te = (ei == n_eval - 1 && n_eval > 1) ? 1.0 : (double)ei * estep + 0.0;
+                if (te > t_new) break;
+                const double x = (te - t) / h;
+                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const double kk[7] = {f[i], K1[i], K2[i], K3[i], K4[i], K5[i], K6[i]};
+                    double acc = 0.0;
+                    const double pw[4] = {p1, p2, p3, p4};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        double q = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) q += kk[j] * RK_P[j][cc];
+                        acc += q * pw[cc];
+                    }
+                    yo[(size_t)i * n_eval + ei] = h * acc + y[i];
+                }
+                ++ei;
+            }
+            t = t_new;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { y[i] = yn[i]; f[i] = K6[i]; }
+            ++nsteps;
+        } else {
+            h_abs = h_try * fmax(RK_MIN_FACTOR, RK_SAFETY * pow(en, -0.2));
+            rejected = true;
+        }
+    }
+    if (t != t_bound && err == 0) err = MPCX_ST_STEP;
+    a.status[sat] = err;
+    a.nsteps[sat] = nsteps;
+}
+
+}  // namespace mpcx
+
+using namespace mpcx;
+
+extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                                        const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
+                                        int Ku, const double *end_tau, double max_step, double *y_out,
+                                        int32_t *status, int32_t *nsteps, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || n_eval < 1 || !(max_step > 0.0)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1, max_step>0");
+    if (ctrl_kind < MPCX_CTRL_ZERO || ctrl_kind > MPCX_CTRL_SEQUENCE) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: unknown thrust law");
+    if (ctrl_kind == MPCX_CTRL_SEQUENCE && (Ku < 2 || !end_tau || !ctrl_vec)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: sequence needs Ku>=2, table and end_tau");
+    if ((ctrl_kind == MPCX_CTRL_CONSTANT || ctrl_kind == MPCX_CTRL_TANGENTIAL) && !ctrl_vec) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: thrust parameters missing");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    PropArgs a{S, n_eval, flags, ctrl_kind, Ku, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
+    hipLaunchKernelGGL(propagate_kernel, dim3((S + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                                    const double *consts, int flags, int ctrl_kind, const double *ctrl_vec, int Ku,
+                                    const double *end_tau, double max_step, double *y_out, int32_t *status,
+                                    int32_t *nsteps)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || n_eval < 1) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceArena ar(ctx);
+    double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST);
+    size_t nv = 0;
+    if (ctrl_kind == MPCX_CTRL_CONSTANT) nv = (size_t)S * 3;
+    else if (ctrl_kind == MPCX_CTRL_TANGENTIAL) nv = S;
+    else if (ctrl_kind == MPCX_CTRL_SEQUENCE) nv = (size_t)S * 3 * Ku;
+    double *dv = (nv && ctrl_vec) ? ar.upload(ctrl_vec, nv) : nullptr;
+    double *de = (ctrl_kind == MPCX_CTRL_SEQUENCE && end_tau) ? ar.upload(end_tau, S) : nullptr;
+    double *dy = ar.alloc<double>((size_t)S * 7 * n_eval);
+    int32_t *dst = ar.alloc<int32_t>(S), *dns = ar.alloc<int32_t>(S);
+    if (ar.failed()) return ar.code();
+    int rc = mpcx_propagate_batch_dev(ctx, S, n_eval, dy0, dtf, dc, flags, ctrl_kind, dv, Ku, de, max_step, dy, dst,
+                                      dns, ctx->stream);
+    if (rc) return rc;
+    ar.download(y_out, dy, (size_t)S * 7 * n_eval); ar.download(status, dst, S); ar.download(nsteps, dns, S);
+    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ar.failed() ? ar.code() : MPCX_OK;
+}

@@ -1,0 +1,145 @@
+"""Simulator: drop-in for reference simulator.py.  The nonlinear rollouts (get_trajectory_ODE, one
+scipy solve_ivp per satellite in the reference) run as one batched kernel on the device
+(mpcx_propagate_batch); there is no host integrator fallback."""
+from datetime import datetime
+
+import numpy as np
+
+from . import _ffi
+from .constants import C_D, R_EARTH
+from .control import Controller
+from .satellite_scale import SatelliteScale
+
+
+class OdeResult:
+    """The fields of scipy's OdeResult that the reference reads (sol.y, sol.t)."""
+
+    def __init__(self, t, y, status, nsteps):
+        self.t, self.y, self.status, self.nsteps = t, y, status, nsteps
+        self.success = (status == 0)
+
+
+def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0):
+    """y0 (S,7) normalised, tf (S,), consts (S,8); law = (kind, vec, Ku, end_tau) with per-satellite or
+    broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,)."""
+    y0 = _ffi.as_f64(y0); S = y0.shape[0]
+    tf = _ffi.as_f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (S,)))
+    consts = _ffi.as_f64(consts)
+    kind, vec, Ku, end_tau = law
+    vec_p = None; et_p = None
+    if kind == _ffi.CTRL_CONSTANT:
+        vec = _ffi.as_f64(np.broadcast_to(np.asarray(vec, dtype=np.float64).reshape(-1, 3), (S, 3))); vec_p = _ffi.dptr(vec)
+    elif kind == _ffi.CTRL_TANGENTIAL:
+        vec = _ffi.as_f64(np.broadcast_to(np.asarray(vec, dtype=np.float64).reshape(-1), (S,))); vec_p = _ffi.dptr(vec)
+    elif kind == _ffi.CTRL_SEQUENCE:
+        vec = np.asarray(vec, dtype=np.float64)
+        vec = _ffi.as_f64(np.broadcast_to(vec if vec.ndim == 3 else vec[None], (S, 3, Ku))); vec_p = _ffi.dptr(vec)
+        end_tau = _ffi.as_f64(np.broadcast_to(np.asarray(end_tau, dtype=np.float64), (S,))); et_p = _ffi.dptr(end_tau)
+    y = np.empty((S, 7, n_eval)); status = np.zeros(S, dtype=np.int32); nsteps = np.zeros(S, dtype=np.int32)
+    flags = (_ffi.FLAG_DRAG if include_drag else 0) | (_ffi.FLAG_J2 if include_J2 else 0)
+    lib = _ffi.load(); ctx = _ffi.context(device)
+    rc = lib.mpcx_propagate_batch(ctx, S, int(n_eval), _ffi.dptr(y0), _ffi.dptr(tf), _ffi.dptr(consts), flags, kind,
+                                  vec_p, int(Ku), et_p, float(max_step), _ffi.dptr(y), _ffi.iptr(status),
+                                  _ffi.iptr(nsteps))
+    _ffi.check(rc, ctx, "mpcx_propagate_batch")
+    return y, status, nsteps
+
+
+class Simulator:
+    def __init__(self, sats=[], controller=Controller(), scale=SatelliteScale(), base_res=100, include_drag=True,
+                 include_J2=True, verbose=False, device=0):
+        self.sim_data = {}
+        self.sim_time = {}
+        self.sats = sats
+        self.base_res = base_res
+        self.eval_points = self.base_res
+        self.controller = controller
+        self.include_drag = include_drag
+        self.include_J2 = include_J2
+        self.scale = scale
+        self.verbose = verbose
+        self.device = device
+
+    # ---- batched rollout of all satellites (one kernel) ----
+    def _rollout(self, sats, tf):
+        const = self.scale.get_normalized_constants().as_vector()
+        y0 = np.stack([self.scale.normalize_state(s.get_state_vector()) for s in sats])
+        law = self.controller.device_law()
+        y, status, nsteps = propagate_batch(y0, tf, np.tile(const, (len(sats), 1)), law, self.eval_points,
+                                            self.include_drag, self.include_J2, 0.001, self.device)
+        if (status == 1).any():
+            raise Exception("ERROR: INVALID SATELLITE MASS")           # simulator.py:135-136
+        if (status != 0).any():
+            raise RuntimeError(f"propagation failed: {[_ffi.STATUS_TEXT.get(int(c), c) for c in status if c]}")
+        t = np.linspace(0, 1, self.eval_points)
+        return [OdeResult(t.copy(), y[i], int(status[i]), int(nsteps[i])) for i in range(len(sats))]
+
+    def run(self, tf=10):
+        """reference simulator.py:29-48"""
+        self.eval_points = int(self.base_res * tf)
+        sols = self._rollout(self.sats, tf) if self.sats else []
+        self.sim_data = {s.id: sol.y for s, sol in zip(self.sats, sols)}
+        self.sim_time = {s.id: sol.t for s, sol in zip(self.sats, sols)}
+        return self.sim_data, self.sim_time
+
+    def run_segment(self, tf=1):
+        """reference simulator.py:50-77 (the controller re-plans once per satellite, as there)"""
+        self.eval_points = int(self.base_res * tf)
+        for sat in self.sats:
+            self.controller.update()
+            sol = self._rollout([sat], tf)[0]
+            sat.update_state_vector(self.scale.redim_state(sol.y[:, -1]))
+            if sat.id in self.sim_data and sat.id in self.sim_time:
+                time = sol.t + self.sim_time.get(sat.id, [0])[-1] * tf + 0.0000001
+                self.sim_data[sat.id] = np.concatenate([self.sim_data[sat.id], sol.y], axis=1)
+                self.sim_time[sat.id] = np.concatenate([self.sim_time[sat.id], time])
+            else:
+                self.sim_data[sat.id] = sol.y
+                self.sim_time[sat.id] = sol.t
+
+    def run_segments(self, tf=1, num_segments=1):
+        """reference simulator.py:79-92"""
+        tf_step = tf / float(num_segments)
+        for n in range(num_segments):
+            if self.verbose:
+                print(f"\nRunning segment {n+1} of {num_segments}; tf {tf_step*(n+1)} of {tf}")
+            self.run_segment(tf=tf_step)
+
+    def get_trajectory_ODE(self, sat, tf, u_func=None):
+        """reference simulator.py:164-189; the thrust law is taken from self.controller (device form)."""
+        return self._rollout([sat], tf)[0]
+
+    @staticmethod
+    def get_atmo_density(r, r0):
+        return 9.983E-13                                               # simulator.py:97-112
+
+    @staticmethod
+    def satellite_dynamics(tau, y, u_func, tf, const, include_drag=True, include_J2=True):
+        """Host evaluation of the dynamics for callers that want f(tau, y) itself (reference
+        simulator.py:116-161).  The device kernels carry their own copy; this is never used by them."""
+        r = y[0:3]; v = y[3:6]; m = y[6]
+        if m <= 0.1:
+            print(f"WARNING: low mass {m}")
+        if m <= 0:
+            raise Exception(f"ERROR: INVALID SATELLITE MASS: {m}")
+        r_norm = np.linalg.norm(r)
+        y_dot = np.zeros((7,))
+        y_dot[0:3] = v
+        u = u_func(y, tau)
+        y_dot[3:6] = -const.MU / r_norm ** 3 * r + u / m
+        if include_drag:
+            y_dot[3:6] += -1 / 2 * C_D * const.S * (1 / m) * (Simulator.get_atmo_density(r, const.R0) / const.RHO) \
+                * np.linalg.norm(v) * v
+        if include_J2:
+            q = (r[2] / r_norm) ** 2
+            y_dot[3:6] += 1.5 * const.J2 * const.MU * const.R_E ** 2 / r_norm ** 5 \
+                * np.array([5 * q - 1, 5 * q - 1, 5 * q - 3]) * r
+        y_dot[6] = -np.linalg.norm(u) / (const.G0 * const.ISP)
+        return tf * y_dot
+
+    def save_to_csv(self, suffix="", redimensionalize=True):
+        """reference simulator.py:192-201: trajectory_{date}_{id}{suffix}.csv, T rows x 7 columns"""
+        date = datetime.today().strftime('%Y-%m-%d-%H-%M-%S')
+        for sat in self.sats:
+            data = self.scale.redim_state(self.sim_data[sat.id]) if redimensionalize else self.sim_data[sat.id]
+            np.savetxt(f"trajectory_{date}_{sat.id}{suffix}.csv", data.T, delimiter=",")
