@@ -591,7 +591,7 @@ struct Scratch {   // LDS working set of the recursion
     double p[NCH][8], v[NCH][8], w[NCH][8], t[NCH][8], y[NCH][8], yh[NCH][8], u[NCH][4], qu[NCH][4], gx[NCH][8], aff[NCH][8], rho[NCH][8], gu[NCH][4];
 };
 
-// Backward Riccati sweep: factorisation (oracle/nlp_ipm.py riccati_factor).  Returns false on breakdown.
+// Backward Riccati sweep: factorisation.  Returns false on breakdown.
 __device__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane)
 {
     const int K = s.K;
@@ -921,7 +921,7 @@ __device__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const 
 }
 
 // Residual of the reduced KKT system at the current direction -> rhs record of channel 0
-// (oracle/nlp_ipm.py reduced_residual).  Stage-parallel.  Returns gtf_rhs, rvt_rhs, gterm[] via sd.red / gterm.
+// ("Linear solve").  Stage-parallel.  Returns gtf_rhs, rvt_rhs, gterm[] via sd.red / gterm.
 __device__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
 {
     const int K = s.K;
@@ -1033,7 +1033,7 @@ __device__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gt
     __syncthreads();
 }
 
-// dt, ds, dz by back-substitution (oracle finish_direction) and the fraction-to-the-boundary step.
+// dt, ds, dz by back-substitution ("Linear solve") and the fraction-to-the-boundary step.
 __device__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
 {
     const int K = s.K;

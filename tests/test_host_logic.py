@@ -1,0 +1,136 @@
+"""Host-side mirrors of the reference API (no GPU needed): units, controllers, constraint terms, options,
+constellation generator, sharding; and a world_size-2 gloo run of the multi-GPU plumbing."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def hubble():
+    from mpconstellation_amd import Satellite
+    return Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+
+
+def test_scale_and_constants(golden_dir):
+    from mpconstellation_amd import SatelliteScale
+    c = np.load(os.path.join(golden_dir, "constants_hubble.npz"))
+    sc = SatelliteScale(sat=hubble())
+    assert np.array_equal(sc.get_normalized_constants().as_vector(), c["const"])
+    assert np.array_equal(sc.normalize_state(c["state"]), c["x_norm"])
+    assert np.array_equal(sc.redim_state(c["x_norm"]), c["x_redim"])
+    x2 = np.column_stack([c["state"], c["state"]])
+    assert np.array_equal(sc.redim_state(sc.normalize_state(x2))[:, 0], c["x_redim"])
+    assert np.allclose(sc.normalize_thrust(sc.redim_thrust(np.ones(3))), 1.0)
+    d = SatelliteScale()                                     # default: unit scale (satellite_scale.py:25-26)
+    assert d._r0 == 1 and d._m0 == 1
+
+
+def test_satellite_ids_unique():
+    from mpconstellation_amd import Satellite
+    ids = {Satellite().id for _ in range(2000)}              # reference test_satellite.py:21-28
+    assert len(ids) == 2000
+    s = hubble(); s.update_state_vector(np.arange(7.0))
+    assert np.array_equal(s.get_state_vector(), np.arange(7.0))
+
+
+def test_controllers_match_oracle_and_golden(golden_dir):
+    from mpconstellation_amd import (Discretizer, ConstantTangentialThrustController, ConstantThrustController,
+                                     SequenceController, Controller)
+    d = np.load(os.path.join(golden_dir, "disc_tan_K30_tf1.npz"))
+    c = ConstantTangentialThrustController([], 0.5)
+    u = Discretizer.extract_uk(d["x"], d["t"], c)
+    assert np.abs(u - d["u"]).max() < 1e-14                  # extract_uk, linearize_discretize.py:393-411
+    fo = np.load(os.path.join(golden_dir, "foh.npz"))
+    sc = SequenceController(u=fo["u_30"], tf_u=0.6, tf_sim=1.0)
+    f = sc.get_u_func()
+    oc = O.make_ctrl(O.CTRL_SEQUENCE, useq=fo["u_30"], end_tau=0.6)
+    import ctypes
+    for tau in np.concatenate([fo["tau_30"], [0.6, 0.61, 1.0]]):
+        out = np.zeros(3)
+        O.lib().oracle_ctrl_eval.argtypes = [ctypes.POINTER(O.OracleCtrl), ctypes.POINTER(ctypes.c_double), ctypes.c_double,
+                                             ctypes.POINTER(ctypes.c_double)]
+        O.lib().oracle_ctrl_eval(ctypes.byref(oc), d["x"][:, 0].copy().ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 float(tau), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        assert np.array_equal(f(None, tau), out)
+    assert np.array_equal(Controller().get_u_func()(None, 0.3), np.zeros(3))
+    assert np.array_equal(ConstantThrustController([], np.array([1., 2., 3.])).get_u_func()(None, 0.3), [1, 2, 3])
+    assert sc.device_law()[0] == 3 and c.device_law()[0] == 2
+
+
+def test_constraint_terms_mirror(golden_dir):
+    from mpconstellation_amd import Optimizer, SatelliteScale, Discretizer
+    d = np.load(os.path.join(golden_dir, "disc_tan_K60_tf2.npz"))
+    scale = SatelliteScale(sat=hubble())
+    opt = Optimizer([d["x"]], [d["u"]], [np.zeros_like(d["x"])], 2, Discretizer(scale.get_normalized_constants()),
+                    None, scale, verbose=False)
+    ct = opt.get_constraint_terms()
+    for k, v in ct.items():
+        assert np.allclose(v[0], d["ct_" + k], rtol=0, atol=1e-13, equal_nan=True), k
+    assert opt.init_options({"r_des": 1.3})["r_des"] == 1.3 and opt.init_options({})["w_nu"] == 1000
+    with pytest.raises(NotImplementedError):                 # one tf shared by several satellites (optimizer.py:287)
+        Optimizer([d["x"], d["x"]], [d["u"], d["u"]], [None, None], 2, None, None, scale)
+
+
+def test_host_dynamics_matches_oracle(golden_dir):
+    from mpconstellation_amd import Simulator
+    from mpconstellation_amd.constants import Constants
+    p = np.load(os.path.join(golden_dir, "pointwise.npz"))
+    const = Constants(*p["const"])
+    for i in range(0, 128, 7):
+        u = p["u"][i]
+        f = Simulator.satellite_dynamics(0.3, p["x"][i], lambda y, t: u, p["tf"][i], const, include_drag=True, include_J2=True)
+        assert np.abs(f - p["f_drag_j2"][i]).max() < 1e-12
+
+
+def test_constellation_generator_and_sharding(golden_dir):
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+    from mpconstellation_amd.sharding import shard_block
+    c64 = np.load(os.path.join(golden_dir, "constellation64.npz"))
+    st = constellation_states(64)
+    y0, consts = normalize_batch(st)
+    for i in c64["idx"]:
+        assert np.abs(st[i] - c64[f"state_{i}"]).max() < 1e-6          # metres: same generator as the golden script
+        assert np.abs(consts[i] - c64[f"const_{i}"]).max() / np.abs(c64[f"const_{i}"]).max() < 1e-14
+        assert np.abs(tangential_thrust(c64[f"x_{i}"][None], 0.5)[0] - c64[f"u_{i}"]).max() < 1e-14
+    assert np.array_equal(constellation_states(64, first=10, count=5), st[10:15])
+    for S, W in ((65536, 8), (64, 2), (10, 3), (5, 8)):
+        blocks = [shard_block(S, W, r) for r in range(W)]
+        assert sum(c for _, c in blocks) == S and blocks[0][0] == 0
+        assert all(blocks[r][0] + blocks[r][1] == blocks[r + 1][0] for r in range(W - 1))
+        assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from mpconstellation_amd.constellation import constellation_states
+    from mpconstellation_amd.sharding import shard_block, gather_trajectories
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = 11
+    first, count = shard_block(S, world, rank)
+    local = torch.tensor(constellation_states(S, first=first, count=count))
+    full = gather_trajectories(local)                       # the optional final gather (ragged blocks)
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                # bench.py: max over ranks of the timed region
+    dist.barrier()
+    if rank == 0:
+        q.put((full.numpy(), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    import torch.multiprocessing as mp
+    from mpconstellation_amd.constellation import constellation_states
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    full, tmax = q.get(timeout=120)
+    for p in procs: p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(full, constellation_states(11))
+    assert abs(tmax - 0.2) < 1e-12
