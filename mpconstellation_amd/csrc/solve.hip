@@ -29,13 +29,15 @@ enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16,
 enum { N_WX = 0, N_WU = 49, N_D = 58, N_AA = 65, N_BB = 72, N_GT = 79, N_RHO = 86, N_GX = 93, N_GU = 100,
        N_E = 103, NB_N = 112 };
 // factorisation per node
-enum { F_P = 0, F_L = 49, F_WL = 98, F_PT = 147, F_QI = 196, F_QUY = 205, F_BH = 226, FAC_N = 248 };
+enum { F_P = 0, F_MINV = 49, F_G = 98, F_PT = 147, F_QI = 196, F_KG = 205, F_BH = 226, FAC_N = 248 };
 // channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
 enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, CH_N = 104 };
+// stored trajectory of one channel at one node
+enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -54,7 +56,7 @@ struct SolveArgs {
 
 __host__ __device__ inline size_t ws_doubles(int K)
 {
-    return (size_t)K * (2 * IT_N + NB_N + FAC_N + CH_N) + 2 * GL_N + 3 * (size_t)K + 64;
+    return (size_t)K * (2 * IT_N + NB_N + FAC_N + CH_N + 8 * 24) + 2 * GL_N + 3 * (size_t)K + 64;
 }
 
 // ---- per-satellite constant data kept in LDS --------------------------------------------
@@ -124,7 +126,7 @@ __device__ void vt_reduced(const double *x, double vt_des, double &c, double *g6
 
 // Optimizer.get_constraint_terms (optimizer.py:80-170) for the terminal node, incl. the
 // operator-precedence form of Dv_h_hat (:122); builds the six terminal linear inequalities.
-__device__ void build_terminal(const double *xK, double mu_grav, double r_des, const SolveOpts &o, SatData &sd)
+__device__ __noinline__ void build_terminal(const double *xK, double mu_grav, double r_des, const SolveOpts &o, SatData &sd)
 {
     double r[3] = {xK[0], xK[1], xK[2]}, v[3] = {xK[3], xK[4], xK[5]}, h[3], rh[3], hh[3];
     const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
@@ -182,7 +184,7 @@ __device__ void build_terminal(const double *xK, double mu_grav, double r_des, c
 struct Sat {
     int K;
     const double *stage, *xbar, *ubar;   // stage (K-1,105); xbar (7,K); ubar (3,K)
-    double *it, *itg, *dr, *drg, *nb, *fac, *ch, *rbh;   // workspace pieces
+    double *it, *itg, *dr, *drg, *nb, *fac, *ch, *traj, *rbh;   // workspace pieces
     __device__ const double *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
     __device__ const double *Bn(int k) const { return A(k) + 49; }
     __device__ const double *Bp(int k) const { return A(k) + 70; }
@@ -215,22 +217,22 @@ __device__ __forceinline__ void load_node(const Sat &s, int k, double a, NodeVal
 }
 
 struct ResAcc {   // accumulators of one residual evaluation
-    double dual_max, prim_max, comp_max, sq, zsum, lsum, prod_min, prod_sum;
+    double dual_max, prim_max, comp_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
 };
 
 // Perturbed KKT residual F_mu at (iterate + a*direction): ipopt's scaled error pieces and the
 // 2-norm used by the line search.  Lane k handles node k.  Results are wave-uniform.
-__device__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
+__device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
 {
     const int K = s.K;
-    double dual = 0.0, prim = 0.0, comp = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, psum = 0.0;
+    double dual = 0.0, prim = 0.0, comp = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, pmax = -1e300, psum = 0.0;
     double gtf_part = 0.0;
     const double tf = s.itg[G_TF] + a * s.drg[G_TF];
     const double lvt = s.itg[G_LVT] + a * s.drg[G_LVT];
 #define ACC_D(v) { const double q_ = (v); dual = fmax(dual, fabs(q_)); sq += q_ * q_; }
 #define ACC_P(v) { const double q_ = (v); prim = fmax(prim, fabs(q_)); sq += q_ * q_; }
 #define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; comp = fmax(comp, fabs(q_)); sq += q_ * q_; \
-                        zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); psum += s_ * z_; }
+                        zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
     for (int k = lane; k < K; k += 64) {
         NodeVals n;
         load_node(s, k, a, n);
@@ -359,22 +361,24 @@ __device__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, in
 #undef ACC_C
     out.dual_max = wave_max(dual); out.prim_max = wave_max(prim); out.comp_max = wave_max(comp);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
-    out.prod_min = wave_min(pmin); out.prod_sum = wave_sum(psum);
+    out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
 }
 
 __device__ __forceinline__ int n_ineq(int K) { return K + (K - 1) + (K - 2) + 6 + 1 + 14 * (K - 1) + 2; }
 
-__device__ double scaled_error(const ResAcc &r, int K)
+// ipopt's scaled optimality error E_mu from one residual evaluation: max_i |s_i z_i - mu| = max(pmax - mu, mu - pmin)
+__device__ double scaled_error(const ResAcc &r, int K, double mu)
 {
     const double smax = 100.0;
     const int nz = n_ineq(K), nl = 7 * (K - 1) + 1;
     const double sdl = fmax(smax, (r.zsum + r.lsum) / (double)(nz + nl)) / smax;
     const double sc = fmax(smax, r.zsum / (double)nz) / smax;
-    return fmax(fmax(r.dual_max / sdl, r.prim_max), r.comp_max / sc);
+    const double comp = fmax(r.prod_max - mu, mu - r.prod_min);
+    return fmax(fmax(r.dual_max / sdl, r.prim_max), comp / sc);
 }
 
 // ---- Newton blocks (stage-parallel) ------------------------------------------------------------
-__device__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta_w, int lane)
+__device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta_w, int lane)
 {
     const int K = s.K;
     double wtf_part = 0.0;
@@ -516,341 +520,403 @@ __device__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta
 }
 
 // ---- tiny dense helpers on LDS matrices --------------------------------------------------------
-// out(i,j) (op)= sum_l A[i*ar + l*ac] * B[l*br + j*bc],  i<M, j<N, l<Kd ; op: 0 assign, 1 add, -1 subtract
-__device__ __forceinline__ void mm(double *out, int ldo, const double *A, int ar, int ac, const double *B, int br,
-                                   int bc, int M, int N, int Kd, int op, int lane)
+// element (i,j) of sum_l A[i*ar + l*ac] * B[l*br + j*bc], l < Kd
+__device__ __forceinline__ double dot_el(const double *A, int ar, int ac, const double *B, int br, int bc, int i, int j, int Kd)
 {
-    for (int e = lane; e < M * N; e += 64) {
-        const int i = e / N, j = e - i * N;
-        double acc = 0.0;
-        for (int l = 0; l < Kd; ++l) acc += A[i * ar + l * ac] * B[l * br + j * bc];
-        double *o = out + i * ldo + j;
-        *o = (op == 0) ? acc : (op > 0 ? *o + acc : *o - acc);
-    }
-    __syncthreads();
-}
-
-// in-place lower Cholesky of an n x n LDS matrix (row-major, ld = n); returns false if not PD
-__device__ bool chol_lds(double *M, int n, int lane, int *flag)
-{
-    if (lane == 0) *flag = 0;
-    __syncthreads();
-    for (int p = 0; p < n; ++p) {
-        if (lane == 0) {
-            const double d = M[p * n + p];
-            if (!(d > 0.0)) *flag = 1;
-            M[p * n + p] = sqrt(d > 0.0 ? d : 1.0);
-        }
-        __syncthreads();
-        if (lane > p && lane < n) M[lane * n + p] /= M[p * n + p];
-        __syncthreads();
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            if (j > p && j <= i) M[i * n + j] -= M[i * n + p] * M[j * n + p];
-        }
-        __syncthreads();
-    }
-    // zero the strict upper triangle so that L can be used as a full matrix
-    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; if (j > i) M[e] = 0.0; }
-    __syncthreads();
-    return *flag == 0;
-}
-
-// X <- L^-1 X for an n x m block (columns independent: one lane per column)
-__device__ __forceinline__ void trsm_lower(const double *L, int n, double *X, int ldx, int m, int lane)
-{
-    if (lane < m) {
-        for (int p = 0; p < n; ++p) {
-            double sacc = X[p * ldx + lane];
-            for (int q = 0; q < p; ++q) sacc -= L[p * n + q] * X[q * ldx + lane];
-            X[p * ldx + lane] = sacc / L[p * n + p];
-        }
-    }
-    __syncthreads();
+    double acc = 0.0;
+    for (int l = 0; l < Kd; ++l) acc += A[i * ar + l * ac] * B[l * br + j * bc];
+    return acc;
 }
 
 // symmetric 3x3 inverse with positive-definiteness test (leading minors)
-__device__ bool inv3_spd(const double *Q, double *Qi)
+__device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 {
     const double a = Q[0], b = Q[1], c = Q[2], d = Q[4], e = Q[5], f = Q[8];
     const double m2 = a * d - b * b;
     const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
-    if (!(a > 0.0) || !(m2 > 0.0) || !(det > 0.0)) return false;
+    const bool ok = (a > 0.0) && (m2 > 0.0) && (det > 0.0);
     const double id = 1.0 / det;
     Qi[0] = (d * f - e * e) * id; Qi[1] = (c * e - b * f) * id; Qi[2] = (b * e - c * d) * id;
     Qi[3] = Qi[1]; Qi[4] = (a * f - c * c) * id; Qi[5] = (b * c - a * e) * id;
     Qi[6] = Qi[2]; Qi[7] = Qi[5]; Qi[8] = (a * d - b * b) * id;
-    return true;
+    return ok;
 }
 
-struct Scratch {   // LDS working set of the recursion
-    double Pn[49], M[49], Wl[49], Pt[49], A[49], Wx[49], PtA[49], tmp[49];
-    double Bn[21], Bpm[21], Bh[21], PtBh[21], WxBp[21], Quy[21], QiQuy[21];
-    double Wu[9], Quu[9], Qi[9], D[8];
-    // channel vectors: [channel][8]
-    double p[NCH][8], v[NCH][8], w[NCH][8], t[NCH][8], y[NCH][8], yh[NCH][8], u[NCH][4], qu[NCH][4], gx[NCH][8], aff[NCH][8], rho[NCH][8], gu[NCH][4];
+struct StageOps {          // operands of one node, double-buffered in LDS
+    double A[49], Wx[49], G[49], Pt[49], Minv[49];
+    double Bn[21], Bpm[21], Bh[21], Kg[21];
+    double Wu[9], Qi[9], D[8];
 };
 
-// Backward Riccati sweep: factorisation.  Returns false on breakdown.
-__device__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane)
+struct Scratch {   // LDS working set of the recursion
+    StageOps ops[2];
+    double Pn[49], L[49], WlLi[98], PtA[49], Qyy[49];
+    double PtBh[21], WxBp[21], Quy[21];
+    double Quu[9];
+};
+
+// In-register Cholesky of the 7x7 SPD matrix whose element (i,j) sits in lane i*7+j (lanes 0..48).
+// Right-looking elimination with ds_bpermute broadcasts, no LDS traffic, no barriers.  Returns L(i,j) (j<=i) and ok.
+__device__ __forceinline__ double chol7_reg(double m, int lane, bool &ok)
 {
-    const int K = s.K;
-    for (int k = K - 1; k >= 0; --k) {
-        const double *nb = s.nb + (size_t)k * NB_N;
-        double *fac = s.fac + (size_t)k * FAC_N;
-        // stage operands -> LDS
-        for (int e = lane; e < 49; e += 64) {
-            w.Wx[e] = (k == K - 1) ? sd.WxK[e] : nb[N_WX + e];
-            w.A[e] = (k <= K - 2) ? s.A(k)[e] : 0.0;
-        }
-        if (lane < 21) {
-            w.Bpm[lane] = (k >= 1) ? s.Bp(k - 1)[lane] : 0.0;
-            w.Bn[lane] = (k <= K - 2) ? s.Bn(k)[lane] : 0.0;
-        }
-        if (lane < 9) w.Wu[lane] = nb[N_WU + lane];
-        if (lane < 7) w.D[lane] = (k <= K - 2) ? nb[N_D + lane] : 0.0;
-        __syncthreads();
-        if (k <= K - 2) {
-            for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.M[e] = w.Pn[e] + (i == j ? w.D[i] : 0.0); w.Wl[e] = w.Pn[e]; }
-            __syncthreads();
-            if (!chol_lds(w.M, 7, lane, &sd.flag)) return false;
-            trsm_lower(w.M, 7, w.Wl, 7, 7, lane);                                   // Wl = L^-1 Pn
-            for (int e = lane; e < 49; e += 64) w.Pt[e] = w.Pn[e];
-            __syncthreads();
-            mm(w.Pt, 7, w.Wl, 1, 7, w.Wl, 7, 1, 7, 7, 7, -1, lane);                 // Pt = Pn - Wl^T Wl
-            for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.tmp[e] = 0.5 * (w.Pt[e] + w.Pt[j * 7 + i]); }
-            __syncthreads();
-            for (int e = lane; e < 49; e += 64) { w.Pt[e] = w.tmp[e]; fac[F_L + e] = w.M[e]; fac[F_WL + e] = w.Wl[e]; fac[F_PT + e] = w.tmp[e]; }
-            if (lane < 21) w.Bh[lane] = w.Bn[lane];
-            __syncthreads();
-            mm(w.Bh, 3, w.A, 7, 1, w.Bpm, 3, 1, 7, 3, 7, 1, lane);                  // Bh = A Bpm + Bn
-            mm(w.PtA, 7, w.Pt, 7, 1, w.A, 7, 1, 7, 7, 7, 0, lane);                  // Pt A
-            mm(w.PtBh, 3, w.Pt, 7, 1, w.Bh, 3, 1, 7, 3, 7, 0, lane);                // Pt Bh
-        } else {
-            for (int e = lane; e < 49; e += 64) { w.Pt[e] = 0.0; w.PtA[e] = 0.0; }
-            if (lane < 21) { w.Bh[lane] = 0.0; w.PtBh[lane] = 0.0; }
-            __syncthreads();
-        }
-        mm(w.WxBp, 3, w.Wx, 7, 1, w.Bpm, 3, 1, 7, 3, 7, 0, lane);                   // Wx Bpm
-        if (lane < 9) w.Quu[lane] = w.Wu[lane];
-        __syncthreads();
-        mm(w.Quu, 3, w.Bpm, 1, 3, w.WxBp, 3, 1, 3, 3, 7, 1, lane);                  // + Bpm^T Wx Bpm
-        mm(w.Quu, 3, w.Bh, 1, 3, w.PtBh, 3, 1, 3, 3, 7, 1, lane);                   // + Bh^T Pt Bh
-        // Quy = Bpm^T Wx + Bh^T Pt A   (3x7)
-        mm(w.Quy, 7, w.Bpm, 1, 3, w.Wx, 7, 1, 3, 7, 7, 0, lane);
-        mm(w.Quy, 7, w.Bh, 1, 3, w.PtA, 7, 1, 3, 7, 7, 1, lane);
-        // Pn <- Wx + A^T Pt A
-        for (int e = lane; e < 49; e += 64) w.Pn[e] = w.Wx[e];
-        __syncthreads();
-        mm(w.Pn, 7, w.A, 1, 7, w.PtA, 7, 1, 7, 7, 7, 1, lane);
-        if (lane == 0) sd.flag = inv3_spd(w.Quu, w.Qi) ? 0 : 1;
-        __syncthreads();
-        if (sd.flag) return false;
-        mm(w.QiQuy, 7, w.Qi, 3, 1, w.Quy, 7, 1, 3, 7, 3, 0, lane);                  // Qi Quy
-        mm(w.Pn, 7, w.Quy, 1, 7, w.QiQuy, 7, 1, 7, 7, 3, -1, lane);                 // - Quy^T Qi Quy
-        for (int e = lane; e < 49; e += 64) { const int i = e / 7, j = e - i * 7; w.tmp[e] = 0.5 * (w.Pn[e] + w.Pn[j * 7 + i]); }
-        __syncthreads();
-        for (int e = lane; e < 49; e += 64) { w.Pn[e] = w.tmp[e]; fac[F_P + e] = w.tmp[e]; }
-        if (lane < 9) fac[F_QI + lane] = w.Qi[lane];
-        if (lane < 21) { fac[F_QUY + lane] = w.Quy[lane]; fac[F_BH + lane] = w.Bh[lane]; }
-        __syncthreads();
+    const int i = lane / 7, j = lane - 7 * i;
+    ok = true;
+    double dsave = 1.0;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        const double d = __shfl(m, p * 8, 64);
+        const double mip = __shfl(m, (i < 7 ? i : 0) * 7 + p, 64);
+        const double mjp = __shfl(m, j * 7 + p, 64);
+        if (!(d > 0.0)) ok = false;
+        if (i > p && j > p && i < 7) m -= mip * mjp / d;
+        if (j == p) dsave = d;
     }
-    return true;
+    return (i < 7 && j <= i) ? m / sqrt(dsave) : 0.0;
 }
 
-// load stage operands needed by the linear-term sweeps into LDS
-__device__ __forceinline__ void load_sweep_stage(const Sat &s, Scratch &w, int k, int lane)
+// Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
+__device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane)
+{
+    const int K = s.K;
+    bool good = true;
+    // operand prefetch: node k's (A, Wx, Bn, Bpm, Wu, D) -> registers -> LDS buffer
+    double pre[3];
+    auto fetch = [&](int k) {
+        const double *nb = s.nb + (size_t)k * NB_N;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = lane + 64 * q;
+            double v = 0.0;
+            if (e < 49) v = (k <= K - 2) ? s.A(k)[e] : 0.0;
+            else if (e < 98) v = (k == K - 1) ? sd.WxK[e - 49] : nb[N_WX + e - 49];
+            else if (e < 119) v = (k <= K - 2) ? s.Bn(k)[e - 98] : 0.0;
+            else if (e < 140) v = (k >= 1) ? s.Bp(k - 1)[e - 119] : 0.0;
+            else if (e < 149) v = nb[N_WU + e - 140];
+            else if (e < 156) v = (k <= K - 2) ? nb[N_D + e - 149] : 0.0;
+            pre[q] = v;
+        }
+    };
+    auto stash = [&](StageOps &o) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 49) o.A[e] = pre[q];
+            else if (e < 98) o.Wx[e - 49] = pre[q];
+            else if (e < 119) o.Bn[e - 98] = pre[q];
+            else if (e < 140) o.Bpm[e - 119] = pre[q];
+            else if (e < 149) o.Wu[e - 140] = pre[q];
+            else if (e < 156) o.D[e - 149] = pre[q];
+        }
+    };
+    fetch(K - 1);
+    stash(w.ops[(K - 1) & 1]);
+    for (int e = lane; e < 49; e += 64) w.Pn[e] = 0.0;
+    __syncthreads();
+    const int mi = lane / 7, mj = lane - 7 * mi;
+    for (int k = K - 1; k >= 0; --k) {
+        StageOps &o = w.ops[k & 1];
+        double *fac = s.fac + (size_t)k * FAC_N;
+        if (k >= 1) fetch(k - 1);
+        const bool dyn = (k <= K - 2);
+        // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm ; Cholesky of M = D + Pn in registers
+        if (lane < 21) {
+            const int i = lane / 3, j = lane - 3 * i;
+            o.Bh[lane] = dyn ? o.Bn[lane] + dot_el(o.A, 7, 1, o.Bpm, 3, 1, i, j, 7) : 0.0;
+        } else if (lane >= 32 && lane < 53) {
+            const int e = lane - 32, i = e / 3, j = e - 3 * i;
+            w.WxBp[e] = dot_el(o.Wx, 7, 1, o.Bpm, 3, 1, i, j, 7);
+        }
+        if (dyn) {
+            double m = (lane < 49) ? w.Pn[lane] + (mi == mj ? o.D[mi] : 0.0) : 0.0;
+            bool okc;
+            const double l = chol7_reg(m, lane, okc);
+            if (!okc) good = false;
+            if (lane < 49) w.L[lane] = l;
+            // right-hand sides [Pn | I]
+            for (int e = lane; e < 98; e += 64) { const int r = e / 14, c = e - 14 * r; w.WlLi[e] = (c < 7) ? w.Pn[r * 7 + c] : (c - 7 == r ? 1.0 : 0.0); }
+        }
+        __syncthreads();
+        if (dyn) {
+            // P3: [Wl | Li] = L^-1 [Pn | I], one lane per column
+            if (lane < 14) {
+                for (int p = 0; p < 7; ++p) {
+                    double acc = w.WlLi[p * 14 + lane];
+                    for (int q = 0; q < p; ++q) acc -= w.L[p * 7 + q] * w.WlLi[q * 14 + lane];
+                    w.WlLi[p * 14 + lane] = acc / w.L[p * 7 + p];
+                }
+            }
+            __syncthreads();
+            // P4: Pt = Pn - Wl^T Wl ; G = Wl^T Li ; Minv = Li^T Li
+            if (lane < 49) {
+                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int l = 0; l < 7; ++l) {
+                    const double wi = w.WlLi[l * 14 + mi], wj = w.WlLi[l * 14 + mj];
+                    const double li = w.WlLi[l * 14 + 7 + mi], lj = w.WlLi[l * 14 + 7 + mj];
+                    a1 += wi * wj; a2 += wi * lj; a3 += li * lj;
+                }
+                o.Pt[lane] = w.Pn[lane] - a1; o.G[lane] = a2; o.Minv[lane] = a3;
+                fac[F_PT + lane] = o.Pt[lane]; fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
+            }
+            __syncthreads();
+        } else {
+            if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_PT + lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; }
+            __syncthreads();
+        }
+        // P5: PtA, PtBh, Q0 = Wu + Bpm^T WxBp, Quy0 = Bpm^T Wx
+        if (lane < 49) w.PtA[lane] = dot_el(o.Pt, 7, 1, o.A, 7, 1, mi, mj, 7);
+        if (lane < 21) {
+            const int i = lane / 3, j = lane - 3 * i;
+            w.PtBh[lane] = dot_el(o.Pt, 7, 1, o.Bh, 3, 1, i, j, 7);
+            const int r = lane / 7, c = lane - 7 * r;
+            w.Quy[lane] = dot_el(o.Bpm, 1, 3, o.Wx, 7, 1, r, c, 7);
+        } else if (lane >= 32 && lane < 41) {
+            const int e = lane - 32, i = e / 3, j = e - 3 * i;
+            w.Quu[e] = o.Wu[e] + dot_el(o.Bpm, 1, 3, w.WxBp, 3, 1, i, j, 7);
+        }
+        __syncthreads();
+        // P6: Quu += Bh^T PtBh ; Quy += Bh^T PtA ; Qyy = Wx + A^T PtA
+        if (lane < 49) w.Qyy[lane] = o.Wx[lane] + dot_el(o.A, 1, 7, w.PtA, 7, 1, mi, mj, 7);
+        double quy_add = 0.0, quu_add = 0.0;
+        if (lane < 21) { const int r = lane / 7, c = lane - 7 * r; quy_add = dot_el(o.Bh, 1, 3, w.PtA, 7, 1, r, c, 7); }
+        else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; quu_add = dot_el(o.Bh, 1, 3, w.PtBh, 3, 1, i, j, 7); }
+        __syncthreads();
+        if (lane < 21) w.Quy[lane] += quy_add;
+        else if (lane >= 32 && lane < 41) w.Quu[lane - 32] += quu_add;
+        __syncthreads();
+        // P7+P8: every lane inverts the 3x3 itself; Kg = Qi Quy
+        double Qi[9];
+        if (!inv3_spd(w.Quu, Qi)) good = false;
+        if (lane < 21) {
+            const int r = lane / 7, c = lane - 7 * r;
+            const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
+            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane];
+        }
+        if (lane < 9) fac[F_QI + lane] = Qi[lane];
+        __syncthreads();
+        // P9: P_k = sym(Qyy - Quy^T Kg)
+        if (lane < 49) {
+            double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
+            for (int l = 0; l < 3; ++l) { a1 -= w.Quy[l * 7 + mi] * o.Kg[l * 7 + mj]; a2 -= w.Quy[l * 7 + mj] * o.Kg[l * 7 + mi]; }
+            const double pk = 0.5 * (a1 + a2);
+            w.Pn[lane] = pk; fac[F_P + lane] = pk;
+        }
+        if (k >= 1) stash(w.ops[(k - 1) & 1]);
+        __syncthreads();
+    }
+    return __all(good);
+}
+
+// ---- linear-term sweeps: lane group c = channel, lane r = component ------------------------------
+// Stage matrices are staged through a double-buffered LDS copy (prefetched one node ahead); each lane reads
+// its own rows/columns into registers and the channel vectors travel by ds_bpermute inside the 8-lane group,
+// so a node costs one barrier (the buffer swap).
+struct SweepPre { double v[5]; };
+
+__device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
     const int K = s.K;
     const double *fac = s.fac + (size_t)k * FAC_N;
-    for (int e = lane; e < 49; e += 64) {
-        w.A[e] = (k <= K - 2) ? s.A(k)[e] : 0.0;
-        w.M[e] = (k <= K - 2) ? fac[F_L + e] : 0.0;
-        w.Wl[e] = (k <= K - 2) ? fac[F_WL + e] : 0.0;
-        w.Pt[e] = (k <= K - 2) ? fac[F_PT + e] : 0.0;
-        w.Pn[e] = (k <= K - 2) ? s.fac[(size_t)(k + 1) * FAC_N + F_P + e] : 0.0;
+    const bool dyn = (k <= K - 2);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = lane + 64 * q;
+        double v = 0.0;
+        if (e < 49) v = dyn ? s.A(k)[e] : 0.0;
+        else if (e < 98) v = fac[F_G + e - 49];
+        else if (e < 147) v = fac[F_PT + e - 98];
+        else if (e < 196) v = fac[F_MINV + e - 147];
+        else if (e < 217) v = fac[F_KG + e - 196];
+        else if (e < 238) v = fac[F_BH + e - 217];
+        else if (e < 259) v = (k >= 1) ? s.Bp(k - 1)[e - 238] : 0.0;
+        else if (e < 268) v = fac[F_QI + e - 259];
+        else if (e < 275) v = dyn ? s.nb[(size_t)k * NB_N + N_D + e - 268] : 0.0;
+        pre.v[q] = v;
     }
-    if (lane < 21) {
-        w.Bpm[lane] = (k >= 1) ? s.Bp(k - 1)[lane] : 0.0;
-        w.Quy[lane] = fac[F_QUY + lane];
-        w.Bh[lane] = fac[F_BH + lane];
-    }
-    if (lane < 9) w.Qi[lane] = fac[F_QI + lane];
-    if (lane < 7) w.D[lane] = (k <= K - 2) ? s.nb[(size_t)k * NB_N + N_D + lane] : 0.0;
 }
 
-// Backward linear-term sweep for channels [c0, c1): lane group c handles channel c, lane r = row.
-// Channel data: 0 = rhs record; 1 = unit dtf (aff = Sigma); 2.. = unit terminal gradients.
-__device__ void sweep_backward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
+__device__ __forceinline__ void sweep_stash_mats(StageOps &o, int lane, const SweepPre &pre)
+{
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = lane + 64 * q;
+        const double v = pre.v[q];
+        if (e < 49) o.A[e] = v;
+        else if (e < 98) o.G[e - 49] = v;
+        else if (e < 147) o.Pt[e - 98] = v;
+        else if (e < 196) o.Minv[e - 147] = v;
+        else if (e < 217) o.Kg[e - 196] = v;
+        else if (e < 238) o.Bh[e - 217] = v;
+        else if (e < 259) o.Bpm[e - 238] = v;
+        else if (e < 268) o.Qi[e - 259] = v;
+        else if (e < 275) o.D[e - 268] = v;
+    }
+}
+
+struct ChanIn { double gx, gu, rho, aff; };
+
+// inputs of component r of channel c at node k (channel 0: rhs record; 1: unit dtf; 2..: unit terminal gradients)
+__device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, int k, int c, int r, bool act)
+{
+    ChanIn ci{0.0, 0.0, 0.0, 0.0};
+    if (!act) return ci;
+    const int K = s.K;
+    const bool dyn = (k <= K - 2);
+    if (c == 0) {
+        const double *ch = s.ch + (size_t)k * CH_N + C_RHS;
+        ci.gx = ch[R_GX + r];
+        if (r < 3) ci.gu = ch[R_GU + r];
+        if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
+    } else if (c == 1) { if (dyn) ci.aff = s.Sig(k)[r]; }
+    else if (k == K - 1) ci.gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
+    return ci;
+}
+
+// Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
+__device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
-    const bool act = (c >= c0 && c < c1);
+    const bool act = (c >= c0 && c < c1) && r < 7;
+    const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
+    SweepPre pre;
+    sweep_fetch_mats(s, K - 1, lane, pre);
+    sweep_stash_mats(w.ops[(K - 1) & 1], lane, pre);
+    ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
+    double pnext = 0.0;
+    __syncthreads();
     for (int k = K - 1; k >= 0; --k) {
-        load_sweep_stage(s, w, k, lane);
-        double *ch = s.ch + (size_t)k * CH_N;
-        // channel inputs
-        if (act && r < 7) {
-            double gx = 0.0, rho = 0.0, aff = 0.0;
-            if (c == 0) { gx = ch[C_RHS + R_GX + r]; if (k <= K - 2) { rho = ch[C_RHS + R_RHO + r]; aff = ch[C_RHS + R_AFF + r]; } }
-            else if (c == 1) { if (k <= K - 2) aff = s.Sig(k)[r]; }
-            else if (k == K - 1) gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
-            w.gx[c][r] = gx; w.rho[c][r] = rho; w.aff[c][r] = aff;
-            if (r < 3) w.gu[c][r] = (c == 0) ? ch[C_RHS + R_GU + r] : 0.0;
-            // v = rho + p_{k+1}   (p of the node above is still in w.p)
-            w.v[c][r] = (k <= K - 2) ? rho + w.p[c][r] : 0.0;
+        const StageOps &o = w.ops[k & 1];
+        if (k >= 1) { sweep_fetch_mats(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
+        const bool dyn = (k <= K - 2);
+        double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            Grow[q] = o.G[rr * 7 + q]; Ptrow[q] = o.Pt[rr * 7 + q]; Acol[q] = o.A[q * 7 + rr];
+            Bpmcol[q] = o.Bpm[q * 3 + r3]; Bhcol[q] = o.Bh[q * 3 + r3];
         }
-        __syncthreads();
-        if (k <= K - 2) {
-            // w = L^-1 v  (one lane per channel), pt = p - Wl^T w, t = pt + Pt aff
-            if (act && r == 0) {
-                for (int p = 0; p < 7; ++p) {
-                    double sacc = w.v[c][p];
-                    for (int q = 0; q < p; ++q) sacc -= w.M[p * 7 + q] * w.w[c][q];
-                    w.w[c][p] = sacc / w.M[p * 7 + p];
-                }
-            }
-            __syncthreads();
-            if (act && r < 7) {
-                double acc = w.p[c][r];
-                for (int q = 0; q < 7; ++q) acc -= w.Wl[q * 7 + r] * w.w[c][q];
-                for (int q = 0; q < 7; ++q) acc += w.Pt[r * 7 + q] * w.aff[c][q];
-                w.t[c][r] = acc;
-            }
-        } else if (act && r < 7) w.t[c][r] = 0.0;
-        __syncthreads();
-        if (act && r < 3) {
-            double acc = w.gu[c][r];
-            for (int q = 0; q < 7; ++q) acc += w.Bpm[q * 3 + r] * w.gx[c][q] + w.Bh[q * 3 + r] * w.t[c][q];
-            w.qu[c][r] = acc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + rr];
+        const double v = cur.rho + pnext;
+        double t = pnext;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) t += -Grow[q] * __shfl(v, q, 8) + Ptrow[q] * __shfl(cur.aff, q, 8);
+        if (!dyn || !act) t = 0.0;
+        double qu = cur.gu;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(t, q, 8);
+        if (r >= 3 || !act) qu = 0.0;
+        double p = cur.gx;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) p += Acol[q] * __shfl(t, q, 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) p -= Kgcol[q] * __shfl(qu, q, 8);
+        if (act) {
+            double *ch = s.ch + (size_t)k * CH_N;
+            ch[C_P + c * 7 + r] = p;
+            if (r < 3) ch[C_QU + c * 3 + r] = qu;
+            pnext = p;
         }
-        __syncthreads();
-        if (act && r < 3) {
-            w.u[c][r] = w.Qi[r * 3] * w.qu[c][0] + w.Qi[r * 3 + 1] * w.qu[c][1] + w.Qi[r * 3 + 2] * w.qu[c][2];
-            ch[C_QU + c * 3 + r] = w.qu[c][r];
-        }
-        __syncthreads();
-        if (act && r < 7) {
-            double acc = w.gx[c][r];
-            for (int q = 0; q < 7; ++q) acc += w.A[q * 7 + r] * w.t[c][q];
-            for (int q = 0; q < 3; ++q) acc -= w.Quy[q * 7 + r] * w.u[c][q];
-            w.p[c][r] = acc;
-            ch[C_P + c * 7 + r] = acc;
-        }
+        if (k >= 1) sweep_stash_mats(w.ops[(k - 1) & 1], lane, pre);
+        cur = nxt;
         __syncthreads();
     }
 }
 
-// Forward sweep.  mode 0: channels [c0,c1) accumulate the border coefficients (Sigma.lam, x_K).
-// mode 1: single combined channel (group 0) with p, qu, aff combined by sol[]; adds the result to the direction.
-__device__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int mode, int lane)
+// Forward sweep for channels [c0, c1): stores each channel's trajectory (x, u, nu, lam) per node and
+// accumulates the border coefficients (Sigma.lam, x_K).
+__device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
-    const bool act = (mode == 0) ? (c >= c0 && c < c1) : (c == 0);
-    if (act && r < 7) w.y[c][r] = 0.0;
-    double siglam = 0.0;
+    const bool act = (c >= c0 && c < c1) && r < 7;
+    const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
+    SweepPre pre;
+    sweep_fetch_mats(s, 0, lane, pre);
+    sweep_stash_mats(w.ops[0], lane, pre);
+    ChanIn cur = chan_inputs(s, sd, 0, c, r, act), nxt = cur;
+    auto load_pq = [&](int k, double &qu, double &pn) {
+        qu = 0.0; pn = 0.0;
+        if (!act) return;
+        const double *ch = s.ch + (size_t)k * CH_N;
+        if (r < 3) qu = ch[C_QU + c * 3 + r];
+        if (k <= K - 2) pn = (ch + CH_N)[C_P + c * 7 + r];
+    };
+    double quc, pnc, qun = 0.0, pnn = 0.0;
+    load_pq(0, quc, pnc);
+    double y = 0.0, siglam = 0.0;
     __syncthreads();
     for (int k = 0; k < K; ++k) {
-        load_sweep_stage(s, w, k, lane);
-        const double *ch = s.ch + (size_t)k * CH_N;
-        const double *chn = s.ch + (size_t)(k + 1) * CH_N;
+        const StageOps &o = w.ops[k & 1];
+        if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nxt = chan_inputs(s, sd, k + 1, c, r, act); load_pq(k + 1, qun, pnn); }
+        const bool dyn = (k <= K - 2);
+        double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { Kgrow[q] = o.Kg[r3 * 7 + q]; Arow[q] = o.A[rr * 7 + q]; Gcol[q] = o.G[q * 7 + rr]; Mrow[q] = o.Minv[rr * 7 + q]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { Qirow[q] = o.Qi[r3 * 3 + q]; Bpmrow[q] = o.Bpm[rr * 3 + q]; Bhrow[q] = o.Bh[rr * 3 + q]; }
+        const double Dr = o.D[rr];
+        double u = 0.0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) u -= Kgrow[q] * __shfl(y, q, 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u -= Qirow[q] * __shfl(quc, q, 8);
+        if (r >= 3 || !act) u = 0.0;
+        double x = y, yh = cur.aff;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const double uq = __shfl(u, q, 8); x += Bpmrow[q] * uq; yh += Bhrow[q] * uq; }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) yh += Arow[q] * __shfl(y, q, 8);
+        if (!dyn || !act) yh = 0.0;
+        const double wv = cur.rho + pnc;
+        double nu = 0.0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) nu -= Gcol[q] * __shfl(yh, q, 8) + Mrow[q] * __shfl(wv, q, 8);
         if (act) {
-            if (r < 3) {
-                double q = 0.0;
-                if (mode == 0) q = ch[C_QU + c * 3 + r];
-                else { q = ch[C_QU + r]; for (int j = 0; j < NBD; ++j) q += sd.sol[j] * ch[C_QU + (1 + j) * 3 + r]; }
-                w.qu[c][r] = q;
-            }
-            if (r < 7 && k <= K - 2) {
-                double pn = 0.0, aff = 0.0, rho = 0.0;
-                if (mode == 0) {
-                    pn = chn[C_P + c * 7 + r];
-                    if (c == 0) { aff = ch[C_RHS + R_AFF + r]; rho = ch[C_RHS + R_RHO + r]; }
-                    else if (c == 1) aff = s.Sig(k)[r];
-                } else {
-                    pn = chn[C_P + r];
-                    for (int j = 0; j < NBD; ++j) pn += sd.sol[j] * chn[C_P + (1 + j) * 7 + r];
-                    aff = ch[C_RHS + R_AFF + r] + sd.sol[0] * s.Sig(k)[r];
-                    rho = ch[C_RHS + R_RHO + r];
-                }
-                w.p[c][r] = pn; w.aff[c][r] = aff; w.rho[c][r] = rho;
-            }
-        }
-        __syncthreads();
-        if (act && r < 3) {
-            double acc = w.qu[c][r];
-            for (int q = 0; q < 7; ++q) acc += w.Quy[r * 7 + q] * w.y[c][q];
-            w.t[c][r] = acc;     // Quy y + qu
-        }
-        __syncthreads();
-        if (act && r < 3) w.u[c][r] = -(w.Qi[r * 3] * w.t[c][0] + w.Qi[r * 3 + 1] * w.t[c][1] + w.Qi[r * 3 + 2] * w.t[c][2]);
-        __syncthreads();
-        double xr = 0.0;
-        if (act && r < 7) {
-            xr = w.y[c][r];
-            for (int q = 0; q < 3; ++q) xr += w.Bpm[r * 3 + q] * w.u[c][q];
-            if (k == K - 1 && mode == 0) sd.xK[c][r] = xr;
-            if (k <= K - 2) {
-                double yh = w.aff[c][r];
-                for (int q = 0; q < 7; ++q) yh += w.A[r * 7 + q] * w.y[c][q];
-                for (int q = 0; q < 3; ++q) yh += w.Bh[r * 3 + q] * w.u[c][q];
-                w.yh[c][r] = yh;
-            }
-        }
-        __syncthreads();
-        if (k <= K - 2) {
-            if (act && r < 7) {
-                double acc = w.rho[c][r] + w.p[c][r];
-                for (int q = 0; q < 7; ++q) acc += w.Pn[r * 7 + q] * w.yh[c][q];
-                w.v[c][r] = acc;
-            }
-            __syncthreads();
-            if (act && r == 0) {
-                // nu = -L^-T L^-1 v
-                for (int p = 0; p < 7; ++p) {
-                    double sacc = w.v[c][p];
-                    for (int q = 0; q < p; ++q) sacc -= w.M[p * 7 + q] * w.w[c][q];
-                    w.w[c][p] = sacc / w.M[p * 7 + p];
-                }
-                for (int p = 6; p >= 0; --p) {
-                    double sacc = w.w[c][p];
-                    for (int q = p + 1; q < 7; ++q) sacc -= w.M[q * 7 + p] * w.t[c][q];
-                    w.t[c][p] = sacc / w.M[p * 7 + p];
-                }
-            }
-            __syncthreads();
-        }
-        if (act && r < 7) {
-            double nu = 0.0, lam = 0.0;
-            if (k <= K - 2) {
-                nu = -w.t[c][r];
-                lam = w.D[r] * nu + w.rho[c][r];
+            double *tr = s.traj + ((size_t)k * NCH + c) * TR_N;
+            tr[T_X + r] = x;
+            if (r < 3) tr[T_U + r] = u;
+            if (k == K - 1) sd.xK[c][r] = x;
+            if (dyn) {
+                const double lam = Dr * nu + cur.rho;
+                tr[T_NU + r] = nu; tr[T_LAM + r] = lam;
                 siglam += s.Sig(k)[r] * lam;
-            }
-            if (mode == 1) {
-                double *d = s.dr + (size_t)k * IT_N;
-                d[I_X + r] += xr;
-                if (r < 3) d[I_U + r] += w.u[c][r];
-                if (k <= K - 2) { d[I_NU + r] += nu; d[I_LAM + r] += lam; }
+                y = yh + nu;
             }
         }
-        __syncthreads();
-        if (act && r < 7 && k <= K - 2) w.y[c][r] = w.yh[c][r] - w.t[c][r];
+        if (k + 1 < K) sweep_stash_mats(w.ops[(k + 1) & 1], lane, pre);
+        cur = nxt; quc = qun; pnc = pnn;
         __syncthreads();
     }
-    if (mode == 0) {
-        // reduce Sigma.lam over the 8 lanes of each group
-        siglam += __shfl_xor(siglam, 1, 8);
-        siglam += __shfl_xor(siglam, 2, 8);
-        siglam += __shfl_xor(siglam, 4, 8);
-        if (act && r == 0) sd.siglam[c] = siglam;
+    siglam += __shfl_xor(siglam, 1, 8);
+    siglam += __shfl_xor(siglam, 2, 8);
+    siglam += __shfl_xor(siglam, 4, 8);
+    if (act && r == 0) sd.siglam[c] = siglam;
+    __syncthreads();
+}
+
+// direction += trajectory of channel 0 + sum_j sol[j] * trajectory of channel 1+j ; one lane per (node, component)
+__device__ __noinline__ void combine_channels(const Sat &s, SatData &sd, int lane)
+{
+    const int K = s.K;
+    double sol[NBD];
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) sol[j] = sd.sol[j];
+    for (int e = lane; e < K * TR_N; e += 64) {
+        const int k = e / TR_N, i = e - k * TR_N;
+        if (k == K - 1 && i >= T_NU) continue;
+        const double *tr = s.traj + (size_t)k * NCH * TR_N + i;
+        double v = tr[0];
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) v += sol[j] * tr[(1 + j) * TR_N];
+        const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
+        s.dr[(size_t)k * IT_N + off] += v;
     }
+    if (lane == 0) { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
     __syncthreads();
 }
 
 // Border matrix from the unit channels (1..7), LU with partial pivoting by lane 0.
-__device__ bool border_factor(SatData &sd, int lane)
+__device__ __noinline__ bool border_factor(SatData &sd, int lane)
 {
     if (lane == 0) {
         double wex[NTERM];
@@ -891,7 +957,7 @@ __device__ bool border_factor(SatData &sd, int lane)
 }
 
 // Right-hand side of the border system from channel 0, then solve with the stored LU.
-__device__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const double *gex, int lane)
+__device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const double *gex, int lane)
 {
     if (lane == 0) {
         double rb[NBD];
@@ -922,7 +988,7 @@ __device__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const 
 
 // Residual of the reduced KKT system at the current direction -> rhs record of channel 0
 // ("Linear solve").  Stage-parallel.  Returns gtf_rhs, rvt_rhs, gterm[] via sd.red / gterm.
-__device__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
+__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
 {
     const int K = s.K;
     double gtf_part = 0.0;
@@ -1033,8 +1099,38 @@ __device__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gt
     __syncthreads();
 }
 
+// Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
+// themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).
+__device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
+{
+    const int K = s.K;
+    for (int e = lane; e < K * 24; e += 64) {
+        const int k = e / 24, i = e - k * 24;
+        const double *nb = s.nb + (size_t)k * NB_N;
+        double v;
+        if (i < 7) v = (k == 0) ? 0.0 : ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]);
+        else if (i < 10) v = nb[N_GU + i - 7];
+        else if (i < 17) v = (k <= K - 2) ? nb[N_RHO + i - 10] : 0.0;
+        else v = (k <= K - 2) ? -nb[N_E + i - 17] : 0.0;
+        s.ch[(size_t)k * CH_N + C_RHS + i] = v;
+    }
+    gtf_rhs = sd.gtf;
+    rvt_rhs = -sd.cv;
+    for (int t = 0; t < NTERM; ++t) gterm[t] = sd.tgh[t];
+    __syncthreads();
+    if (lane == 0) {
+        double *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
+        for (int t = 0; t < NTERM; ++t) {
+            const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
+        }
+        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_rhs * sd.avt[i];
+    }
+    __syncthreads();
+}
+
 // dt, ds, dz by back-substitution ("Linear solve") and the fraction-to-the-boundary step.
-__device__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
+__device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
 {
     const int K = s.K;
     double amax = 1.0;
@@ -1116,7 +1212,7 @@ __device__ double finish_direction(const Sat &s, SatData &sd, double mu, double 
 }
 
 // iterate <- iterate + a * direction, slack reset and multiplier safeguard (stage-parallel)
-__device__ void apply_step(const Sat &s, SatData &sd, double a, double mu, int lane)
+__device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, double mu, int lane)
 {
     const int K = s.K;
 #define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
@@ -1168,8 +1264,19 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
     hipLaunchKernelGGL(merge_status_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, dstat, status);
 }
 
-__global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
+#ifdef MPCX_PHASE_TIMING
+#define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, pt0_ = 0; unsigned pc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define PT_BEGIN pt0_ = __builtin_amdgcn_s_memtime();
+#define PT_END(i) { pt_[i] += __builtin_amdgcn_s_memtime() - pt0_; pc_[i]++; }
+#else
+#define PT_DECL
+#define PT_BEGIN
+#define PT_END(i)
+#endif
+
+__global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
 {
+    PT_DECL
     __shared__ SatData sd;
     __shared__ Scratch w;
     const int lane = threadIdx.x;
@@ -1187,6 +1294,7 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
     s.nb = ws; ws += (size_t)K * NB_N;
     s.fac = ws; ws += (size_t)K * FAC_N;
     s.ch = ws; ws += (size_t)K * CH_N;
+    s.traj = ws; ws += (size_t)K * NCH * TR_N;
     s.itg = ws; ws += GL_N;
     s.drg = ws; ws += GL_N;
     s.rbh = ws;
@@ -1241,30 +1349,37 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
     for (int iter = 0;; ++iter) {
         it_count = iter;
         ResAcc r0;
-        eval_residual(s, sd, 0.0, 0.0, lane, r0);
-        E0 = scaled_error(r0, K);
+        PT_BEGIN
+        eval_residual(s, sd, 0.0, mu, lane, r0);          // one evaluation serves E_0, E_mu (any mu) and the line search
+        PT_END(0)
+        E0 = scaled_error(r0, K, 0.0);
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
         n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
         if (n_acc >= o.acc_iter) { status = MPCX_ST_ACCEPTABLE; break; }
         if (iter >= o.max_iter) { status = (E0 <= o.acc_tol) ? MPCX_ST_ACCEPTABLE : MPCX_ST_MAXITER; break; }
         // monotone barrier update (ipopt: kappa_eps 10, kappa_mu 0.2, theta_mu 1.5)
+        const double mu_in = mu;
         for (int guard = 0; guard < 64; ++guard) {
-            ResAcc rm;
-            eval_residual(s, sd, 0.0, mu, lane, rm);
-            if (scaled_error(rm, K) <= 10.0 * mu && mu > o.tol / 10.0) mu = fmax(o.tol / 10.0, fmin(0.2 * mu, pow(mu, 1.5)));
+            if (scaled_error(r0, K, mu) <= 10.0 * mu && mu > o.tol / 10.0) mu = fmax(o.tol / 10.0, fmin(0.2 * mu, pow(mu, 1.5)));
             else break;
+        }
+        if (mu != mu_in) {                                   // the 2-norm of F_mu needs the new mu
+            PT_BEGIN
+            eval_residual(s, sd, 0.0, mu, lane, r0);
+            PT_END(0)
         }
         // Newton direction, with Hessian regularisation retries on breakdown
         bool have_dir = false;
         double delta_w = 0.0;
         for (int trial = 0; trial < 10 && !have_dir; ++trial) {
+            PT_BEGIN
             newton_blocks(s, sd, mu, delta_w, lane);
+            PT_END(1)
+            PT_BEGIN
             bool ok = riccati_factor(s, sd, w, lane);
+            PT_END(2)
             if (ok) {
-                // unit channels 1..7: backward vectors + border coefficients
-                for (int e = lane; e < NCH * 8; e += 64) ((double *)w.p)[e] = 0.0;
-                __syncthreads();
                 // direction := (0, ..., -lam, -lam_vt) so that the first residual carries no multipliers
                 for (int k = lane; k < K; k += 64) {
                     double *d = s.dr + (size_t)k * IT_N;
@@ -1274,29 +1389,34 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
                 }
                 if (lane == 0) { for (int i = 0; i < GL_N; ++i) s.drg[i] = 0.0; s.drg[G_LVT] = -s.itg[G_LVT]; }
                 __syncthreads();
-                const int passes = 1 + ((delta_w == 0.0) ? o.n_refine : 0);
+                // iterative refinement only once a terminal barrier weight is stiff enough to cost digits
+                double twmax = 0.0;
+                for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
+                const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
                 for (int pass = 0; pass < passes && ok; ++pass) {
                     double gtf_rhs, rvt_rhs, gterm[NTERM], gex[NTERM];
-                    reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                    PT_BEGIN
+                    if (pass == 0) initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                    else reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                    PT_END(5)
                     for (int t = 0; t < NTERM; ++t) {
                         const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
                         gex[t] = gterm[t] * (1.0 - share);
                     }
-                    for (int e = lane; e < NCH * 8; e += 64) ((double *)w.p)[e] = 0.0;
-                    __syncthreads();
-                    if (pass == 0) {
-                        sweep_backward(s, sd, w, 0, NCH, lane);
-                        sweep_forward(s, sd, w, 0, NCH, 0, lane);
-                        ok = border_factor(sd, lane);
-                        if (!ok) break;
-                    } else {
-                        sweep_backward(s, sd, w, 0, 1, lane);
-                        sweep_forward(s, sd, w, 0, 1, 0, lane);
-                    }
+                    // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only
+                    const int c1 = (pass == 0) ? NCH : 1;
+                    PT_BEGIN
+                    sweep_backward(s, sd, w, 0, c1, lane);
+                    PT_END(3)
+                    PT_BEGIN
+                    sweep_forward(s, sd, w, 0, c1, lane);
+                    if (pass == 0) ok = border_factor(sd, lane);
+                    PT_END(4)
+                    if (!ok) break;
+                    PT_BEGIN
                     border_solve(sd, gtf_rhs, rvt_rhs, gex, lane);
-                    sweep_forward(s, sd, w, 0, 1, 1, lane);
-                    if (lane == 0) { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
-                    __syncthreads();
+                    combine_channels(s, sd, lane);
+                    PT_END(7)
                 }
             }
             if (ok) {
@@ -1314,21 +1434,25 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
         }
         if (!have_dir) { status = MPCX_ST_NUMERIC; break; }
         const double tau = fmax(0.99, 1.0 - mu);
+        PT_BEGIN
         double alpha = finish_direction(s, sd, mu, tau, lane);
+        PT_END(8)
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
-        ResAcc rc;
-        eval_residual(s, sd, 0.0, mu, lane, rc);
-        const double rn0 = sqrt(rc.sq);
+        const double rn0 = sqrt(r0.sq);
         const int nzc = n_ineq(K);
         for (int ls = 0; ls < 30; ++ls) {
             ResAcc rt;
+            PT_BEGIN
             eval_residual(s, sd, alpha, mu, lane, rt);
+            PT_END(10)
             const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
             const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
             if (dec && cen) break;
             alpha *= 0.5;
         }
+        PT_BEGIN
         apply_step(s, sd, alpha, mu, lane);
+        PT_END(9)
     }
 
     // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----
@@ -1345,6 +1469,11 @@ __global__ __launch_bounds__(64) void solve_kernel(SolveArgs a)
         a.status[sat] = status;
         a.iters[sat] = it_count;
         a.kkt[sat] = E0;
+#ifdef MPCX_PHASE_TIMING
+        // diagnostic build only: cycle sums per phase into the NU block of this satellite (never shipped)
+        double *dbg = a.NU + (size_t)sat * 7 * K;
+        for (int i = 0; i < 12; ++i) { dbg[2 * i] = (double)pt_[i]; dbg[2 * i + 1] = (double)pc_[i]; }
+#endif
     }
 }
 

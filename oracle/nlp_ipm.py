@@ -49,6 +49,7 @@ BOUND_PUSH = 1e-2
 KAPPA_SIGMA = 100.0
 GAMMA_NBHD = 1e-3
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
+REFINE_TW = 1e9       # iterative refinement only once a terminal barrier weight exceeds this
 N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
 
 
@@ -242,8 +243,9 @@ def newton_blocks(P, it, mu, delta_w=0.0):
 
 def riccati_factor(P, nb):
     """Backward Riccati sweep in the shifted state y_k = x_k - Bp_{k-1} u_k (absorbs the first-order
-    hold), nu_k eliminated per stage by a 7x7 Cholesky.  Terminal Hessian: soft part + capped share of
-    the rank-1 barrier weights + augmented-Lagrangian term gamma a_vt a_vt^T (exact, see solve)."""
+    hold), nu_k eliminated per stage through M = D + P_{k+1} (Cholesky, explicit inverse so that the
+    linear-term sweeps are pure matrix-vector products).  Terminal Hessian: soft part + capped share of
+    the rank-1 barrier weights + augmented-Lagrangian term gamma a_vt a_vt^T (exact, see riccati_solve)."""
     K = P.K; Wx, Wu, D = nb["Wx"], nb["Wu"], nb["D"]
     WxK = nb["WxK_soft"].copy()
     win = []
@@ -253,53 +255,56 @@ def riccati_factor(P, nb):
     avt = nb["avt"]
     gam = (1.0 + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt)
     WxK += gam * np.outer(avt, avt)
-    F = dict(P=np.zeros((K, 7, 7)), L=np.zeros((K, 7, 7)), Wl=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
-             Quu_inv=np.zeros((K, 3, 3)), Quy=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)), win=win, gam=gam, WxK=WxK)
+    F = dict(P=np.zeros((K, 7, 7)), Minv=np.zeros((K, 7, 7)), G=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
+             Qi=np.zeros((K, 3, 3)), Kg=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)), win=win, gam=gam, WxK=WxK)
+    I7 = np.eye(7)
     for k in range(K - 1, -1, -1):
         Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
         Wxk = WxK if k == K - 1 else Wx[k]
         if k <= K - 2:
             Pn = F["P"][k + 1]
             L = np.linalg.cholesky(np.diag(D[:, k]) + Pn)            # raises LinAlgError when not PD
-            Wl = np.linalg.solve(L, Pn)
+            WlLi = np.linalg.solve(L, np.hstack([Pn, I7]))           # [L^-1 Pn | L^-1]
+            Wl, Li = WlLi[:, :7], WlLi[:, 7:]
             Pt = Pn - Wl.T @ Wl; Pt = 0.5 * (Pt + Pt.T)
+            F["G"][k] = Wl.T @ Li                                    # Pn M^-1
+            F["Minv"][k] = Li.T @ Li
             Ah = P.A[k]; Bh = P.A[k] @ Bpm + P.Bn[k]
-            F["L"][k] = L; F["Wl"][k] = Wl
         else:
             Pt = np.zeros((7, 7)); Ah = np.zeros((7, 7)); Bh = np.zeros((7, 3))
         Quu = Wu[k] + Bpm.T @ Wxk @ Bpm + Bh.T @ Pt @ Bh
         Quy = Bpm.T @ Wxk + Bh.T @ Pt @ Ah
         np.linalg.cholesky(Quu)
         Qi = np.linalg.inv(Quu)
-        Pk = Wxk + Ah.T @ Pt @ Ah - Quy.T @ Qi @ Quy
-        F["P"][k] = 0.5 * (Pk + Pk.T); F["Pt"][k] = Pt; F["Quu_inv"][k] = Qi; F["Quy"][k] = Quy; F["Bh"][k] = Bh
+        Kg = Qi @ Quy
+        Pk = Wxk + Ah.T @ Pt @ Ah - Quy.T @ Kg
+        F["P"][k] = 0.5 * (Pk + Pk.T); F["Pt"][k] = Pt; F["Qi"][k] = Qi; F["Kg"][k] = Kg; F["Bh"][k] = Bh
     return F
 
 
 def riccati_channel(P, nb, F, gx, gu, rho, aff):
-    """one linear-term sweep (backward + forward) for given gradients / affine dynamics terms"""
+    """one linear-term sweep (backward + forward) for given gradients / affine dynamics terms; only
+    matrix-vector products with the stored stage matrices"""
     K = P.K; D = nb["D"]
     p = np.zeros((K, 7)); qu = np.zeros((K, 3))
     for k in range(K - 1, -1, -1):
         Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
         if k <= K - 2:
-            pt = p[k + 1] - F["Wl"][k].T @ np.linalg.solve(F["L"][k], rho[:, k] + p[k + 1])
-            t = pt + F["Pt"][k] @ aff[:, k]
+            t = p[k + 1] - F["G"][k] @ (rho[:, k] + p[k + 1]) + F["Pt"][k] @ aff[:, k]
             Ah = P.A[k]
         else:
             t = np.zeros(7); Ah = np.zeros((7, 7))
         qu[k] = gu[:, k] + Bpm.T @ gx[:, k] + F["Bh"][k].T @ t
-        p[k] = gx[:, k] + Ah.T @ t - F["Quy"][k].T @ (F["Quu_inv"][k] @ qu[k])
+        p[k] = gx[:, k] + Ah.T @ t - F["Kg"][k].T @ qu[k]
     X = np.zeros((7, K)); U = np.zeros((3, K)); NU = np.zeros((7, K - 1)); LAM = np.zeros((7, K - 1))
     y = np.zeros(7)
     for k in range(K):
         Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
-        u = -F["Quu_inv"][k] @ (F["Quy"][k] @ y + qu[k])
+        u = -(F["Kg"][k] @ y) - F["Qi"][k] @ qu[k]
         U[:, k] = u; X[:, k] = y + Bpm @ u
         if k <= K - 2:
             yh = P.A[k] @ y + F["Bh"][k] @ u + aff[:, k]
-            rhs = rho[:, k] + p[k + 1] + F["P"][k + 1] @ yh
-            nu = -np.linalg.solve(F["L"][k].T, np.linalg.solve(F["L"][k], rhs))
+            nu = -(F["G"][k].T @ yh) - F["Minv"][k] @ (rho[:, k] + p[k + 1])
             NU[:, k] = nu; LAM[:, k] = D[:, k] * nu + rho[:, k]
             y = yh + nu
     return X, U, NU, LAM
@@ -383,7 +388,8 @@ def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
     zero = dict(X=np.zeros((7, K)), U=np.zeros((3, K)), NU=np.zeros((7, K - 1)), tf=0.0,
                 lam=-it.lam.copy(), lam_vt=-it.lam_vt)             # so that lam + dlam = 0: rhs has no multipliers
     d = zero
-    for _ in range(1 + n_refine):
+    passes = 1 + (n_refine if max(w for (a, w, gh) in nb["term"]) > REFINE_TW else 0)
+    for _ in range(passes):
         rhs = reduced_residual(P, nb, it, d)
         c = riccati_solve(P, nb, F, rhs)
         d = dict(X=d["X"] + c["X"], U=d["U"] + c["U"], NU=d["NU"] + c["NU"], tf=d["tf"] + c["tf"],

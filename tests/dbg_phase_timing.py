@@ -1,0 +1,25 @@
+"""diagnostic (not a test): per-phase cycle shares of solve_kernel from a -DMPCX_PHASE_TIMING build"""
+import os, sys, subprocess, ctypes as C
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from mpconstellation_amd import build as b
+lib = "/tmp/libmpcx_timing.so"
+subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DMPCX_PHASE_TIMING", "-o", lib] + b.sources())
+from mpconstellation_amd import _ffi
+_ffi.LIB_PATH = lib
+from mpconstellation_amd import solve_batch
+G = os.path.join(ROOT, "tests", "golden")
+d = np.load(os.path.join(G, "disc_tan_K30_tf1.npz"))
+x, u, tf, cst = d["x"], d["u"], float(d["tf"]), d["const"]
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rep = lambda a: np.repeat(a[None], S, axis=0)
+r = solve_batch(rep(d["A"]), rep(d["Bp"]), rep(d["Bn"]), rep(d["Sigma"]), rep(d["xi"]), rep(x), rep(u), [tf] * S, rep(cst),
+                [np.linalg.norm(x[:3, -1])] * S)
+names = ["eval_res(E0,Emu,r0)", "newton_blocks", "riccati_factor", "sweep_bwd 8ch", "sweep_fwd 8ch+border", "reduced_residual",
+         "ch0 bwd+fwd", "border_solve+comb fwd", "finish_direction", "apply_step", "line-search evals", "-"]
+t = r.NU[0].ravel()[:24].reshape(12, 2)
+tot = t[:, 0].sum()
+print("iters", r.iters[0], "status", r.status[0], "total cycles(100MHz ticks?)", tot)
+for n, (cyc, cnt) in zip(names, t):
+    if cnt: print(f"{n:28s} {cyc/tot*100:6.2f}%  calls {int(cnt):5d}  per call {cyc/cnt:10.0f}")

@@ -93,5 +93,5 @@ def test_status_codes(golden_dir):
     P = problem(golden_dir, "tan_K20_tf2")
     r = N.solve(P, max_iter=4)
     assert r["status"] == N.ST_MAXITER and r["iters"] == 4
-    r = N.solve(P, tol=1e-10, acceptable_tol=1e-6, max_iter=120)      # below what fp64 reaches here: stops at the acceptable level
+    r = N.solve(P, tol=1e-15, acceptable_tol=1e-6, max_iter=120)      # below what fp64 reaches: stops at the acceptable level
     assert r["status"] == N.ST_ACCEPTABLE and r["kkt"] <= 1e-6
