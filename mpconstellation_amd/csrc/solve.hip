@@ -37,7 +37,7 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 0.1;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -1320,10 +1320,10 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
         // slacks pushed into the interior (bound_push), multipliers 1
-        for (int i = 0; i < 7; ++i) { p[I_STP + i] = kBoundPush; p[I_STN + i] = kBoundPush; p[I_ZTP + i] = 1.0; p[I_ZTN + i] = 1.0; }
-        p[I_SU] = fmax(-(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u), kBoundPush * fmax(1.0, fabs(sd.b_u))); p[I_ZU] = 1.0;
-        p[I_SRMAX] = fmax(-(rn * rn - sd.b_rmax), kBoundPush * fmax(1.0, fabs(sd.b_rmax))); p[I_ZRMAX] = 1.0;
-        p[I_SRMIN] = fmax(-(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin), kBoundPush * fmax(1.0, fabs(sd.b_rmin))); p[I_ZRMIN] = 1.0;
+        for (int i = 0; i < 7; ++i) { p[I_STP + i] = kBoundPush; p[I_STN + i] = kBoundPush; p[I_ZTP + i] = kMuInit / kBoundPush; p[I_ZTN + i] = kMuInit / kBoundPush; }
+        p[I_SU] = fmax(-(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u), kBoundPush * fmax(1.0, fabs(sd.b_u))); p[I_ZU] = kMuInit / p[I_SU];
+        p[I_SRMAX] = fmax(-(rn * rn - sd.b_rmax), kBoundPush * fmax(1.0, fabs(sd.b_rmax))); p[I_ZRMAX] = kMuInit / p[I_SRMAX];
+        p[I_SRMIN] = fmax(-(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin), kBoundPush * fmax(1.0, fabs(sd.b_rmin))); p[I_ZRMIN] = kMuInit / p[I_SRMIN];
     }
     if (lane == 0) {
         for (int i = 0; i < GL_N; ++i) { s.itg[i] = 0.0; s.drg[i] = 0.0; }
@@ -1332,18 +1332,18 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         for (int j = 0; j < 6; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * xK[i];
-            s.itg[G_STERM + j] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[G_ZTERM + j] = 1.0;
+            s.itg[G_STERM + j] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[G_ZTERM + j] = kMuInit / s.itg[G_STERM + j];
         }
         const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
-        s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = 1.0;
+        s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = kMuInit / s.itg[G_SRF];
         const double tf = sd.tfbar;
         s.itg[G_TF] = tf;
-        s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = 1.0;
-        s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = 1.0;
+        s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = kMuInit / s.itg[G_STF];
+        s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = kMuInit / s.itg[G_STF + 1];
     }
     __syncthreads();
 
-    double mu = 0.1;
+    double mu = kMuInit;
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
     for (int iter = 0;; ++iter) {

@@ -13,7 +13,9 @@ What is restated
 * The solver it hands that NLP to is ipopt (third-party, unpinned, not installed here).  What is
   restated of ipopt is its published primal-dual interior-point scheme (Waechter & Biegler, Math.
   Prog. 106, 2006): slack form of the inequalities, relaxation of every bound by 1e-8*max(1,|b|)
-  (bound_relax_factor), slack/multiplier initialisation (bound_push 1e-2, multipliers 1),
+  (bound_relax_factor), slack initialisation (bound_push 1e-2), multipliers z = mu_init/s (ipopt's
+  bound_mult_init_method = mu-based; its default 'constant 1' left 7 of 4096 benchmark satellites crawling
+  along one boundary for 90-165 iterations),
   fraction-to-the-boundary rule tau = max(0.99, 1-mu), monotone barrier update
   mu <- max(tol/10, min(0.2 mu, mu^1.5)) once E_mu <= 10 mu, the scaled optimality error E_0 with
   s_max = 100 and tol = 1e-8, multiplier safeguard z in [mu/(kappa s), kappa mu/s].
@@ -48,6 +50,7 @@ BOUND_RELAX = 1e-8
 BOUND_PUSH = 1e-2
 KAPPA_SIGMA = 100.0
 GAMMA_NBHD = 1e-3
+MU_INIT = 0.1
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
 REFINE_TW = 1e9       # iterative refinement only once a terminal barrier weight exceeds this
 N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
@@ -145,7 +148,7 @@ def initial_iterate(P):
     bnd = {"u": P.b_u, "rmax": P.b_rmax, "rmin": P.b_rmin, "term": P.bT, "rfmax": P.b_rfmax, "tp": 0.0,
            "tn": 0.0, "tf": P.b_tf}
     it.s = {k: np.maximum(-v, BOUND_PUSH * np.maximum(1.0, np.abs(bnd[k]))) for k, v in g.items()}
-    it.z = {k: np.ones_like(v) for k, v in g.items()}
+    it.z = {k: MU_INIT / it.s[k] for k in g}        # ipopt bound_mult_init_method = mu-based
     return it
 
 
@@ -468,7 +471,7 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
           verbose=False):
     """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective)."""
     it = initial_iterate(P)
-    mu = 0.1
+    mu = MU_INIT
     n_acc = 0; status = ST_MAXITER; k_it = 0
     for k_it in range(max_iter + 1):
         E0 = optimality_error(P, it, 0.0)[0]
