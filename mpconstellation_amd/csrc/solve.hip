@@ -37,7 +37,7 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 0.1;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -1320,7 +1320,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
         // slacks pushed into the interior (bound_push), multipliers 1
-        for (int i = 0; i < 7; ++i) { p[I_STP + i] = kBoundPush; p[I_STN + i] = kBoundPush; p[I_ZTP + i] = kMuInit / kBoundPush; p[I_ZTN + i] = kMuInit / kBoundPush; }
+        // L1 slack pairs start dual feasible and centred: z+ = z- = w_nu/2, s = t = mu/z
+        if (k <= K - 2) for (int i = 0; i < 7; ++i) { const double zl = sd.w_nu / 2.0, sl = kMuInit / zl; p[I_T + i] = sl; p[I_STP + i] = sl; p[I_STN + i] = sl; p[I_ZTP + i] = zl; p[I_ZTN + i] = zl; }
+        else for (int i = 0; i < 7; ++i) { p[I_STP + i] = 1.0; p[I_STN + i] = 1.0; p[I_ZTP + i] = 1.0; p[I_ZTN + i] = 1.0; }
         p[I_SU] = fmax(-(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u), kBoundPush * fmax(1.0, fabs(sd.b_u))); p[I_ZU] = kMuInit / p[I_SU];
         p[I_SRMAX] = fmax(-(rn * rn - sd.b_rmax), kBoundPush * fmax(1.0, fabs(sd.b_rmax))); p[I_ZRMAX] = kMuInit / p[I_SRMAX];
         p[I_SRMIN] = fmax(-(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin), kBoundPush * fmax(1.0, fabs(sd.b_rmin))); p[I_ZRMIN] = kMuInit / p[I_SRMIN];

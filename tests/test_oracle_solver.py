@@ -85,8 +85,9 @@ def test_against_scipy_trust_constr(golden_dir):
     assert r["status"] == 0
     # two different algorithms, two formulations of the tangential constraint, tol 1e-8 each: 1e-5 on a flat objective
     assert abs(r["tf"] - float(f["tf_opt"])) < 1e-6
-    assert np.abs(r["X"] - f["X"]).max() < 1e-5 and np.abs(r["U"] - f["U"]).max() < 1e-5
-    assert abs(r["objective"] - float(f["fun"])) < 1e-6
+    # u is held only by the trust-region weight 2 w_tr = 0.004, so a KKT error of 1e-8 leaves it loose to ~1e-5
+    assert np.abs(r["X"] - f["X"]).max() < 1e-5 and np.abs(r["U"] - f["U"]).max() < 5e-5
+    assert abs(r["objective"] - float(f["fun"])) < 5e-6      # includes w_nu * sum(t) with t at the final barrier level
 
 
 def test_status_codes(golden_dir):

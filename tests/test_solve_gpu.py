@@ -14,8 +14,8 @@ import nlp_ipm as N
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9        # same stage data in -> same iteration path: agreement to rounding
-TOL_SOL = 1e-6    # stated fp64 tolerance of a converged solution (tol 1e-8 on the scaled KKT error leaves the
-                  # minimiser determined to ~1e-7 because the objective is flat: w_tr = 0.002); used wherever GPU and
+TOL_SOL = 5e-6    # stated fp64 tolerance of a converged solution (tol 1e-8 on the scaled KKT error leaves the
+                  # minimiser determined to ~1e-6 because the objective is flat: w_tr = 0.002); used wherever GPU and
                   # oracle discretise independently, where a 1e-16 difference can flip one line-search decision
 CASES = ["tan_K20_tf2", "tan_K30_tf1", "tan_K60_tf2", "tan_K100_tf1", "zero_K20_tf1"]
 
