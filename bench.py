@@ -6,6 +6,7 @@ the reference, one SCP iteration) over every satellite of the batch, inputs resi
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement"."""
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -16,16 +17,122 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {            # BASELINE.json configs
-    "S64_K30": (64, 30), "S4096_K30": (4096, 30), "S4096_K100": (4096, 100), "S8192_K30": (8192, 30),
+WORKLOADS = {            # BASELINE.json configs: name -> (satellites per GPU, nodes K, SCP iterations per MPC step)
+    "S64_K30": (64, 30, 1),            # configs[1]
+    "S4096_K30": (4096, 30, 1),        # configs[2]
+    "S4096_K100_scp2": (4096, 100, 2), # configs[3]: 2 SCP iterations with nonlinear re-rollout (control.py:166,183-227)
+    "S8192_K30": (8192, 30, 1),        # configs[4] per GPU (65,536 over 8)
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table
 
 
 def algorithmic_bytes(K):
-    """compulsory traffic of one fused satellite-MPC-step: read xbar(7K) ubar(3K) tf consts(5),
-    write x(7K) u(3K) nu(7K) tf status  =  8(27K+7)+8 bytes."""
+    """compulsory traffic of one fused satellite-MPC-step (one SCP iteration): read xbar(7K) ubar(3K)
+    tf consts(5), write x(7K) u(3K) nu(7K) tf status  =  8(27K+7)+8 bytes."""
     return 8 * (27 * K + 7) + 8
+
+
+class Runner:
+    """Device-resident state of one workload on one GPU; step() enqueues one MPC step for every satellite."""
+
+    def __init__(self, workload, rank, world, local_rank):
+        import torch
+        from mpconstellation_amd import _ffi
+        from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+        from mpconstellation_amd.simulator import propagate_batch
+        from mpconstellation_amd.sharding import shard_block
+        self.torch, self.ffi = torch, _ffi
+        self.lib = _ffi.load(); self.ctx = _ffi.context(local_rank)
+        S, K, n_scp = WORKLOADS[workload]
+        self.S, self.K, self.n_scp = S, K, n_scp
+        S_total = S * world
+        first, count = shard_block(S_total, world, rank)        # contiguous block, no exchange
+        assert count == S
+        states = constellation_states(S_total, first=first, count=S)
+        y0, consts = normalize_batch(states)
+        tfbar = np.ones(S)
+        xbar, st, _ = propagate_batch(y0, tfbar, consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, device=local_rank)
+        assert (st == 0).all()
+        ubar = np.ascontiguousarray(tangential_thrust(xbar, 0.5))
+        r_des = np.linalg.norm(xbar[:, 0:3, -1], axis=1)
+        self.host = dict(xbar=xbar, ubar=ubar, tfbar=tfbar, consts=consts, r_des=r_des)
+        dev = torch.device("cuda", local_rank)
+        t64 = dict(dtype=torch.float64, device=dev)
+        T = lambda a: torch.tensor(a, **t64)
+        self.d_x0, self.d_u0, self.d_tf0 = T(xbar), T(ubar), T(tfbar)
+        self.d_x, self.d_u, self.d_tf = self.d_x0.clone(), self.d_u0.clone(), self.d_tf0.clone()
+        self.d_c, self.d_rd, self.d_y0, self.d_one = T(consts), T(r_des), T(y0), T(np.ones(S))
+        self.d_X = torch.empty((S, 7, K), **t64); self.d_U = torch.empty((S, 3, K), **t64); self.d_NU = torch.empty((S, 7, K), **t64)
+        self.d_tfo = torch.empty(S, **t64); self.d_kkt = torch.empty(S, **t64)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.d_st = torch.empty(S, **i32); self.d_it = torch.empty(S, **i32); self.d_dst = torch.empty(S, **i32)
+        self.d_pst = torch.empty(S, **i32); self.d_pns = torch.empty(S, **i32)
+        self.d_stage = torch.empty((S, K - 1, _ffi.STAGE_DOUBLES), **t64)
+        self.d_ws = torch.empty(self.lib.mpcx_solve_workspace_bytes(S, K) // 8 + 8, **t64)
+        self.opts = _ffi.make_solve_opts({})
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.solve_events = []
+
+    def step(self, record=False):
+        torch, lib, ctx, ffi = self.torch, self.lib, self.ctx, self.ffi
+        p = lambda t: C.c_void_p(t.data_ptr())
+        S, K = self.S, self.K
+        st = C.c_void_p(self.stream)
+        if self.n_scp > 1:                      # every MPC step starts from the same reference rollout
+            self.d_x.copy_(self.d_x0); self.d_u.copy_(self.d_u0); self.d_tf.copy_(self.d_tf0)
+        for it in range(self.n_scp):
+            # the two launches of mpcx_mpc_step_batch_dev, issued separately so the solve can be bracketed by events
+            ffi.check(lib.mpcx_discretize_stages_dev(ctx, S, K, K, p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c), 0, 1e-2,
+                                                     p(self.d_stage), p(self.d_dst), st), ctx, "discretize")
+            if record:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+            ffi.check(lib.mpcx_solve_batch_dev(ctx, S, K, p(self.d_stage), p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c),
+                                               p(self.d_rd), C.byref(self.opts), p(self.d_X), p(self.d_U), p(self.d_NU), p(self.d_tfo),
+                                               p(self.d_st), p(self.d_it), p(self.d_kkt), p(self.d_ws), st), ctx, "solve")
+            if record:
+                e1.record(); self.solve_events.append((e0, e1))
+            if self.n_scp > 1:
+                # SCP re-linearisation point (control.py:221,227): nonlinear rollout under the optimised FOH sequence over
+                # tf_u; the new reference thrust is the sequence itself (FOH at its own nodes)
+                ffi.check(lib.mpcx_propagate_batch_dev(ctx, S, K, p(self.d_y0), p(self.d_tfo), p(self.d_c), 0, ffi.CTRL_SEQUENCE,
+                                                       p(self.d_U), K, p(self.d_one), 1e-3, p(self.d_x), p(self.d_pst), p(self.d_pns),
+                                                       st), ctx, "propagate")
+                self.d_u.copy_(self.d_U); self.d_tf.copy_(self.d_tfo)
+
+    def solver_stats(self):
+        status = self.d_st.cpu().numpy(); dstat = self.d_dst.cpu().numpy()
+        status = np.where(dstat != 0, dstat, status)
+        return status, self.d_it.cpu().numpy(), self.d_kkt.cpu().numpy()
+
+
+def measure(runner, steps, warmup, world):
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step(record=True)
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    solve_ms = float(np.mean([a.elapsed_time(b) for a, b in runner.solve_events]))
+    return elapsed, solve_ms
+
+
+def measured_traffic(workload, kernel="solve_kernel"):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        w = json.load(open(f)).get("workloads", {}).get(workload, {}).get(kernel)
+        if w: return w["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -35,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="S64_K30", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra S4096_K30 measurement of the default run")
     ap.add_argument("--cpu-sample", type=int, default=6, help="satellites solved by the CPU oracle")
     args = ap.parse_args()
 
@@ -48,86 +156,53 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmpcx has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    from mpconstellation_amd import _ffi
-    from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
-    from mpconstellation_amd.simulator import propagate_batch
-    lib = _ffi.load(); ctx = _ffi.context(local_rank)
-
-    S, K = WORKLOADS[args.workload]      # per GPU (weak scaling: satellites shard with no exchange)
-    S_total = S * world
-    # ---- synthetic inputs (setup, untimed): this rank's block of the S_total-satellite constellation ----
-    states = constellation_states(S_total, first=rank * S, count=S)
-    y0, consts = normalize_batch(states)
-    tfbar = np.ones(S)
-    xbar, st, _ = propagate_batch(y0, tfbar, consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K,
-                                  device=local_rank)
-    assert (st == 0).all()
-    ubar = tangential_thrust(xbar, 0.5)
-    r_des = np.linalg.norm(xbar[:, 0:3, -1], axis=1)
-
-    t64 = dict(dtype=torch.float64, device=dev)
-    d_x = torch.tensor(xbar, **t64); d_u = torch.tensor(np.ascontiguousarray(ubar), **t64)
-    d_tf = torch.tensor(tfbar, **t64); d_c = torch.tensor(consts, **t64); d_rd = torch.tensor(r_des, **t64)
-    d_X = torch.empty((S, 7, K), **t64); d_U = torch.empty((S, 3, K), **t64); d_NU = torch.empty((S, 7, K), **t64)
-    d_tfo = torch.empty(S, **t64); d_kkt = torch.empty(S, **t64)
-    d_st = torch.empty(S, dtype=torch.int32, device=dev); d_it = torch.empty(S, dtype=torch.int32, device=dev)
-    ws_bytes = lib.mpcx_mpc_step_workspace_bytes(S, K)
-    d_ws = torch.empty(ws_bytes // 8 + 8, **t64)
-    opts = _ffi.make_solve_opts({})
-    stream = torch.cuda.current_stream().cuda_stream
-    p = lambda t: C.c_void_p(t.data_ptr())
-
-    def step():
-        rc = lib.mpcx_mpc_step_batch_dev(ctx, S, K, p(d_x), p(d_u), p(d_tf), p(d_c), p(d_rd), 0, 1e-2, C.byref(opts),
-                                         p(d_X), p(d_U), p(d_NU), p(d_tfo), p(d_st), p(d_it), p(d_kkt), p(d_ws),
-                                         C.c_void_p(stream))
-        _ffi.check(rc, ctx, "mpcx_mpc_step_batch_dev")
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in ev:        # events on the stream the kernels are launched on
-        e0.record(); step(); e1.record()
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], **t64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
-    step_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-
-    status = d_st.cpu().numpy(); iters = d_it.cpu().numpy(); kkt = d_kkt.cpu().numpy()
-    conv = int(((status == 0) | (status == 7)).sum())
-    stats = torch.tensor([conv, S], dtype=torch.float64, device=dev)
+    run = Runner(args.workload, rank, world, local_rank)
+    S, K, n_scp = run.S, run.K, run.n_scp
+    elapsed, solve_ms = measure(run, args.steps, args.warmup, world)
+    status, iters, kkt = run.solver_stats()
+    stats = torch.tensor([float(((status == 0) | (status == 7)).sum()), float(S)], dtype=torch.float64, device="cuda")
     if world > 1: dist.all_reduce(stats)
 
     if rank == 0:
+        S_total = S * world
         value = S_total * args.steps / elapsed
         B = algorithmic_bytes(K)
-        achieved = S * B / (step_ms * 1e-3) / 1e9          # per GPU, whole fused step (discretize + solve kernels)
+        achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
+        traffic = measured_traffic(args.workload)
         out = {
-            "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve, 1 SCP iteration)",
+            "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve per SCP iteration)",
             "value": value, "unit": "satellite-MPC-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "satellites_per_gpu": S, "satellites_total": S_total, "nodes_K": K,
-                       "scp_iterations_per_step": 1, "parallelism": f"satellite-sharded x{world}, no collective"},
+                       "scp_iterations_per_step": n_scp, "parallelism": f"satellite-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "note": "algorithmic bytes/step = 8(27K+7)+8 per satellite; fused step = discretize_kernel + solve_kernel, "
-                                 "duration from HIP events on the launch stream; the path is fp64-VALU/latency bound, not HBM bound"},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "mpcx::solve_kernel",
+                         "kernel_ms": solve_ms,
+                         "note": "algorithmic bytes = 8(27K+7)+8 per satellite per launch; duration = HIP events around solve_kernel on its "
+                                 "launch stream; traffic = FETCH_SIZE+WRITE_SIZE of profiles/ (workspace re-reads: the kernel is "
+                                 "latency / fp64-VALU bound at 64 satellites and workspace-traffic bound at 4096, not algorithmic-HBM bound)"},
             "solver": {"converged": int(stats[0].item()), "of": int(stats[1].item()),
                        "ipm_iterations_mean": float(iters.mean()), "ipm_iterations_max": int(iters.max()),
                        "kkt_max": float(kkt.max())},
         }
+        if n_scp > 1:
+            out["scp_iterations_per_s"] = value * n_scp
+        h = run.host
+        if world == 1 and not args.no_also and args.workload == "S64_K30":
+            del run
+            torch.cuda.empty_cache()
+            r2 = Runner("S4096_K30", 0, 1, local_rank)
+            e2, s2 = measure(r2, 3, 1, 1)
+            st2, it2, _ = r2.solver_stats()
+            out["also"] = {"S4096_K30": {"value": 4096 * 3 / e2, "unit": "satellite-MPC-steps/s", "ms_per_step": e2 / 3 * 1e3,
+                                         "solve_kernel_ms": s2, "converged": int(((st2 == 0) | (st2 == 7)).sum()), "of": 4096,
+                                         "ipm_iterations_mean": float(it2.mean()),
+                                         "traffic": measured_traffic("S4096_K30"),
+                                         "note": "BASELINE configs[2], same run, 3 steps after 1 warm-up"}}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(xbar, ubar, tfbar, consts, r_des, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
