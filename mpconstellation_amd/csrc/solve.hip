@@ -574,11 +574,37 @@ __device__ __forceinline__ double chol7_reg(double m, int lane, bool &ok)
     return (i < 7 && j <= i) ? m / sqrt(dsave) : 0.0;
 }
 
+struct ChanIn { double gx, gu, rho, aff; };
+
+// inputs of component r of channel c at node k (channel 0: rhs record; 1: unit dtf; 2..: unit terminal gradients)
+__device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, int k, int c, int r, bool act)
+{
+    ChanIn ci{0.0, 0.0, 0.0, 0.0};
+    if (!act) return ci;
+    const int K = s.K;
+    const bool dyn = (k <= K - 2);
+    if (c == 0) {
+        const double *ch = s.ch + (size_t)k * CH_N + C_RHS;
+        ci.gx = ch[R_GX + r];
+        if (r < 3) ci.gu = ch[R_GU + r];
+        if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
+    } else if (c == 1) { if (dyn) ci.aff = s.Sig(k)[r]; }
+    else if (k == K - 1) ci.gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
+    return ci;
+}
+
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
-__device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane)
+// With fuse_sweep the backward linear-term sweep of all 8 channels rides along: node k's p_k, qu_k are formed
+// right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
+__device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane, bool fuse_sweep)
 {
     const int K = s.K;
     bool good = true;
+    const int sc = lane >> 3, sr = lane & 7;
+    const bool sact = fuse_sweep && sr < 7;
+    const int srr = (sr < 7) ? sr : 6, sr3 = (sr < 3) ? sr : 2;
+    ChanIn cur = chan_inputs(s, sd, K - 1, sc, sr, sact), nxt = cur;
+    double pnext = 0.0;
     // operand prefetch: node k's (A, Wx, Bn, Bpm, Wu, D) -> registers -> LDS buffer
     double pre[3];
     auto fetch = [&](int k) {
@@ -616,7 +642,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
         double *fac = s.fac + (size_t)k * FAC_N;
-        if (k >= 1) fetch(k - 1);
+        if (k >= 1) { fetch(k - 1); if (fuse_sweep) nxt = chan_inputs(s, sd, k - 1, sc, sr, sact); }
         const bool dyn = (k <= K - 2);
         // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm ; Cholesky of M = D + Pn in registers
         if (lane < 21) {
@@ -700,6 +726,37 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
             const double pk = 0.5 * (a1 + a2);
             w.Pn[lane] = pk; fac[F_P + lane] = pk;
         }
+        if (fuse_sweep) {
+            double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                Grow[q] = o.G[srr * 7 + q]; Ptrow[q] = o.Pt[srr * 7 + q]; Acol[q] = o.A[q * 7 + srr];
+                Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.Bh[q * 3 + sr3];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + srr];
+            const double v = cur.rho + pnext;
+            double t = pnext;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) t += -Grow[q] * __shfl(v, q, 8) + Ptrow[q] * __shfl(cur.aff, q, 8);
+            if (!dyn || !sact) t = 0.0;
+            double qu = cur.gu;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(t, q, 8);
+            if (sr >= 3 || !sact) qu = 0.0;
+            double pp = cur.gx;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pp += Acol[q] * __shfl(t, q, 8);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
+            if (sact) {
+                double *ch = s.ch + (size_t)k * CH_N;
+                ch[C_P + sc * 7 + sr] = pp;
+                if (sr < 3) ch[C_QU + sc * 3 + sr] = qu;
+                pnext = pp;
+            }
+            cur = nxt;
+        }
         if (k >= 1) stash(w.ops[(k - 1) & 1]);
         __syncthreads();
     }
@@ -750,25 +807,6 @@ __device__ __forceinline__ void sweep_stash_mats(StageOps &o, int lane, const Sw
         else if (e < 268) o.Qi[e - 259] = v;
         else if (e < 275) o.D[e - 268] = v;
     }
-}
-
-struct ChanIn { double gx, gu, rho, aff; };
-
-// inputs of component r of channel c at node k (channel 0: rhs record; 1: unit dtf; 2..: unit terminal gradients)
-__device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, int k, int c, int r, bool act)
-{
-    ChanIn ci{0.0, 0.0, 0.0, 0.0};
-    if (!act) return ci;
-    const int K = s.K;
-    const bool dyn = (k <= K - 2);
-    if (c == 0) {
-        const double *ch = s.ch + (size_t)k * CH_N + C_RHS;
-        ci.gx = ch[R_GX + r];
-        if (r < 3) ci.gu = ch[R_GU + r];
-        if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
-    } else if (c == 1) { if (dyn) ci.aff = s.Sig(k)[r]; }
-    else if (k == K - 1) ci.gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
-    return ci;
 }
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
@@ -1378,8 +1416,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             PT_BEGIN
             newton_blocks(s, sd, mu, delta_w, lane);
             PT_END(1)
+            double gtf_rhs, rvt_rhs, gterm[NTERM], gex[NTERM];
             PT_BEGIN
-            bool ok = riccati_factor(s, sd, w, lane);
+            initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);      // right-hand side of the first solve = the Newton blocks
+            PT_END(5)
+            PT_BEGIN
+            bool ok = riccati_factor(s, sd, w, lane, true);          // factorisation + backward sweep of all 8 channels
             PT_END(2)
             if (ok) {
                 // direction := (0, ..., -lam, -lam_vt) so that the first residual carries no multipliers
@@ -1396,20 +1438,22 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
                 for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
                 const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
                 for (int pass = 0; pass < passes && ok; ++pass) {
-                    double gtf_rhs, rvt_rhs, gterm[NTERM], gex[NTERM];
-                    PT_BEGIN
-                    if (pass == 0) initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
-                    else reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
-                    PT_END(5)
+                    if (pass > 0) {
+                        PT_BEGIN
+                        reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                        PT_END(5)
+                    }
                     for (int t = 0; t < NTERM; ++t) {
                         const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
                         gex[t] = gterm[t] * (1.0 - share);
                     }
                     // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only
                     const int c1 = (pass == 0) ? NCH : 1;
-                    PT_BEGIN
-                    sweep_backward(s, sd, w, 0, c1, lane);
-                    PT_END(3)
+                    if (pass > 0) {
+                        PT_BEGIN
+                        sweep_backward(s, sd, w, 0, c1, lane);
+                        PT_END(3)
+                    }
                     PT_BEGIN
                     sweep_forward(s, sd, w, 0, c1, lane);
                     if (pass == 0) ok = border_factor(sd, lane);

@@ -52,6 +52,7 @@ BOUND_PUSH = 1e-2
 KAPPA_SIGMA = 100.0
 GAMMA_NBHD = 1e-3
 MU_INIT = 1.0
+KAPPA_EPS, KAPPA_MU, THETA_MU = 10.0, 0.2, 1.5     # ipopt barrier_tol_factor, mu_linear_decrease_factor, mu_superlinear_decrease_power
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
 REFINE_TW = 1e9       # iterative refinement only once a terminal barrier weight exceeds this
 N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
@@ -487,8 +488,8 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         n_acc = n_acc + 1 if E0 <= acceptable_tol else 0
         if n_acc >= acceptable_iter: status = ST_ACCEPTABLE; break
         if k_it == max_iter: status = ST_ACCEPTABLE if E0 <= acceptable_tol else ST_MAXITER; break
-        while optimality_error(P, it, mu)[0] <= 10 * mu and mu > tol / 10:
-            mu = max(tol / 10, min(0.2 * mu, mu ** 1.5))
+        while optimality_error(P, it, mu)[0] <= KAPPA_EPS * mu and mu > tol / 10:
+            mu = max(tol / 10, min(KAPPA_MU * mu, mu ** THETA_MU))
         d = None; dw = 0.0
         for trial in range(10):
             try:
