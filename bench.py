@@ -121,7 +121,8 @@ def measure(runner, steps, warmup, world):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     solve_ms = float(np.mean([a.elapsed_time(b) for a, b in runner.solve_events]))
     return elapsed, solve_ms
@@ -150,9 +151,12 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    single_dev = os.environ.get("MPCX_BENCH_SINGLE_DEVICE") == "1"   # rehearsal of the N>1 path on a 1-GPU box (gloo)
+    if single_dev:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group("gloo" if (single_dev or not torch.cuda.is_available()) else "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmpcx has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -161,7 +165,8 @@ def main():
     S, K, n_scp = run.S, run.K, run.n_scp
     elapsed, solve_ms = measure(run, args.steps, args.warmup, world)
     status, iters, kkt = run.solver_stats()
-    stats = torch.tensor([float(((status == 0) | (status == 7)).sum()), float(S)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(((status == 0) | (status == 7)).sum()), float(S)], dtype=torch.float64,
+                         device="cpu" if (world > 1 and dist.get_backend() == "gloo") else "cuda")
     if world > 1: dist.all_reduce(stats)
 
     if rank == 0:

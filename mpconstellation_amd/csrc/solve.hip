@@ -29,7 +29,8 @@ enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16,
 enum { N_WX = 0, N_WU = 49, N_D = 58, N_AA = 65, N_BB = 72, N_GT = 79, N_RHO = 86, N_GX = 93, N_GU = 100,
        N_E = 103, NB_N = 112 };
 // factorisation per node
-enum { F_P = 0, F_MINV = 49, F_G = 98, F_PT = 147, F_QI = 196, F_KG = 205, F_BH = 226, FAC_N = 248 };
+// factorisation per node, stored in exactly the order the sweeps stage it through LDS (one contiguous block)
+enum { F_A = 0, F_G = 49, F_PT = 98, F_MINV = 147, F_KG = 196, F_BH = 217, F_BPM = 238, F_QI = 259, F_D = 268, FAC_USED = 275, FAC_N = 280 };
 // channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
 enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, CH_N = 104 };
 // stored trajectory of one channel at one node
@@ -95,6 +96,15 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Barrier for the single-wave workgroups of this kernel when lanes exchange data through LDS only: DS operations of
+// one wave execute in issue order, so it is enough to stop the compiler from moving LDS accesses across this point.
+// Unlike __syncthreads() it does not drain outstanding global loads (the node-ahead prefetch stays in flight).
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // c~ = |v|^2 - (r.v)^2/|r|^2 - vt_des^2 (same zero set as the quartic of optimizer.py:492-517)
@@ -550,6 +560,7 @@ struct StageOps {          // operands of one node, double-buffered in LDS
 
 struct Scratch {   // LDS working set of the recursion
     StageOps ops[2];
+    double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
     double Pn[49], L[49], WlLi[98], PtA[49], Qyy[49];
     double PtBh[21], WxBp[21], Quy[21];
     double Quu[9];
@@ -661,7 +672,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
             // right-hand sides [Pn | I]
             for (int e = lane; e < 98; e += 64) { const int r = e / 14, c = e - 14 * r; w.WlLi[e] = (c < 7) ? w.Pn[r * 7 + c] : (c - 7 == r ? 1.0 : 0.0); }
         }
-        __syncthreads();
+        wsync();
         if (dyn) {
             // P3: [Wl | Li] = L^-1 [Pn | I], one lane per column
             if (lane < 14) {
@@ -671,7 +682,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
                     w.WlLi[p * 14 + lane] = acc / w.L[p * 7 + p];
                 }
             }
-            __syncthreads();
+            wsync();
             // P4: Pt = Pn - Wl^T Wl ; G = Wl^T Li ; Minv = Li^T Li
             if (lane < 49) {
                 double a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -683,10 +694,10 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
                 o.Pt[lane] = w.Pn[lane] - a1; o.G[lane] = a2; o.Minv[lane] = a3;
                 fac[F_PT + lane] = o.Pt[lane]; fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
             }
-            __syncthreads();
+            wsync();
         } else {
             if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_PT + lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; }
-            __syncthreads();
+            wsync();
         }
         // P5: PtA, PtBh, Q0 = Wu + Bpm^T WxBp, Quy0 = Bpm^T Wx
         if (lane < 49) w.PtA[lane] = dot_el(o.Pt, 7, 1, o.A, 7, 1, mi, mj, 7);
@@ -699,32 +710,33 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
             const int e = lane - 32, i = e / 3, j = e - 3 * i;
             w.Quu[e] = o.Wu[e] + dot_el(o.Bpm, 1, 3, w.WxBp, 3, 1, i, j, 7);
         }
-        __syncthreads();
+        wsync();
         // P6: Quu += Bh^T PtBh ; Quy += Bh^T PtA ; Qyy = Wx + A^T PtA
         if (lane < 49) w.Qyy[lane] = o.Wx[lane] + dot_el(o.A, 1, 7, w.PtA, 7, 1, mi, mj, 7);
         double quy_add = 0.0, quu_add = 0.0;
         if (lane < 21) { const int r = lane / 7, c = lane - 7 * r; quy_add = dot_el(o.Bh, 1, 3, w.PtA, 7, 1, r, c, 7); }
         else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; quu_add = dot_el(o.Bh, 1, 3, w.PtBh, 3, 1, i, j, 7); }
-        __syncthreads();
+        wsync();
         if (lane < 21) w.Quy[lane] += quy_add;
         else if (lane >= 32 && lane < 41) w.Quu[lane - 32] += quu_add;
-        __syncthreads();
+        wsync();
         // P7+P8: every lane inverts the 3x3 itself; Kg = Qi Quy
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
             const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
-            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane];
+            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane]; fac[F_BPM + lane] = o.Bpm[lane];
         }
         if (lane < 9) fac[F_QI + lane] = Qi[lane];
-        __syncthreads();
+        if (lane < 7) fac[F_D + lane] = o.D[lane];
+        wsync();
         // P9: P_k = sym(Qyy - Quy^T Kg)
         if (lane < 49) {
             double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
             for (int l = 0; l < 3; ++l) { a1 -= w.Quy[l * 7 + mi] * o.Kg[l * 7 + mj]; a2 -= w.Quy[l * 7 + mj] * o.Kg[l * 7 + mi]; }
             const double pk = 0.5 * (a1 + a2);
-            w.Pn[lane] = pk; fac[F_P + lane] = pk;
+            w.Pn[lane] = pk; fac[F_A + lane] = o.A[lane];
         }
         if (fuse_sweep) {
             double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
@@ -758,8 +770,9 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
             cur = nxt;
         }
         if (k >= 1) stash(w.ops[(k - 1) & 1]);
-        __syncthreads();
+        wsync();
     }
+    __syncthreads();
     return __all(good);
 }
 
@@ -771,42 +784,17 @@ struct SweepPre { double v[5]; };
 
 __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
-    const int K = s.K;
     const double *fac = s.fac + (size_t)k * FAC_N;
-    const bool dyn = (k <= K - 2);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int e = lane + 64 * q;
-        double v = 0.0;
-        if (e < 49) v = dyn ? s.A(k)[e] : 0.0;
-        else if (e < 98) v = fac[F_G + e - 49];
-        else if (e < 147) v = fac[F_PT + e - 98];
-        else if (e < 196) v = fac[F_MINV + e - 147];
-        else if (e < 217) v = fac[F_KG + e - 196];
-        else if (e < 238) v = fac[F_BH + e - 217];
-        else if (e < 259) v = (k >= 1) ? s.Bp(k - 1)[e - 238] : 0.0;
-        else if (e < 268) v = fac[F_QI + e - 259];
-        else if (e < 275) v = dyn ? s.nb[(size_t)k * NB_N + N_D + e - 268] : 0.0;
-        pre.v[q] = v;
-    }
+    for (int q = 0; q < 4; ++q) pre.v[q] = fac[lane + 64 * q];
+    pre.v[4] = (lane + 256 < FAC_USED) ? fac[lane + 256] : 0.0;
 }
 
-__device__ __forceinline__ void sweep_stash_mats(StageOps &o, int lane, const SweepPre &pre)
+__device__ __forceinline__ void sweep_stash_mats(double *f, int lane, const SweepPre &pre)
 {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int e = lane + 64 * q;
-        const double v = pre.v[q];
-        if (e < 49) o.A[e] = v;
-        else if (e < 98) o.G[e - 49] = v;
-        else if (e < 147) o.Pt[e - 98] = v;
-        else if (e < 196) o.Minv[e - 147] = v;
-        else if (e < 217) o.Kg[e - 196] = v;
-        else if (e < 238) o.Bh[e - 217] = v;
-        else if (e < 259) o.Bpm[e - 238] = v;
-        else if (e < 268) o.Qi[e - 259] = v;
-        else if (e < 275) o.D[e - 268] = v;
-    }
+    for (int q = 0; q < 4; ++q) f[lane + 64 * q] = pre.v[q];
+    if (lane + 256 < FAC_N) f[lane + 256] = pre.v[4];
 }
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
@@ -818,22 +806,22 @@ __device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
     sweep_fetch_mats(s, K - 1, lane, pre);
-    sweep_stash_mats(w.ops[(K - 1) & 1], lane, pre);
+    sweep_stash_mats(w.flat[(K - 1) & 1], lane, pre);
     ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
     double pnext = 0.0;
     __syncthreads();
     for (int k = K - 1; k >= 0; --k) {
-        const StageOps &o = w.ops[k & 1];
+        const double *f = w.flat[k & 1];
         if (k >= 1) { sweep_fetch_mats(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
         const bool dyn = (k <= K - 2);
         double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            Grow[q] = o.G[rr * 7 + q]; Ptrow[q] = o.Pt[rr * 7 + q]; Acol[q] = o.A[q * 7 + rr];
-            Bpmcol[q] = o.Bpm[q * 3 + r3]; Bhcol[q] = o.Bh[q * 3 + r3];
+            Grow[q] = f[F_G + rr * 7 + q]; Ptrow[q] = f[F_PT + rr * 7 + q]; Acol[q] = f[F_A + q * 7 + rr];
+            Bpmcol[q] = f[F_BPM + q * 3 + r3]; Bhcol[q] = f[F_BH + q * 3 + r3];
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + rr];
+        for (int q = 0; q < 3; ++q) Kgcol[q] = f[F_KG + q * 7 + rr];
         const double v = cur.rho + pnext;
         double t = pnext;
 #pragma unroll
@@ -854,10 +842,11 @@ __device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &
             if (r < 3) ch[C_QU + c * 3 + r] = qu;
             pnext = p;
         }
-        if (k >= 1) sweep_stash_mats(w.ops[(k - 1) & 1], lane, pre);
+        if (k >= 1) sweep_stash_mats(w.flat[(k - 1) & 1], lane, pre);
         cur = nxt;
-        __syncthreads();
+        wsync();
     }
+    __syncthreads();
 }
 
 // Forward sweep for channels [c0, c1): stores each channel's trajectory (x, u, nu, lam) per node and
@@ -870,7 +859,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
     sweep_fetch_mats(s, 0, lane, pre);
-    sweep_stash_mats(w.ops[0], lane, pre);
+    sweep_stash_mats(w.flat[0], lane, pre);
     ChanIn cur = chan_inputs(s, sd, 0, c, r, act), nxt = cur;
     auto load_pq = [&](int k, double &qu, double &pn) {
         qu = 0.0; pn = 0.0;
@@ -884,15 +873,15 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
     double y = 0.0, siglam = 0.0;
     __syncthreads();
     for (int k = 0; k < K; ++k) {
-        const StageOps &o = w.ops[k & 1];
+        const double *f = w.flat[k & 1];
         if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nxt = chan_inputs(s, sd, k + 1, c, r, act); load_pq(k + 1, qun, pnn); }
         const bool dyn = (k <= K - 2);
         double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { Kgrow[q] = o.Kg[r3 * 7 + q]; Arow[q] = o.A[rr * 7 + q]; Gcol[q] = o.G[q * 7 + rr]; Mrow[q] = o.Minv[rr * 7 + q]; }
+        for (int q = 0; q < 7; ++q) { Kgrow[q] = f[F_KG + r3 * 7 + q]; Arow[q] = f[F_A + rr * 7 + q]; Gcol[q] = f[F_G + q * 7 + rr]; Mrow[q] = f[F_MINV + rr * 7 + q]; }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { Qirow[q] = o.Qi[r3 * 3 + q]; Bpmrow[q] = o.Bpm[rr * 3 + q]; Bhrow[q] = o.Bh[rr * 3 + q]; }
-        const double Dr = o.D[rr];
+        for (int q = 0; q < 3; ++q) { Qirow[q] = f[F_QI + r3 * 3 + q]; Bpmrow[q] = f[F_BPM + rr * 3 + q]; Bhrow[q] = f[F_BH + rr * 3 + q]; }
+        const double Dr = f[F_D + rr];
         double u = 0.0;
 #pragma unroll
         for (int q = 0; q < 7; ++q) u -= Kgrow[q] * __shfl(y, q, 8);
@@ -921,9 +910,9 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
                 y = yh + nu;
             }
         }
-        if (k + 1 < K) sweep_stash_mats(w.ops[(k + 1) & 1], lane, pre);
+        if (k + 1 < K) sweep_stash_mats(w.flat[(k + 1) & 1], lane, pre);
         cur = nxt; quc = qun; pnc = pnn;
-        __syncthreads();
+        wsync();
     }
     siglam += __shfl_xor(siglam, 1, 8);
     siglam += __shfl_xor(siglam, 2, 8);
