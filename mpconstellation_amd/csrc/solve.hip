@@ -75,6 +75,9 @@ struct SatData {
     double sol[NBD];
     double red[8];
     int flag;
+#ifdef MPCX_PHASE_TIMING
+    unsigned long long fpt[16];   // diagnostic build only: cycle sums of the recursion's inner phases
+#endif
 };
 
 __device__ __forceinline__ double relax(double b) { return b + kBoundRelax * fmax(1.0, fabs(b)); }
@@ -566,24 +569,47 @@ struct Scratch {   // LDS working set of the recursion
     double Quu[9];
 };
 
-// In-register Cholesky of the 7x7 SPD matrix whose element (i,j) sits in lane i*7+j (lanes 0..48).
-// Right-looking elimination with ds_bpermute broadcasts, no LDS traffic, no barriers.  Returns L(i,j) (j<=i) and ok.
-__device__ __forceinline__ double chol7_reg(double m, int lane, bool &ok)
+template <int N>
+__device__ __forceinline__ double dotN(const double *a, int sa, const double *b, int sb)
+{
+    double x[N], y[N];
+#pragma unroll
+    for (int l = 0; l < N; ++l) { x[l] = a[l * sa]; y[l] = b[l * sb]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) acc += x[l] * y[l];
+    return acc;
+}
+
+// In-register LDL^T of the 7x7 SPD matrix whose element (i,j) sits in lane i*7+j (lanes 0..48): right-looking
+// elimination with ds_bpermute broadcasts, no LDS traffic, no barriers, one reciprocal per pivot.
+// Returns Lt(i,j) (unit lower, j < i; 0 elsewhere) and the reciprocals of the pivots (wave-uniform).
+__device__ __forceinline__ double ldl7_reg(double m, int lane, double (&rd)[7], bool &ok)
 {
     const int i = lane / 7, j = lane - 7 * i;
+    const int ic = (i < 7) ? i : 0;
     ok = true;
-    double dsave = 1.0;
+    double rsel = 0.0;
 #pragma unroll
     for (int p = 0; p < 7; ++p) {
         const double d = __shfl(m, p * 8, 64);
-        const double mip = __shfl(m, (i < 7 ? i : 0) * 7 + p, 64);
+        const double mip = __shfl(m, ic * 7 + p, 64);
         const double mjp = __shfl(m, j * 7 + p, 64);
         if (!(d > 0.0)) ok = false;
-        if (i > p && j > p && i < 7) m -= mip * mjp / d;
-        if (j == p) dsave = d;
+        rd[p] = 1.0 / d;
+        if (i > p && j > p && i < 7) m -= (mip * rd[p]) * mjp;
+        if (j == p) rsel = rd[p];
     }
-    return (i < 7 && j <= i) ? m / sqrt(dsave) : 0.0;
+    return (i < 7 && j < i) ? m * rsel : 0.0;
 }
+
+#ifdef MPCX_PHASE_TIMING
+#define FT_DECL unsigned long long ft0_ = __builtin_amdgcn_s_memtime(), ft1_;
+#define FT_MARK(i) { ft1_ = __builtin_amdgcn_s_memtime(); if (lane == 0) sd.fpt[i] += ft1_ - ft0_; ft0_ = ft1_; }
+#else
+#define FT_DECL
+#define FT_MARK(i)
+#endif
 
 struct ChanIn { double gx, gu, rho, aff; };
 
@@ -653,73 +679,88 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
         double *fac = s.fac + (size_t)k * FAC_N;
+        FT_DECL
         if (k >= 1) { fetch(k - 1); if (fuse_sweep) nxt = chan_inputs(s, sd, k - 1, sc, sr, sact); }
         const bool dyn = (k <= K - 2);
-        // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm ; Cholesky of M = D + Pn in registers
+        FT_MARK(0)
+        // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm ; LDL^T of M = D + Pn in registers
         if (lane < 21) {
             const int i = lane / 3, j = lane - 3 * i;
-            o.Bh[lane] = dyn ? o.Bn[lane] + dot_el(o.A, 7, 1, o.Bpm, 3, 1, i, j, 7) : 0.0;
+            o.Bh[lane] = dyn ? o.Bn[lane] + dotN<7>(o.A + i * 7, 1, o.Bpm + j, 3) : 0.0;
         } else if (lane >= 32 && lane < 53) {
             const int e = lane - 32, i = e / 3, j = e - 3 * i;
-            w.WxBp[e] = dot_el(o.Wx, 7, 1, o.Bpm, 3, 1, i, j, 7);
+            w.WxBp[e] = dotN<7>(o.Wx + i * 7, 1, o.Bpm + j, 3);
         }
+        double rd[7] = {0, 0, 0, 0, 0, 0, 0};
         if (dyn) {
-            double m = (lane < 49) ? w.Pn[lane] + (mi == mj ? o.D[mi] : 0.0) : 0.0;
+            const double m = (lane < 49) ? w.Pn[lane] + (mi == mj ? o.D[mi] : 0.0) : 0.0;
             bool okc;
-            const double l = chol7_reg(m, lane, okc);
+            const double lt = ldl7_reg(m, lane, rd, okc);
             if (!okc) good = false;
-            if (lane < 49) w.L[lane] = l;
+            if (lane < 49) w.L[lane] = lt;
             // right-hand sides [Pn | I]
             for (int e = lane; e < 98; e += 64) { const int r = e / 14, c = e - 14 * r; w.WlLi[e] = (c < 7) ? w.Pn[r * 7 + c] : (c - 7 == r ? 1.0 : 0.0); }
         }
         wsync();
+        FT_MARK(1)
         if (dyn) {
-            // P3: [Wl | Li] = L^-1 [Pn | I], one lane per column
+            // P3: [X1 | X2] = Lt^-1 [Pn | I] (unit lower), one lane per column, everything in registers
             if (lane < 14) {
-                for (int p = 0; p < 7; ++p) {
-                    double acc = w.WlLi[p * 14 + lane];
-                    for (int q = 0; q < p; ++q) acc -= w.L[p * 7 + q] * w.WlLi[q * 14 + lane];
-                    w.WlLi[p * 14 + lane] = acc / w.L[p * 7 + p];
-                }
+                double lt[21], x[7];
+#pragma unroll
+                for (int pp = 1, n = 0; pp < 7; ++pp)
+#pragma unroll
+                    for (int q = 0; q < pp; ++q, ++n) lt[n] = w.L[pp * 7 + q];
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) x[pp] = w.WlLi[pp * 14 + lane];
+#pragma unroll
+                for (int pp = 1, n = 0; pp < 7; ++pp)
+#pragma unroll
+                    for (int q = 0; q < pp; ++q, ++n) x[pp] -= lt[n] * x[q];
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) w.WlLi[pp * 14 + lane] = x[pp];
             }
             wsync();
-            // P4: Pt = Pn - Wl^T Wl ; G = Wl^T Li ; Minv = Li^T Li
+            FT_MARK(2)
+            // P4: Pt = sym(Pn - X1^T R X1) ; G = X1^T R X2 ; Minv = X2^T R X2 with R = diag(1/d)
             if (lane < 49) {
-                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                double a1 = 0.0, a1t = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
                 for (int l = 0; l < 7; ++l) {
-                    const double wi = w.WlLi[l * 14 + mi], wj = w.WlLi[l * 14 + mj];
-                    const double li = w.WlLi[l * 14 + 7 + mi], lj = w.WlLi[l * 14 + 7 + mj];
-                    a1 += wi * wj; a2 += wi * lj; a3 += li * lj;
+                    const double x1i = w.WlLi[l * 14 + mi], x1j = w.WlLi[l * 14 + mj];
+                    const double x2i = w.WlLi[l * 14 + 7 + mi], x2j = w.WlLi[l * 14 + 7 + mj];
+                    a1 += x1i * (rd[l] * x1j); a1t += x1j * (rd[l] * x1i);
+                    a2 += x1i * (rd[l] * x2j); a3 += x2i * (rd[l] * x2j);
                 }
-                o.Pt[lane] = w.Pn[lane] - a1; o.G[lane] = a2; o.Minv[lane] = a3;
-                fac[F_PT + lane] = o.Pt[lane]; fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
+                const double pt = 0.5 * ((w.Pn[lane] - a1) + (w.Pn[mj * 7 + mi] - a1t));
+                o.Pt[lane] = pt; o.G[lane] = a2; o.Minv[lane] = a3;
+                fac[F_PT + lane] = pt; fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
             }
             wsync();
         } else {
             if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_PT + lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; }
             wsync();
         }
-        // P5: PtA, PtBh, Q0 = Wu + Bpm^T WxBp, Quy0 = Bpm^T Wx
-        if (lane < 49) w.PtA[lane] = dot_el(o.Pt, 7, 1, o.A, 7, 1, mi, mj, 7);
+        FT_MARK(3)
+        // P5: PtA, PtBh, Quu0 = Wu + Bpm^T WxBp, Quy0 = Bpm^T Wx
+        if (lane < 49) w.PtA[lane] = dotN<7>(o.Pt + mi * 7, 1, o.A + mj, 7);
         if (lane < 21) {
             const int i = lane / 3, j = lane - 3 * i;
-            w.PtBh[lane] = dot_el(o.Pt, 7, 1, o.Bh, 3, 1, i, j, 7);
+            w.PtBh[lane] = dotN<7>(o.Pt + i * 7, 1, o.Bh + j, 3);
             const int r = lane / 7, c = lane - 7 * r;
-            w.Quy[lane] = dot_el(o.Bpm, 1, 3, o.Wx, 7, 1, r, c, 7);
+            w.Quy[lane] = dotN<7>(o.Bpm + r, 3, o.Wx + c, 7);
         } else if (lane >= 32 && lane < 41) {
             const int e = lane - 32, i = e / 3, j = e - 3 * i;
-            w.Quu[e] = o.Wu[e] + dot_el(o.Bpm, 1, 3, w.WxBp, 3, 1, i, j, 7);
+            w.Quu[e] = o.Wu[e] + dotN<7>(o.Bpm + i, 3, w.WxBp + j, 3);
         }
         wsync();
+        FT_MARK(4)
         // P6: Quu += Bh^T PtBh ; Quy += Bh^T PtA ; Qyy = Wx + A^T PtA
-        if (lane < 49) w.Qyy[lane] = o.Wx[lane] + dot_el(o.A, 1, 7, w.PtA, 7, 1, mi, mj, 7);
-        double quy_add = 0.0, quu_add = 0.0;
-        if (lane < 21) { const int r = lane / 7, c = lane - 7 * r; quy_add = dot_el(o.Bh, 1, 3, w.PtA, 7, 1, r, c, 7); }
-        else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; quu_add = dot_el(o.Bh, 1, 3, w.PtBh, 3, 1, i, j, 7); }
+        if (lane < 49) w.Qyy[lane] = o.Wx[lane] + dotN<7>(o.A + mi, 7, w.PtA + mj, 7);
+        if (lane < 21) { const int r = lane / 7, c = lane - 7 * r; w.Quy[lane] += dotN<7>(o.Bh + r, 3, w.PtA + c, 7); }
+        else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; w.Quu[e] += dotN<7>(o.Bh + i, 3, w.PtBh + j, 3); }
         wsync();
-        if (lane < 21) w.Quy[lane] += quy_add;
-        else if (lane >= 32 && lane < 41) w.Quu[lane - 32] += quu_add;
-        wsync();
+        FT_MARK(5)
         // P7+P8: every lane inverts the 3x3 itself; Kg = Qi Quy
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
@@ -731,13 +772,16 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
         if (lane < 9) fac[F_QI + lane] = Qi[lane];
         if (lane < 7) fac[F_D + lane] = o.D[lane];
         wsync();
+        FT_MARK(6)
         // P9: P_k = sym(Qyy - Quy^T Kg)
         if (lane < 49) {
             double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
+#pragma unroll
             for (int l = 0; l < 3; ++l) { a1 -= w.Quy[l * 7 + mi] * o.Kg[l * 7 + mj]; a2 -= w.Quy[l * 7 + mj] * o.Kg[l * 7 + mi]; }
             const double pk = 0.5 * (a1 + a2);
             w.Pn[lane] = pk; fac[F_A + lane] = o.A[lane];
         }
+        FT_MARK(7)
         if (fuse_sweep) {
             double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
@@ -769,8 +813,10 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
             }
             cur = nxt;
         }
+        FT_MARK(8)
         if (k >= 1) stash(w.ops[(k - 1) & 1]);
         wsync();
+        FT_MARK(9)
     }
     __syncthreads();
     return __all(good);
@@ -874,8 +920,10 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
     __syncthreads();
     for (int k = 0; k < K; ++k) {
         const double *f = w.flat[k & 1];
+        FT_DECL
         if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nxt = chan_inputs(s, sd, k + 1, c, r, act); load_pq(k + 1, qun, pnn); }
         const bool dyn = (k <= K - 2);
+        FT_MARK(10)
         double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
 #pragma unroll
         for (int q = 0; q < 7; ++q) { Kgrow[q] = f[F_KG + r3 * 7 + q]; Arow[q] = f[F_A + rr * 7 + q]; Gcol[q] = f[F_G + q * 7 + rr]; Mrow[q] = f[F_MINV + rr * 7 + q]; }
@@ -894,10 +942,12 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
 #pragma unroll
         for (int q = 0; q < 7; ++q) yh += Arow[q] * __shfl(y, q, 8);
         if (!dyn || !act) yh = 0.0;
+        FT_MARK(11)
         const double wv = cur.rho + pnc;
         double nu = 0.0;
 #pragma unroll
         for (int q = 0; q < 7; ++q) nu -= Gcol[q] * __shfl(yh, q, 8) + Mrow[q] * __shfl(wv, q, 8);
+        FT_MARK(12)
         if (act) {
             double *tr = s.traj + ((size_t)k * NCH + c) * TR_N;
             tr[T_X + r] = x;
@@ -910,9 +960,11 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
                 y = yh + nu;
             }
         }
+        FT_MARK(13)
         if (k + 1 < K) sweep_stash_mats(w.flat[(k + 1) & 1], lane, pre);
         cur = nxt; quc = qun; pnc = pnn;
         wsync();
+        FT_MARK(14)
     }
     siglam += __shfl_xor(siglam, 1, 8);
     siglam += __shfl_xor(siglam, 2, 8);
@@ -1333,6 +1385,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
         build_terminal(xK, a.consts[(size_t)sat * MPCX_NCONST + MPCX_C_MU], a.r_des[sat], o, sd);
         sd.tfbar = a.tfbar[sat];
+#ifdef MPCX_PHASE_TIMING
+        for (int i = 0; i < 16; ++i) sd.fpt[i] = 0;
+#endif
     }
     __syncthreads();
     for (int k = lane; k < K; k += 64) {
@@ -1508,6 +1563,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         // diagnostic build only: cycle sums per phase into the NU block of this satellite (never shipped)
         double *dbg = a.NU + (size_t)sat * 7 * K;
         for (int i = 0; i < 12; ++i) { dbg[2 * i] = (double)pt_[i]; dbg[2 * i + 1] = (double)pc_[i]; }
+        for (int i = 0; i < 16; ++i) dbg[24 + i] = (double)sd.fpt[i];
 #endif
     }
 }

@@ -251,9 +251,28 @@ def newton_blocks(P, it, mu, delta_w=0.0):
                 cv=cv, avt=avt, Hv=Hv, a_=a_, b_=b_, gt=gt, g=g, sig=sig, zhat=zhat)
 
 
+def ldl_solve7(M, B):
+    """M = Lt diag(d) Lt^T (unit lower Lt, no pivoting, SPD M).  Returns X1 = Lt^-1 B, X2 = Lt^-1 and 1/d, so that
+    M^-1 = X2^T diag(1/d) X2.  Written entry by entry in the order the device kernel uses."""
+    n = M.shape[0]
+    W = M.copy(); Lt = np.eye(n); rd = np.zeros(n)
+    for p in range(n):
+        d = W[p, p]
+        if not d > 0.0: raise np.linalg.LinAlgError("not positive definite")
+        rd[p] = 1.0 / d
+        col = W[p + 1:, p].copy()
+        Lt[p + 1:, p] = col * rd[p]
+        W[p + 1:, p + 1:] -= np.outer(col * rd[p], col)
+    X = np.hstack([B, np.eye(n)]).astype(float)
+    for p in range(n):
+        for q in range(p):
+            X[p] -= Lt[p, q] * X[q]
+    return X[:, :n], X[:, n:], rd
+
+
 def riccati_factor(P, nb):
     """Backward Riccati sweep in the shifted state y_k = x_k - Bp_{k-1} u_k (absorbs the first-order
-    hold), nu_k eliminated per stage through M = D + P_{k+1} (Cholesky, explicit inverse so that the
+    hold), nu_k eliminated per stage through M = D + P_{k+1} (LDL^T, explicit inverse so that the
     linear-term sweeps are pure matrix-vector products).  Terminal Hessian: soft part + capped share of
     the rank-1 barrier weights + augmented-Lagrangian term gamma a_vt a_vt^T (exact, see riccati_solve)."""
     K = P.K; Wx, Wu, D = nb["Wx"], nb["Wu"], nb["D"]
@@ -273,12 +292,11 @@ def riccati_factor(P, nb):
         Wxk = WxK if k == K - 1 else Wx[k]
         if k <= K - 2:
             Pn = F["P"][k + 1]
-            L = np.linalg.cholesky(np.diag(D[:, k]) + Pn)            # raises LinAlgError when not PD
-            WlLi = np.linalg.solve(L, np.hstack([Pn, I7]))           # [L^-1 Pn | L^-1]
-            Wl, Li = WlLi[:, :7], WlLi[:, 7:]
-            Pt = Pn - Wl.T @ Wl; Pt = 0.5 * (Pt + Pt.T)
-            F["G"][k] = Wl.T @ Li                                    # Pn M^-1
-            F["Minv"][k] = Li.T @ Li
+            X1, X2, rd = ldl_solve7(np.diag(D[:, k]) + Pn, Pn)       # raises LinAlgError when not PD
+            C1 = rd[:, None] * X1; C2 = rd[:, None] * X2
+            Pt = Pn - X1.T @ C1; Pt = 0.5 * (Pt + Pt.T)
+            F["G"][k] = X1.T @ C2                                    # Pn M^-1
+            F["Minv"][k] = X2.T @ C2
             Ah = P.A[k]; Bh = P.A[k] @ Bpm + P.Bn[k]
         else:
             Pt = np.zeros((7, 7)); Ah = np.zeros((7, 7)); Bh = np.zeros((7, 3))

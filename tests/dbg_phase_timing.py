@@ -23,3 +23,10 @@ tot = t[:, 0].sum()
 print("iters", r.iters[0], "status", r.status[0], "total cycles(100MHz ticks?)", tot)
 for n, (cyc, cnt) in zip(names, t):
     if cnt: print(f"{n:28s} {cyc/tot*100:6.2f}%  calls {int(cnt):5d}  per call {cyc/cnt:10.0f}")
+fn = ["fetch issue", "P1 Bh,WxBp,LDL", "P3 fwd subst", "P4 Pt,G,Minv", "P5", "P6", "P7+8 inv3,Kg", "P9 P_k", "fused bwd sweep", "stash+sync",
+      "fwd: fetch", "fwd: u,x", "fwd: yhat,nu,lam", "fwd: store", "fwd: stash", "-"]
+f = r.NU[0].ravel()[24:40]
+nn = max(1, int(t[2, 1])) * x.shape[1]
+print("-- inside the recursions (cycles per node per call) --")
+for n, c in zip(fn, f):
+    if c: print(f"   {n:24s} {c/nn:8.0f}")
