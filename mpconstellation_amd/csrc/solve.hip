@@ -194,15 +194,21 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
 }
 
 // ---- view of one satellite's problem + workspace -------------------------------------------
+// Everything a satellite owns in HBM is addressed through pointers qualified with the global address space: the
+// compiler then emits global_load/global_store (tracked by vmcnt only) instead of flat accesses, which also count
+// against lgkmcnt and would make every LDS wait drain the node-ahead prefetch.
+typedef __attribute__((address_space(1))) double gf64;
+typedef const gf64 cgf64;
+
 struct Sat {
     int K;
-    const double *stage, *xbar, *ubar;   // stage (K-1,105); xbar (7,K); ubar (3,K)
-    double *it, *itg, *dr, *drg, *nb, *fac, *ch, *traj, *rbh;   // workspace pieces
-    __device__ const double *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
-    __device__ const double *Bn(int k) const { return A(k) + 49; }
-    __device__ const double *Bp(int k) const { return A(k) + 70; }
-    __device__ const double *Sig(int k) const { return A(k) + 91; }
-    __device__ const double *xi(int k) const { return A(k) + 98; }
+    cgf64 *stage, *xbar, *ubar;   // stage (K-1,105); xbar (7,K); ubar (3,K)
+    gf64 *it, *itg, *dr, *drg, *nb, *fac, *ch, *traj, *rbh;   // workspace pieces
+    __device__ cgf64 *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
+    __device__ cgf64 *Bn(int k) const { return A(k) + 49; }
+    __device__ cgf64 *Bp(int k) const { return A(k) + 70; }
+    __device__ cgf64 *Sig(int k) const { return A(k) + 91; }
+    __device__ cgf64 *xi(int k) const { return A(k) + 98; }
 };
 
 // Trial point (iterate + a * direction) of one node, everything a residual evaluation needs.
@@ -214,7 +220,7 @@ struct NodeVals {
 
 __device__ __forceinline__ void load_node(const Sat &s, int k, double a, NodeVals &n)
 {
-    const double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+    cgf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
     const bool z = (a == 0.0);
 #define LD(off) (z ? p[off] : p[off] + a * d[off])
 #pragma unroll
@@ -256,8 +262,8 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
         for (int i = 0; i < 3; ++i) gu[i] = 2.0 * sd.w_tr * (n.u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * n.u[i] * n.zu;
         // previous-row multipliers: + lam_{k-1} on x_k, - Bp_{k-1}^T lam_{k-1} on u_k
         if (k >= 1) {
-            const double *pl = s.it + (size_t)(k - 1) * IT_N + I_LAM, *dl = s.dr + (size_t)(k - 1) * IT_N + I_LAM;
-            const double *Bp = s.Bp(k - 1);
+            cgf64 *pl = s.it + (size_t)(k - 1) * IT_N + I_LAM, *dl = s.dr + (size_t)(k - 1) * IT_N + I_LAM;
+            cgf64 *Bp = s.Bp(k - 1);
             double lm[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) { lm[i] = pl[i] + a * dl[i]; gx[i] += lm[i]; }
@@ -270,8 +276,8 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
             }
         }
         if (k <= K - 2) {
-            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
-            const double *pn = s.it + (size_t)(k + 1) * IT_N, *dn = s.dr + (size_t)(k + 1) * IT_N;
+            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
+            cgf64 *pn = s.it + (size_t)(k + 1) * IT_N, *dn = s.dr + (size_t)(k + 1) * IT_N;
             double un[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) un[j] = pn[I_U + j] + a * dn[I_U + j];
@@ -322,7 +328,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #pragma unroll
             for (int i = 0; i < 3; ++i) gx[i] += 2.0 * n.x[i] * n.zrmax;
             if (k <= K - 2) {
-                const double *rb = s.rbh + (size_t)k * 3;
+                cgf64 *rb = s.rbh + (size_t)k * 3;
                 ACC_P(-(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin + n.srmin);
                 ACC_C(n.srmin, n.zrmin);
 #pragma unroll
@@ -398,7 +404,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
     for (int k = lane; k < K; k += 64) {
         NodeVals n;
         load_node(s, k, 0.0, n);
-        double *nb = s.nb + (size_t)k * NB_N;
+        gf64 *nb = s.nb + (size_t)k * NB_N;
         double Wx[49];
 #pragma unroll
         for (int i = 0; i < 49; ++i) Wx[i] = 0.0;
@@ -426,7 +432,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             sig_rmax = n.zrmax / n.srmax; zh_rmax = mu / n.srmax + sig_rmax * (g + n.srmax);
         }
         if (k >= 1 && k <= K - 2) {
-            const double *rb = s.rbh + (size_t)k * 3;
+            cgf64 *rb = s.rbh + (size_t)k * 3;
             const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
             const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
 #pragma unroll
@@ -450,8 +456,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 nb[N_RHO + i] = (zh1 - zh2) - (bb / aa) * gt;
             }
             // dynamics residual e_k
-            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
-            const double *pn = s.it + (size_t)(k + 1) * IT_N;
+            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
+            cgf64 *pn = s.it + (size_t)(k + 1) * IT_N;
             const double tf = s.itg[G_TF];
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
@@ -510,8 +516,12 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             for (int i = 0; i < 7; ++i)
                 for (int j = 0; j < 7; ++j) sd.WxK[i * 7 + j] += sd.gam * sd.avt[i] * sd.avt[j];
         }
+        // the terminal node's slot carries the Hessian the recursion uses (the soft part stays in LDS for the residual)
+        if (k == K - 1) { for (int i = 0; i < 49; ++i) nb[N_WX + i] = sd.WxK[i]; }
+        else {
 #pragma unroll
-        for (int i = 0; i < 49; ++i) nb[N_WX + i] = Wx[i];
+            for (int i = 0; i < 49; ++i) nb[N_WX + i] = Wx[i];
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) nb[N_GX + i] = gx[i];
 #pragma unroll
@@ -541,6 +551,16 @@ __device__ __forceinline__ double dot_el(const double *A, int ar, int ac, const 
     return acc;
 }
 
+// 1/d for d > 0 well inside the normal range: hardware seed + three Newton steps (the full IEEE division
+// sequence with its scaling/fix-up is not needed for pivots and determinants)
+__device__ __forceinline__ double rcp_pos(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    return r;
+}
+
 // symmetric 3x3 inverse with positive-definiteness test (leading minors)
 __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 {
@@ -548,7 +568,7 @@ __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
     const double m2 = a * d - b * b;
     const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
     const bool ok = (a > 0.0) && (m2 > 0.0) && (det > 0.0);
-    const double id = 1.0 / det;
+    const double id = ok ? rcp_pos(det) : 0.0;
     Qi[0] = (d * f - e * e) * id; Qi[1] = (c * e - b * f) * id; Qi[2] = (b * e - c * d) * id;
     Qi[3] = Qi[1]; Qi[4] = (a * f - c * c) * id; Qi[5] = (b * c - a * e) * id;
     Qi[6] = Qi[2]; Qi[7] = Qi[5]; Qi[8] = (a * d - b * b) * id;
@@ -556,15 +576,15 @@ __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 }
 
 struct StageOps {          // operands of one node, double-buffered in LDS
-    double A[49], Wx[49], G[49], Pt[49], Minv[49];
-    double Bn[21], Bpm[21], Bh[21], Kg[21];
-    double Wu[9], Qi[9], D[8];
+    double A[49], Bn[21], Bpm[21], Wx[49], Wu[9], D[7];   // prefetched inputs, contiguous in fetch order (OPS_IN)
+    double G[49], Pt[49], Minv[49], Bh[21], Kg[21];
 };
+constexpr int OPS_IN = 156;
 
 struct Scratch {   // LDS working set of the recursion
     StageOps ops[2];
     double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
-    double Pn[49], L[49], WlLi[98], PtA[49], Qyy[49];
+    double Pn[49], WlLi[98], PtA[49], Qyy[49];
     double PtBh[21], WxBp[21], Quy[21];
     double Quu[9];
 };
@@ -579,28 +599,6 @@ __device__ __forceinline__ double dotN(const double *a, int sa, const double *b,
 #pragma unroll
     for (int l = 0; l < N; ++l) acc += x[l] * y[l];
     return acc;
-}
-
-// In-register LDL^T of the 7x7 SPD matrix whose element (i,j) sits in lane i*7+j (lanes 0..48): right-looking
-// elimination with ds_bpermute broadcasts, no LDS traffic, no barriers, one reciprocal per pivot.
-// Returns Lt(i,j) (unit lower, j < i; 0 elsewhere) and the reciprocals of the pivots (wave-uniform).
-__device__ __forceinline__ double ldl7_reg(double m, int lane, double (&rd)[7], bool &ok)
-{
-    const int i = lane / 7, j = lane - 7 * i;
-    const int ic = (i < 7) ? i : 0;
-    ok = true;
-    double rsel = 0.0;
-#pragma unroll
-    for (int p = 0; p < 7; ++p) {
-        const double d = __shfl(m, p * 8, 64);
-        const double mip = __shfl(m, ic * 7 + p, 64);
-        const double mjp = __shfl(m, j * 7 + p, 64);
-        if (!(d > 0.0)) ok = false;
-        rd[p] = 1.0 / d;
-        if (i > p && j > p && i < 7) m -= (mip * rd[p]) * mjp;
-        if (j == p) rsel = rd[p];
-    }
-    return (i < 7 && j < i) ? m * rsel : 0.0;
 }
 
 #ifdef MPCX_PHASE_TIMING
@@ -621,7 +619,7 @@ __device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, i
     const int K = s.K;
     const bool dyn = (k <= K - 2);
     if (c == 0) {
-        const double *ch = s.ch + (size_t)k * CH_N + C_RHS;
+        cgf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
         ci.gx = ch[R_GX + r];
         if (r < 3) ci.gu = ch[R_GU + r];
         if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
@@ -630,60 +628,78 @@ __device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, i
     return ci;
 }
 
+// Branch-free prefetch of the same inputs for a node k <= K-2: every lane loads from a valid address and
+// chan_mask zeroes what its channel / component does not carry, so the loads stay in flight across the
+// arithmetic of the node before (a load inside a divergent branch would be waited for at the branch's end).
+struct ChanRaw { double gx, gu, rho, aff; };
+
+__device__ __forceinline__ ChanRaw chan_fetch(const Sat &s, int k, int c, int rr, int r3)
+{
+    const int K = s.K;
+    cgf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
+    cgf64 *pa = (c == 1) ? s.Sig(k < K - 2 ? k : K - 2) + rr : ch + R_AFF + rr;
+    ChanRaw cr;
+    cr.gx = ch[R_GX + rr]; cr.gu = ch[R_GU + r3]; cr.rho = ch[R_RHO + rr]; cr.aff = *pa;
+    return cr;
+}
+
+__device__ __forceinline__ ChanIn chan_mask(const ChanRaw &cr, int c, int r, bool act)
+{
+    ChanIn ci;
+    const bool c0 = act && c == 0;
+    ci.gx = c0 ? cr.gx : 0.0; ci.gu = (c0 && r < 3) ? cr.gu : 0.0; ci.rho = c0 ? cr.rho : 0.0;
+    ci.aff = (act && c <= 1) ? cr.aff : 0.0;
+    return ci;
+}
+
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
 // With fuse_sweep the backward linear-term sweep of all 8 channels rides along: node k's p_k, qu_k are formed
 // right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
-__device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane, bool fuse_sweep)
+__device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratch &w, int lane, bool fuse_sweep)
 {
+    const Sat s = s_in;   // private copy: lives in registers, is not re-read after every LDS fence
     const int K = s.K;
     bool good = true;
     const int sc = lane >> 3, sr = lane & 7;
     const bool sact = fuse_sweep && sr < 7;
     const int srr = (sr < 7) ? sr : 6, sr3 = (sr < 3) ? sr : 2;
-    ChanIn cur = chan_inputs(s, sd, K - 1, sc, sr, sact), nxt = cur;
+    ChanIn cur = chan_inputs(s, sd, K - 1, sc, sr, sact);
+    ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
     double pnext = 0.0;
-    // operand prefetch: node k's (A, Wx, Bn, Bpm, Wu, D) -> registers -> LDS buffer
+    // operand prefetch: node k's (A, Bn | Bpm | Wx, Wu, D) -> registers -> LDS buffer.  Three branch-free loads per
+    // lane: A, Bn are the head of stage record k, Bpm = B_kp of record k-1 (same offset), Wx|Wu|D the head of the
+    // Newton-block record; what node k does not have (no dynamics at K-1, no Bpm at 0) is zeroed when stashed.
     double pre[3];
+    const int e1 = lane + 64, e2 = lane + 128;
     auto fetch = [&](int k) {
-        const double *nb = s.nb + (size_t)k * NB_N;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = lane + 64 * q;
-            double v = 0.0;
-            if (e < 49) v = (k <= K - 2) ? s.A(k)[e] : 0.0;
-            else if (e < 98) v = (k == K - 1) ? sd.WxK[e - 49] : nb[N_WX + e - 49];
-            else if (e < 119) v = (k <= K - 2) ? s.Bn(k)[e - 98] : 0.0;
-            else if (e < 140) v = (k >= 1) ? s.Bp(k - 1)[e - 119] : 0.0;
-            else if (e < 149) v = nb[N_WU + e - 140];
-            else if (e < 156) v = (k <= K - 2) ? nb[N_D + e - 149] : 0.0;
-            pre[q] = v;
-        }
+        cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
+        cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
+        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + (e1 - 91);
+        cgf64 *p2 = nb + (e2 < OPS_IN ? e2 - 91 : 0);
+        pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
     };
-    auto stash = [&](StageOps &o) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = lane + 64 * q;
-            if (e < 49) o.A[e] = pre[q];
-            else if (e < 98) o.Wx[e - 49] = pre[q];
-            else if (e < 119) o.Bn[e - 98] = pre[q];
-            else if (e < 140) o.Bpm[e - 119] = pre[q];
-            else if (e < 149) o.Wu[e - 140] = pre[q];
-            else if (e < 156) o.D[e - 149] = pre[q];
-        }
+    auto stash = [&](StageOps &o, int k) {
+        const bool dynk = (k <= K - 2);
+        double *in = o.A;
+        in[lane] = dynk ? pre[0] : 0.0;
+        in[e1] = ((e1 < 70) ? dynk : (e1 < 91) ? (k >= 1) : true) ? pre[1] : 0.0;
+        if (e2 < OPS_IN) in[e2] = (e2 < 149 || dynk) ? pre[2] : 0.0;
     };
     fetch(K - 1);
-    stash(w.ops[(K - 1) & 1]);
+    stash(w.ops[(K - 1) & 1], K - 1);
     for (int e = lane; e < 49; e += 64) w.Pn[e] = 0.0;
     __syncthreads();
     const int mi = lane / 7, mj = lane - 7 * mi;
+    const int xc = (lane < 7) ? lane : 6;                 // column of [Pn | I] this lane substitutes (lanes 0..13)
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
-        double *fac = s.fac + (size_t)k * FAC_N;
+        gf64 *fac = s.fac + (size_t)k * FAC_N;
         FT_DECL
-        if (k >= 1) { fetch(k - 1); if (fuse_sweep) nxt = chan_inputs(s, sd, k - 1, sc, sr, sact); }
+        if (k >= 1) { fetch(k - 1); if (fuse_sweep) nraw = chan_fetch(s, k - 1, sc, srr, sr3); }
         const bool dyn = (k <= K - 2);
         FT_MARK(0)
-        // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm ; LDL^T of M = D + Pn in registers
+        // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm
         if (lane < 21) {
             const int i = lane / 3, j = lane - 3 * i;
             o.Bh[lane] = dyn ? o.Bn[lane] + dotN<7>(o.A + i * 7, 1, o.Bpm + j, 3) : 0.0;
@@ -693,34 +709,48 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
         }
         double rd[7] = {0, 0, 0, 0, 0, 0, 0};
         if (dyn) {
-            const double m = (lane < 49) ? w.Pn[lane] + (mi == mj ? o.D[mi] : 0.0) : 0.0;
-            bool okc;
-            const double lt = ldl7_reg(m, lane, rd, okc);
-            if (!okc) good = false;
-            if (lane < 49) w.L[lane] = lt;
-            // right-hand sides [Pn | I]
-            for (int e = lane; e < 98; e += 64) { const int r = e / 14, c = e - 14 * r; w.WlLi[e] = (c < 7) ? w.Pn[r * 7 + c] : (c - 7 == r ? 1.0 : 0.0); }
+            // P2: LDL^T of M = D + Pn, redundantly in the registers of every lane (broadcast LDS reads, no exchange):
+            // m holds the lower triangle, the strict part ends up as Lt.  Same arithmetic as the oracle's ldl_solve7.
+            double m[28];
+#pragma unroll
+            for (int i = 0, n = 0; i < 7; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j, ++n) m[n] = w.Pn[i * 7 + j] + (i == j ? o.D[i] : 0.0);
+#pragma unroll
+            for (int pp = 0; pp < 7; ++pp) {
+                const double d = m[pp * (pp + 1) / 2 + pp];
+                if (!(d > 0.0)) good = false;
+                rd[pp] = rcp_pos(d);
+                double col[7];
+#pragma unroll
+                for (int i = pp + 1; i < 7; ++i) col[i] = m[i * (i + 1) / 2 + pp];
+#pragma unroll
+                for (int i = pp + 1; i < 7; ++i) {
+                    const double lip = col[i] * rd[pp];
+#pragma unroll
+                    for (int j = pp + 1; j <= i; ++j) m[i * (i + 1) / 2 + j] -= lip * col[j];
+                    m[i * (i + 1) / 2 + pp] = lip;
+                }
+            }
+            // P3: [X1 | X2] = Lt^-1 [Pn | I] (unit lower), lane c < 14 owns column c
+            double x[7];
+#pragma unroll
+            for (int pp = 0; pp < 7; ++pp) {
+                const double pv = w.Pn[pp * 7 + xc];
+                x[pp] = (lane < 7) ? pv : (lane - 7 == pp ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int pp = 1; pp < 7; ++pp)
+#pragma unroll
+                for (int q = 0; q < pp; ++q) x[pp] -= m[pp * (pp + 1) / 2 + q] * x[q];
+            if (lane < 14) {
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) w.WlLi[pp * 14 + lane] = x[pp];
+            }
         }
         wsync();
         FT_MARK(1)
         if (dyn) {
-            // P3: [X1 | X2] = Lt^-1 [Pn | I] (unit lower), one lane per column, everything in registers
-            if (lane < 14) {
-                double lt[21], x[7];
-#pragma unroll
-                for (int pp = 1, n = 0; pp < 7; ++pp)
-#pragma unroll
-                    for (int q = 0; q < pp; ++q, ++n) lt[n] = w.L[pp * 7 + q];
-#pragma unroll
-                for (int pp = 0; pp < 7; ++pp) x[pp] = w.WlLi[pp * 14 + lane];
-#pragma unroll
-                for (int pp = 1, n = 0; pp < 7; ++pp)
-#pragma unroll
-                    for (int q = 0; q < pp; ++q, ++n) x[pp] -= lt[n] * x[q];
-#pragma unroll
-                for (int pp = 0; pp < 7; ++pp) w.WlLi[pp * 14 + lane] = x[pp];
-            }
-            wsync();
             FT_MARK(2)
             // P4: Pt = sym(Pn - X1^T R X1) ; G = X1^T R X2 ; Minv = X2^T R X2 with R = diag(1/d)
             if (lane < 49) {
@@ -806,15 +836,15 @@ __device__ __noinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &
 #pragma unroll
             for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
             if (sact) {
-                double *ch = s.ch + (size_t)k * CH_N;
+                gf64 *ch = s.ch + (size_t)k * CH_N;
                 ch[C_P + sc * 7 + sr] = pp;
                 if (sr < 3) ch[C_QU + sc * 3 + sr] = qu;
                 pnext = pp;
             }
-            cur = nxt;
+            if (k >= 1) cur = chan_mask(nraw, sc, sr, sact);
         }
         FT_MARK(8)
-        if (k >= 1) stash(w.ops[(k - 1) & 1]);
+        if (k >= 1) stash(w.ops[(k - 1) & 1], k - 1);
         wsync();
         FT_MARK(9)
     }
@@ -830,7 +860,7 @@ struct SweepPre { double v[5]; };
 
 __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
-    const double *fac = s.fac + (size_t)k * FAC_N;
+    cgf64 *fac = s.fac + (size_t)k * FAC_N;
 #pragma unroll
     for (int q = 0; q < 4; ++q) pre.v[q] = fac[lane + 64 * q];
     pre.v[4] = (lane + 256 < FAC_USED) ? fac[lane + 256] : 0.0;
@@ -844,8 +874,9 @@ __device__ __forceinline__ void sweep_stash_mats(double *f, int lane, const Swee
 }
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
-__device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
+__device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
+    const Sat s = s_in;
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
     const bool act = (c >= c0 && c < c1) && r < 7;
@@ -883,7 +914,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &
 #pragma unroll
         for (int q = 0; q < 3; ++q) p -= Kgcol[q] * __shfl(qu, q, 8);
         if (act) {
-            double *ch = s.ch + (size_t)k * CH_N;
+            gf64 *ch = s.ch + (size_t)k * CH_N;
             ch[C_P + c * 7 + r] = p;
             if (r < 3) ch[C_QU + c * 3 + r] = qu;
             pnext = p;
@@ -897,8 +928,9 @@ __device__ __noinline__ void sweep_backward(const Sat &s, SatData &sd, Scratch &
 
 // Forward sweep for channels [c0, c1): stores each channel's trajectory (x, u, nu, lam) per node and
 // accumulates the border coefficients (Sigma.lam, x_K).
-__device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w, int c0, int c1, int lane)
+__device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
+    const Sat s = s_in;
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
     const bool act = (c >= c0 && c < c1) && r < 7;
@@ -906,22 +938,25 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
     SweepPre pre;
     sweep_fetch_mats(s, 0, lane, pre);
     sweep_stash_mats(w.flat[0], lane, pre);
-    ChanIn cur = chan_inputs(s, sd, 0, c, r, act), nxt = cur;
-    auto load_pq = [&](int k, double &qu, double &pn) {
-        qu = 0.0; pn = 0.0;
-        if (!act) return;
-        const double *ch = s.ch + (size_t)k * CH_N;
-        if (r < 3) qu = ch[C_QU + c * 3 + r];
-        if (k <= K - 2) pn = (ch + CH_N)[C_P + c * 7 + r];
+    ChanIn cur = chan_inputs(s, sd, 0, c, r, act);
+    ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
+    // qu_k, p_{k+1} and Sigma_k of the lane's channel / component: branch-free loads, masked after arrival
+    auto load_pq = [&](int k, double &qu, double &pn, double &sg) {
+        cgf64 *ch = s.ch + (size_t)k * CH_N;
+        qu = ch[C_QU + c * 3 + r3];
+        pn = (ch + (k <= K - 2 ? CH_N : 0))[C_P + c * 7 + rr];
+        sg = s.Sig(k <= K - 2 ? k : K - 2)[rr];
     };
-    double quc, pnc, qun = 0.0, pnn = 0.0;
-    load_pq(0, quc, pnc);
+    double quc, pnc, sgc, qun = 0.0, pnn = 0.0, sgn = 0.0;
+    load_pq(0, quc, pnc, sgc);
+    if (!(act && r < 3)) quc = 0.0;
+    if (!(act && K >= 2)) pnc = 0.0;
     double y = 0.0, siglam = 0.0;
     __syncthreads();
     for (int k = 0; k < K; ++k) {
         const double *f = w.flat[k & 1];
         FT_DECL
-        if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nxt = chan_inputs(s, sd, k + 1, c, r, act); load_pq(k + 1, qun, pnn); }
+        if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nraw = chan_fetch(s, k + 1, c, rr, r3); load_pq(k + 1, qun, pnn, sgn); }
         const bool dyn = (k <= K - 2);
         FT_MARK(10)
         double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
@@ -949,20 +984,23 @@ __device__ __noinline__ void sweep_forward(const Sat &s, SatData &sd, Scratch &w
         for (int q = 0; q < 7; ++q) nu -= Gcol[q] * __shfl(yh, q, 8) + Mrow[q] * __shfl(wv, q, 8);
         FT_MARK(12)
         if (act) {
-            double *tr = s.traj + ((size_t)k * NCH + c) * TR_N;
+            gf64 *tr = s.traj + ((size_t)k * NCH + c) * TR_N;
             tr[T_X + r] = x;
             if (r < 3) tr[T_U + r] = u;
             if (k == K - 1) sd.xK[c][r] = x;
             if (dyn) {
                 const double lam = Dr * nu + cur.rho;
                 tr[T_NU + r] = nu; tr[T_LAM + r] = lam;
-                siglam += s.Sig(k)[r] * lam;
+                siglam += sgc * lam;
                 y = yh + nu;
             }
         }
         FT_MARK(13)
-        if (k + 1 < K) sweep_stash_mats(w.flat[(k + 1) & 1], lane, pre);
-        cur = nxt; quc = qun; pnc = pnn;
+        if (k + 1 < K) {
+            sweep_stash_mats(w.flat[(k + 1) & 1], lane, pre);
+            cur = chan_mask(nraw, c, r, act);
+            quc = (act && r < 3) ? qun : 0.0; pnc = (act && k + 1 <= K - 2) ? pnn : 0.0; sgc = sgn;
+        }
         wsync();
         FT_MARK(14)
     }
@@ -983,7 +1021,7 @@ __device__ __noinline__ void combine_channels(const Sat &s, SatData &sd, int lan
     for (int e = lane; e < K * TR_N; e += 64) {
         const int k = e / TR_N, i = e - k * TR_N;
         if (k == K - 1 && i >= T_NU) continue;
-        const double *tr = s.traj + (size_t)k * NCH * TR_N + i;
+        cgf64 *tr = s.traj + (size_t)k * NCH * TR_N + i;
         double v = tr[0];
 #pragma unroll
         for (int j = 0; j < NBD; ++j) v += sol[j] * tr[(1 + j) * TR_N];
@@ -1073,9 +1111,9 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
     double gtf_part = 0.0;
     const double dtf = s.drg[G_TF];
     for (int k = lane; k < K; k += 64) {
-        const double *nb = s.nb + (size_t)k * NB_N;
-        const double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
-        double *rec = s.ch + (size_t)k * CH_N + C_RHS;
+        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cgf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
         double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -1084,7 +1122,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         }
         double gx[7], gu[3];
         if (k >= 1) {
-            const double *W = (k == K - 1) ? sd.WxKsoft : nb + N_WX;
+            const double *W = (k == K - 1) ? (const double *)sd.WxKsoft : (const double *)(nb + N_WX);   // LDS or HBM: generic
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 double acc = ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]) + ltm[i];
@@ -1108,7 +1146,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             gu[i] = acc;
         }
         if (k >= 1) {
-            const double *Bp = s.Bp(k - 1);
+            cgf64 *Bp = s.Bp(k - 1);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double acc = 0.0;
@@ -1118,8 +1156,8 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             }
         }
         if (k <= K - 2) {
-            const double *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k);
-            const double *dn = d + IT_N;
+            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k);
+            cgf64 *dn = d + IT_N;
             if (k >= 1) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
@@ -1156,7 +1194,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
     }
     gtf_rhs = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
-    const double *dK = s.dr + (size_t)(K - 1) * IT_N;
+    cgf64 *dK = s.dr + (size_t)(K - 1) * IT_N;
     double av = 0.0;
     for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
     rvt_rhs = -sd.cv - av;
@@ -1168,7 +1206,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
     __syncthreads();
     // terminal-node rhs completion: capped share of the rank-1 gradient terms and the AL shift
     if (lane == 0) {
-        double *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
+        gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
         for (int t = 0; t < NTERM; ++t) {
             const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
             for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
@@ -1185,7 +1223,7 @@ __device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, do
     const int K = s.K;
     for (int e = lane; e < K * 24; e += 64) {
         const int k = e / 24, i = e - k * 24;
-        const double *nb = s.nb + (size_t)k * NB_N;
+        cgf64 *nb = s.nb + (size_t)k * NB_N;
         double v;
         if (i < 7) v = (k == 0) ? 0.0 : ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]);
         else if (i < 10) v = nb[N_GU + i - 7];
@@ -1198,7 +1236,7 @@ __device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, do
     for (int t = 0; t < NTERM; ++t) gterm[t] = sd.tgh[t];
     __syncthreads();
     if (lane == 0) {
-        double *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
+        gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
         for (int t = 0; t < NTERM; ++t) {
             const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
             for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
@@ -1217,8 +1255,8 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
     for (int k = lane; k < K; k += 64) {
         NodeVals n;
         load_node(s, k, 0.0, n);
-        const double *nb = s.nb + (size_t)k * NB_N;
-        double *d = s.dr + (size_t)k * IT_N;
+        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        gf64 *d = s.dr + (size_t)k * IT_N;
         {
             const double g = n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u;
             const double sig = n.zu / n.su, zh = mu / n.su + sig * (g + n.su);
@@ -1234,7 +1272,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             LIM(n.srmax, d[I_SRMAX]); LIM(n.zrmax, d[I_ZRMAX]);
         }
         if (k >= 1 && k <= K - 2) {
-            const double *rb = s.rbh + (size_t)k * 3;
+            cgf64 *rb = s.rbh + (size_t)k * 3;
             const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
             const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
             const double dg = -(rb[0] * d[I_X] + rb[1] * d[I_X + 1] + rb[2] * d[I_X + 2]);
@@ -1297,14 +1335,14 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
 #define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
                              z_ = fmax(fmin(z_, kKappaSigma * mu / s_), mu / (kKappaSigma * s_)); (sv) = s_; (zv) = z_; }
     for (int k = lane; k < K; k += 64) {
-        double *p = s.it + (size_t)k * IT_N;
-        const double *d = s.dr + (size_t)k * IT_N;
+        gf64 *p = s.it + (size_t)k * IT_N;
+        cgf64 *d = s.dr + (size_t)k * IT_N;
         for (int i = 0; i < IT_N - 1; ++i) p[i] += a * d[i];
-        const double *x = p + I_X, *u = p + I_U;
+        cgf64 *x = p + I_X, *u = p + I_U;
         SAFE(p[I_SU], p[I_ZU], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u);
         if (k >= 1) SAFE(p[I_SRMAX], p[I_ZRMAX], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rmax);
         if (k >= 1 && k <= K - 2) {
-            const double *rb = s.rbh + (size_t)k * 3;
+            cgf64 *rb = s.rbh + (size_t)k * 3;
             SAFE(p[I_SRMIN], p[I_ZRMIN], -(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin);
         }
         if (k <= K - 2) {
@@ -1317,7 +1355,7 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
     __syncthreads();
     if (lane == 0) {
         for (int i = 0; i < GL_N; ++i) s.itg[i] += a * s.drg[i];
-        const double *x = s.it + (size_t)(K - 1) * IT_N + I_X;
+        cgf64 *x = s.it + (size_t)(K - 1) * IT_N + I_X;
         for (int j = 0; j < 6; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
@@ -1364,10 +1402,10 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
     const int K = a.K;
     Sat s;
     s.K = K;
-    s.stage = a.stage + (size_t)sat * (K - 1) * MPCX_STAGE_DOUBLES;
-    s.xbar = a.xbar + (size_t)sat * 7 * K;
-    s.ubar = a.ubar + (size_t)sat * 3 * K;
-    double *ws = a.ws + (size_t)sat * a.ws_stride;
+    s.stage = (cgf64 *)a.stage + (size_t)sat * (K - 1) * MPCX_STAGE_DOUBLES;
+    s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * K;
+    s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * K;
+    gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
     s.it = ws; ws += (size_t)K * IT_N;
     s.dr = ws; ws += (size_t)K * IT_N;
     s.nb = ws; ws += (size_t)K * NB_N;
@@ -1395,9 +1433,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * K + k];
         for (int i = 0; i < 3; ++i) u[i] = s.ubar[(size_t)i * K + k];
         const double rn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-        double *rb = s.rbh + (size_t)k * 3;
+        gf64 *rb = s.rbh + (size_t)k * 3;
         for (int i = 0; i < 3; ++i) rb[i] = x[i] / rn;           // optimizer.py:129-130
-        double *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        gf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
         for (int i = 0; i < IT_N; ++i) { p[i] = 0.0; d[i] = 0.0; }
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
@@ -1470,8 +1508,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             if (ok) {
                 // direction := (0, ..., -lam, -lam_vt) so that the first residual carries no multipliers
                 for (int k = lane; k < K; k += 64) {
-                    double *d = s.dr + (size_t)k * IT_N;
-                    const double *p = s.it + (size_t)k * IT_N;
+                    gf64 *d = s.dr + (size_t)k * IT_N;
+                    cgf64 *p = s.it + (size_t)k * IT_N;
                     for (int i = 0; i < IT_N; ++i) d[i] = 0.0;
                     if (k <= K - 2) for (int i = 0; i < 7; ++i) d[I_LAM + i] = -p[I_LAM + i];
                 }
@@ -1513,7 +1551,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
                 // finite check on the direction
                 double bad = 0.0;
                 for (int k = lane; k < K; k += 64) {
-                    const double *d = s.dr + (size_t)k * IT_N;
+                    cgf64 *d = s.dr + (size_t)k * IT_N;
                     for (int i = 0; i < I_STP; ++i) if (!(fabs(d[i]) < 1e300)) bad = 1.0;
                 }
                 if (!(fabs(s.drg[G_TF]) < 1e300)) bad = 1.0;
@@ -1547,7 +1585,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
 
     // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----
     for (int k = lane; k < K; k += 64) {
-        const double *p = s.it + (size_t)k * IT_N;
+        cgf64 *p = s.it + (size_t)k * IT_N;
         for (int i = 0; i < 7; ++i) {
             a.X[(size_t)sat * 7 * K + (size_t)i * K + k] = p[I_X + i];
             a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
