@@ -25,9 +25,10 @@ enum { I_X = 0, I_U = 7, I_NU = 10, I_T = 17, I_LAM = 24, I_STP = 31, I_ZTP = 38
        I_SU = 59, I_ZU = 60, I_SRMAX = 61, I_ZRMAX = 62, I_SRMIN = 63, I_ZRMIN = 64, IT_N = 66 };
 // global part of iterate / direction
 enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16, G_TF = 18, G_LVT = 19, GL_N = 24 };
-// Newton blocks per node
-enum { N_WX = 0, N_WU = 49, N_D = 58, N_AA = 65, N_BB = 72, N_GT = 79, N_RHO = 86, N_GX = 93, N_GU = 100,
-       N_E = 103, NB_N = 112 };
+// Newton blocks per node: the part the recursion reads as one contiguous record per node ...
+enum { N_WX = 0, N_WU = 49, N_D = 58, NB_N = 65 };
+// ... and the part only the node-parallel phases touch (field-major, see Col below)
+enum { NS_AA = 0, NS_BB = 7, NS_GT = 14, NS_RHO = 21, NS_GX = 28, NS_GU = 35, NS_E = 38, NS_D = 45, NS_N = 52 };
 // factorisation per node
 // factorisation per node, stored in exactly the order the sweeps stage it through LDS (one contiguous block)
 enum { F_A = 0, F_G = 49, F_PT = 98, F_MINV = 147, F_KG = 196, F_BH = 217, F_BPM = 238, F_QI = 259, F_D = 268, FAC_USED = 275, FAC_N = 280 };
@@ -55,9 +56,14 @@ struct SolveArgs {
     size_t ws_stride;
 };
 
+// padded node count: leading dimension of the field-major arrays (rows start on 128-byte boundaries)
+__host__ __device__ inline int padded_nodes(int K) { return (K + 15) & ~15; }
+
 __host__ __device__ inline size_t ws_doubles(int K)
 {
-    return (size_t)K * (2 * IT_N + NB_N + FAC_N + CH_N + 8 * 24) + 2 * GL_N + 3 * (size_t)K + 64;
+    const size_t KP = (size_t)padded_nodes(K);
+    const size_t n = KP * (2 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 2 * GL_N;
+    return (n + 15) & ~(size_t)15;
 }
 
 // ---- per-satellite constant data kept in LDS --------------------------------------------
@@ -200,15 +206,51 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
 typedef __attribute__((address_space(1))) double gf64;
 typedef const gf64 cgf64;
 
+// Field-major view of one node's record: element i of node k lives at base[i * ld + k].  The node-parallel phases
+// (one lane per node) read and write the same field of consecutive nodes in consecutive lanes, so every access is
+// a couple of full cache lines instead of one line per lane.
+// The base is made wave-uniform (SGPR pair) and the per-lane part is a 32-bit byte offset, so an access is one
+// global_load/store with scalar base + vector offset and costs a single 32-bit VALU add for its address.
+template <typename T>
+__device__ __forceinline__ T *wave_uniform(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
+template <typename T>
+struct Col {
+    T *base;      // wave-uniform array base
+    int k;        // element offset of this lane's node (and of the first field of the view)
+    int ld;
+    __device__ __forceinline__ T &operator[](int i) const
+    {
+        typedef __attribute__((address_space(1))) char gchar;
+        return *(T *)((gchar *)base + (unsigned)((i * ld + k) * 8));
+    }
+    __device__ __forceinline__ Col operator+(int off) const { return Col{base, k + off * ld, ld}; }
+    __device__ __forceinline__ Col node(int dk) const { return Col{base, k + dk, ld}; }   // same fields, node k + dk
+};
+
 struct Sat {
-    int K;
-    cgf64 *stage, *xbar, *ubar;   // stage (K-1,105); xbar (7,K); ubar (3,K)
-    gf64 *it, *itg, *dr, *drg, *nb, *fac, *ch, *traj, *rbh;   // workspace pieces
+    int K, KP;
+    cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
+    gf64 *it, *dr, *nbs, *stT, *rbh;            // field-major [field][KP]: iterate, direction, Newton scalars, stage copy, r-hat
+    gf64 *itg, *drg, *nb, *fac, *ch, *traj;     // globals; record-per-node arrays read by the recursion (one wave, one record)
+    __device__ Col<gf64> itn(int k) const { return Col<gf64>{wave_uniform(it), k, KP}; }
+    __device__ Col<gf64> drn(int k) const { return Col<gf64>{wave_uniform(dr), k, KP}; }
+    __device__ Col<gf64> nsn(int k) const { return Col<gf64>{wave_uniform(nbs), k, KP}; }
+    __device__ Col<gf64> rbn(int k) const { return Col<gf64>{wave_uniform(rbh), k, KP}; }
+    // stage blocks for the node-parallel phases (field-major copy) ...
+    __device__ Col<cgf64> At(int k) const { return Col<cgf64>{wave_uniform((cgf64 *)stT), k, KP}; }
+    __device__ Col<cgf64> Bnt(int k) const { return At(k) + 49; }
+    __device__ Col<cgf64> Bpt(int k) const { return At(k) + 70; }
+    __device__ Col<cgf64> Sigt(int k) const { return At(k) + 91; }
+    __device__ Col<cgf64> xit(int k) const { return At(k) + 98; }
+    // ... and for the recursion (the discretizer's records)
     __device__ cgf64 *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
-    __device__ cgf64 *Bn(int k) const { return A(k) + 49; }
-    __device__ cgf64 *Bp(int k) const { return A(k) + 70; }
     __device__ cgf64 *Sig(int k) const { return A(k) + 91; }
-    __device__ cgf64 *xi(int k) const { return A(k) + 98; }
 };
 
 // Trial point (iterate + a * direction) of one node, everything a residual evaluation needs.
@@ -218,11 +260,19 @@ struct NodeVals {
     double su, zu, srmax, zrmax, srmin, zrmin;
 };
 
+// iterate + a * direction for one field, branch-free: both loads always issue (so they can all be in flight
+// together); at a == 0 the direction value, which may be stale, is replaced by 0.
+__device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64> &d, int off, double a, bool z)
+{
+    const double dv = d[off], pv = p[off];
+    return fma(a, z ? 0.0 : dv, pv);
+}
+
 __device__ __forceinline__ void load_node(const Sat &s, int k, double a, NodeVals &n)
 {
-    cgf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+    const auto p = s.itn(k), d = s.drn(k);
     const bool z = (a == 0.0);
-#define LD(off) (z ? p[off] : p[off] + a * d[off])
+#define LD(off) trial_value(p, d, off, a, z)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         n.x[i] = LD(I_X + i); n.nu[i] = LD(I_NU + i); n.t[i] = LD(I_T + i); n.lam[i] = LD(I_LAM + i);
@@ -239,6 +289,12 @@ struct ResAcc {   // accumulators of one residual evaluation
     double dual_max, prim_max, comp_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
 };
 
+// The node-parallel phases are written as chunks "loads -> arithmetic (-> stores)" separated by scheduling
+// barriers: a chunk's loads are all in flight together (one memory latency per chunk instead of one per access,
+// which is what interleaved may-alias stores would force), and the barrier keeps the scheduler from hoisting the
+// loads of later chunks on top, which would spill.
+#define CHUNK_END __builtin_amdgcn_sched_barrier(0);
+
 // Perturbed KKT residual F_mu at (iterate + a*direction): ipopt's scaled error pieces and the
 // 2-norm used by the line search.  Lane k handles node k.  Results are wave-uniform.
 __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
@@ -248,97 +304,111 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     double gtf_part = 0.0;
     const double tf = s.itg[G_TF] + a * s.drg[G_TF];
     const double lvt = s.itg[G_LVT] + a * s.drg[G_LVT];
+    const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
+    const bool z = (a == 0.0);
 #define ACC_D(v) { const double q_ = (v); dual = fmax(dual, fabs(q_)); sq += q_ * q_; }
 #define ACC_P(v) { const double q_ = (v); prim = fmax(prim, fabs(q_)); sq += q_ * q_; }
 #define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; comp = fmax(comp, fabs(q_)); sq += q_ * q_; \
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
+#define TRIAL(P, D, off) trial_value(P, D, off, a, z)
     for (int k = lane; k < K; k += 64) {
-        NodeVals n;
-        load_node(s, k, a, n);
-        double gx[7], gu[3];
+        const auto p = s.itn(k), d = s.drn(k);
+        const bool has_prev = (k >= 1), dyn = (k <= K - 2);
+        // ---- chunk 0: states, thrust, neighbours' pieces, ball slacks ----
+        double x[7], u[3], gx[7], gu[3], lm[7], un[3], xn[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * sd.w_tr * (n.x[i] - s.xbar[(size_t)i * K + k]);
+        for (int i = 0; i < 7; ++i) x[i] = TRIAL(p, d, I_X + i);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * sd.w_tr * (n.u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * n.u[i] * n.zu;
-        // previous-row multipliers: + lam_{k-1} on x_k, - Bp_{k-1}^T lam_{k-1} on u_k
-        if (k >= 1) {
-            cgf64 *pl = s.it + (size_t)(k - 1) * IT_N + I_LAM, *dl = s.dr + (size_t)(k - 1) * IT_N + I_LAM;
-            cgf64 *Bp = s.Bp(k - 1);
-            double lm[7];
+        for (int i = 0; i < 3; ++i) u[i] = TRIAL(p, d, I_U + i);
+        const double su = TRIAL(p, d, I_SU), zu = TRIAL(p, d, I_ZU), srmax = TRIAL(p, d, I_SRMAX), zrmax = TRIAL(p, d, I_ZRMAX);
+        const double srmin = TRIAL(p, d, I_SRMIN), zrmin = TRIAL(p, d, I_ZRMIN);
+        {
+            const auto pm = p.node(has_prev ? -1 : 0) + I_LAM, dm = d.node(has_prev ? -1 : 0) + I_LAM;
+            const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { lm[i] = pl[i] + a * dl[i]; gx[i] += lm[i]; }
+            for (int i = 0; i < 7; ++i) { lm[i] = TRIAL(pm, dm, i); xn[i] = TRIAL(pn, dn, I_X + i); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
+        }
+        const auto rb = s.rbn(k);
+        const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * K + k]) + (has_prev ? lm[i] : 0.0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * u[i] * zu;
+        // thrust ball, every node
+        ACC_P(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u + su);
+        ACC_C(su, zu);
+        if (has_prev) {
+            const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            ACC_P(r2 - b_rmax + srmax);
+            ACC_C(srmax, zrmax);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrmax;
+            if (dyn) {
+                ACC_P(-(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin + srmin);
+                ACC_C(srmin, zrmin);
+                gx[0] -= rb0 * zrmin; gx[1] -= rb1 * zrmin; gx[2] -= rb2 * zrmin;
+            }
+        }
+        CHUNK_END
+        // ---- chunk 1: - Bp_{k-1}^T lam_{k-1} on u_k ----
+        if (has_prev) {
+            const auto Bp = s.Bpt(k - 1);
+            double b[21];
+#pragma unroll
+            for (int e = 0; e < 21; ++e) b[e] = Bp[e];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) acc += Bp[i * 3 + j] * lm[i];
+                for (int i = 0; i < 7; ++i) acc += b[i * 3 + j] * lm[i];
                 gu[j] -= acc;
             }
         }
-        if (k <= K - 2) {
-            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
-            cgf64 *pn = s.it + (size_t)(k + 1) * IT_N, *dn = s.dr + (size_t)(k + 1) * IT_N;
-            double un[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) un[j] = pn[I_U + j] + a * dn[I_U + j];
+        CHUNK_END
+        // ---- chunks 2..8: dynamics row i (optimizer.py:327-342), its multiplier, the L1 pair of nu_i ----
+        if (dyn) {
+            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k), xi = s.xit(k);
             double sl = 0.0;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                // dynamics residual row i (optimizer.py:327-342)
-                double acc = Sg[i] * tf + xi[i] + n.nu[i];
+                double ar[7], bn[3], bp[3];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc += A[i * 7 + j] * n.x[j];
+                for (int j = 0; j < 7; ++j) ar[j] = A[i * 7 + j];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += Bn[i * 3 + j] * n.u[j] + Bp[i * 3 + j] * un[j];
-                const double xn = pn[I_X + i] + a * dn[I_X + i];
-                ACC_P(xn - acc);
-                sl += Sg[i] * n.lam[i];
-                lsum += fabs(n.lam[i]);
+                for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; }
+                const double sg = Sg[i], xv = xi[i];
+                const double nu = TRIAL(p, d, I_NU + i), tt = TRIAL(p, d, I_T + i), lam = TRIAL(p, d, I_LAM + i);
+                const double stp = TRIAL(p, d, I_STP + i), ztp = TRIAL(p, d, I_ZTP + i);
+                const double stn = TRIAL(p, d, I_STN + i), ztn = TRIAL(p, d, I_ZTN + i);
+                double acc = sg * tf + xv + nu;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
+                ACC_P(xn[i] - acc);
+                sl += sg * lam;
+                lsum += fabs(lam);
                 // nu / t stationarity
-                ACC_D(n.ztp[i] - n.ztn[i] - n.lam[i]);
-                ACC_D(sd.w_nu - n.ztp[i] - n.ztn[i]);
-                ACC_P(n.nu[i] - n.t[i] + n.stp[i]);
-                ACC_P(-n.nu[i] - n.t[i] + n.stn[i]);
-                ACC_C(n.stp[i], n.ztp[i]);
-                ACC_C(n.stn[i], n.ztn[i]);
+                ACC_D(ztp - ztn - lam);
+                ACC_D(w_nu - ztp - ztn);
+                ACC_P(nu - tt + stp);
+                ACC_P(-nu - tt + stn);
+                ACC_C(stp, ztp);
+                ACC_C(stn, ztn);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) gx[j] -= ar[j] * lam;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) gu[j] -= bn[j] * lam;
+                CHUNK_END
             }
             gtf_part -= sl;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) acc += A[i * 7 + j] * n.lam[i];
-                gx[j] -= acc;
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) acc += Bn[i * 3 + j] * n.lam[i];
-                gu[j] -= acc;
-            }
-        }
-        // thrust ball, every node
-        ACC_P(n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u + n.su);
-        ACC_C(n.su, n.zu);
-        if (k >= 1) {
-            const double r2 = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2];
-            ACC_P(r2 - sd.b_rmax + n.srmax);
-            ACC_C(n.srmax, n.zrmax);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * n.x[i] * n.zrmax;
-            if (k <= K - 2) {
-                cgf64 *rb = s.rbh + (size_t)k * 3;
-                ACC_P(-(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin + n.srmin);
-                ACC_C(n.srmin, n.zrmin);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) gx[i] -= rb[i] * n.zrmin;
-            }
         }
         if (k == K - 1) {
             // terminal inequalities, final-radius ball, vt equality
             double cv, g6[6];
-            vt_reduced(n.x, sd.vt_des, cv, g6, nullptr);
+            vt_reduced(x, sd.vt_des, cv, g6, nullptr);
             ACC_P(cv);
 #pragma unroll
             for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
@@ -347,16 +417,16 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                 const double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
                 const double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
                 double gj = -sd.bT[j];
-                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * n.x[i]; gx[i] += sd.aT[j][i] * zj; }
+                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; gx[i] += sd.aT[j][i] * zj; }
                 ACC_P(gj + sj);
                 ACC_C(sj, zj);
             }
             const double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
-            ACC_P(n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax + srf);
+            ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax + srf);
             ACC_C(srf, zrf);
-            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * n.x[i] * zrf;
+            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrf;
         }
-        if (k >= 1) {
+        if (has_prev) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) ACC_D(gx[i]);
         }
@@ -378,6 +448,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #undef ACC_D
 #undef ACC_P
 #undef ACC_C
+#undef TRIAL
     out.dual_max = wave_max(dual); out.prim_max = wave_max(prim); out.comp_max = wave_max(comp);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
     out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
@@ -400,101 +471,142 @@ __device__ double scaled_error(const ResAcc &r, int K, double mu)
 __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta_w, int lane)
 {
     const int K = s.K;
-    double wtf_part = 0.0;
+    const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
+    const double tf = s.itg[G_TF];
     for (int k = lane; k < K; k += 64) {
-        NodeVals n;
-        load_node(s, k, 0.0, n);
+        const auto p = s.itn(k), ns = s.nsn(k);
+        const auto rb = s.rbn(k);
         gf64 *nb = s.nb + (size_t)k * NB_N;
-        double Wx[49];
-#pragma unroll
-        for (int i = 0; i < 49; ++i) Wx[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) Wx[i * 8] = 2.0 * sd.w_tr + delta_w;
-        double gx[7], gu[3];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * sd.w_tr * (n.x[i] - s.xbar[(size_t)i * K + k]);
-        // thrust ball
+        const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
+        // ---- chunk 0: objective, thrust ball, radius balls; next node's x, u for the dynamics residual ----
+        double x[7], u[3], xn[7], un[3], gx[7], gu[3], Wx3[9];
+        double zh_rmax = 0.0, sig_rmax = 0.0, zrmax;
         {
-            const double g = n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u;
-            const double sig = n.zu / n.su, zh = mu / n.su + sig * (g + n.su);
+            double bs[6], xb[7], ub[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                gu[i] = 2.0 * sd.w_tr * (n.u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * n.u[i] * zh;
+            for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; xb[i] = s.xbar[(size_t)i * K + k]; }
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    nb[N_WU + i * 3 + j] = (i == j ? 2.0 * sd.w_tr + delta_w + 2.0 * n.zu : 0.0) + sig * 4.0 * n.u[i] * n.u[j];
+            for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; ub[i] = s.ubar[(size_t)i * K + k]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
+            const auto pn = p.node(dyn ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) xn[i] = pn[I_X + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) un[i] = pn[I_U + i];
+            const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+            const double rbv[3] = {rb0, rb1, rb2};
+            const double su = bs[0], zu = bs[1], srmax = bs[2], srmin = bs[4], zrmin = bs[5];
+            zrmax = bs[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - xb[i]);
+            // thrust ball
+            double Wu[9];
+            {
+                const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
+                const double sig = zu / su, zh = mu / su + sig * (g + su);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zh;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        Wu[i * 3 + j] = (i == j ? 2.0 * w_tr + delta_w + 2.0 * zu : 0.0) + sig * 4.0 * u[i] * u[j];
+                }
+            }
+            if (k >= 1) {
+                const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+                const double g = r2 - b_rmax;
+                sig_rmax = zrmax / srmax; zh_rmax = mu / srmax + sig_rmax * (g + srmax);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Wx3[i] = ((i & 3) == 0) ? 2.0 * w_tr + delta_w : 0.0;
+            if (inner) {
+                const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
+                const double sig = zrmin / srmin, zh = mu / srmin + sig * (g + srmin);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    gx[i] += 2.0 * x[i] * zh_rmax - rbv[i] * zh;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        Wx3[i * 3 + j] += (i == j ? 2.0 * zrmax : 0.0) + sig_rmax * 4.0 * x[i] * x[j] + sig * rbv[i] * rbv[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
+            if (k != K - 1) {
+                // stage Hessian of x: diagonal + the 3x3 position block (the terminal node's slot is written below)
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        nb[N_WX + i * 7 + j] = (i < 3 && j < 3) ? Wx3[i * 3 + j] : (i == j ? 2.0 * w_tr + delta_w : 0.0);
             }
         }
-        double zh_rmax = 0.0, sig_rmax = 0.0;
-        if (k >= 1) {
-            const double r2 = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2];
-            const double g = r2 - sd.b_rmax;
-            sig_rmax = n.zrmax / n.srmax; zh_rmax = mu / n.srmax + sig_rmax * (g + n.srmax);
-        }
-        if (k >= 1 && k <= K - 2) {
-            cgf64 *rb = s.rbh + (size_t)k * 3;
-            const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
-            const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                gx[i] += 2.0 * n.x[i] * zh_rmax - rb[i] * zh;
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    Wx[i * 7 + j] += (i == j ? 2.0 * n.zrmax : 0.0) + sig_rmax * 4.0 * n.x[i] * n.x[j] + sig * rb[i] * rb[j];
-            }
-        }
-        if (k <= K - 2) {
-            // virtual-control block: eliminate t, keep D and rho (without multipliers)
+        CHUNK_END
+        // ---- chunks 1..7: component i of the virtual-control block (t eliminated, D and rho kept without
+        //      multipliers) and of the dynamics residual e_k ----
+        if (dyn) {
+            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k), xi = s.xit(k);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                const double g1 = n.nu[i] - n.t[i], g2 = -n.nu[i] - n.t[i];
-                const double s1 = n.ztp[i] / n.stp[i], s2 = n.ztn[i] / n.stn[i];
-                const double zh1 = mu / n.stp[i] + s1 * (g1 + n.stp[i]), zh2 = mu / n.stn[i] + s2 * (g2 + n.stn[i]);
-                const double aa = s1 + s2, bb = s2 - s1, gt = sd.w_nu - zh1 - zh2;
-                nb[N_D + i] = 4.0 * s1 * s2 / aa;
-                nb[N_AA + i] = aa; nb[N_BB + i] = bb; nb[N_GT + i] = gt;
-                nb[N_RHO + i] = (zh1 - zh2) - (bb / aa) * gt;
-            }
-            // dynamics residual e_k
-            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k), *xi = s.xi(k);
-            cgf64 *pn = s.it + (size_t)(k + 1) * IT_N;
-            const double tf = s.itg[G_TF];
+                double ar[7], bn[3], bp[3];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                double acc = Sg[i] * tf + xi[i] + n.nu[i];
+                for (int j = 0; j < 7; ++j) ar[j] = A[i * 7 + j];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc += A[i * 7 + j] * n.x[j];
+                for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; }
+                const double sg = Sg[i], xv = xi[i];
+                const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
+                const double stn = p[I_STN + i], ztn = p[I_ZTN + i];
+                const double g1 = nu - tt, g2 = -nu - tt;
+                const double s1 = ztp / stp, s2 = ztn / stn;
+                const double zh1 = mu / stp + s1 * (g1 + stp), zh2 = mu / stn + s2 * (g2 + stn);
+                const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
+                const double dd = 4.0 * s1 * s2 / aa;
+                double acc = sg * tf + xv + nu;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += Bn[i * 3 + j] * n.u[j] + Bp[i * 3 + j] * pn[I_U + j];
-                nb[N_E + i] = pn[I_X + i] - acc;
+                for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
+                nb[N_D + i] = dd; ns[NS_D + i] = dd;
+                ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
+                ns[NS_RHO + i] = (zh1 - zh2) - (bb / aa) * gt;
+                ns[NS_E + i] = xn[i] - acc;
+                CHUNK_END
             }
         }
         if (k == K - 1) {
+            double Wx[49];
+            for (int i = 0; i < 49; ++i) Wx[i] = 0.0;
+            for (int i = 0; i < 7; ++i) Wx[i * 8] = 2.0 * w_tr + delta_w;
             // terminal node: soft Hessian / gradient + the five rank-1 barrier terms
             double cv, g6[6];
-            vt_reduced(n.x, sd.vt_des, cv, g6, sd.Hv);
+            vt_reduced(x, sd.vt_des, cv, g6, sd.Hv);
             sd.cv = cv;
             for (int i = 0; i < 7; ++i) sd.avt[i] = (i < 6) ? g6[i] : 0.0;
             const double lvt = s.itg[G_LVT];
             double sig[6], zh[6];
             for (int j = 0; j < 6; ++j) {
                 double gj = -sd.bT[j];
-                for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * n.x[i];
+                for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
                 const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
                 sig[j] = zj / sj; zh[j] = mu / sj + sig[j] * (gj + sj);
             }
             const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
-            const double grf = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax;
+            const double grf = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
             const double sigrf = zrf / srf, zhrf = mu / srf + sigrf * (grf + srf);
             for (int i = 0; i < 49; ++i) sd.WxKsoft[i] = Wx[i];
-            for (int i = 0; i < 3; ++i) sd.WxKsoft[i * 8] += 2.0 * (n.zrmax + zrf);
+            for (int i = 0; i < 3; ++i) sd.WxKsoft[i * 8] += 2.0 * (zrmax + zrf);
             for (int i = 0; i < 6; ++i)
                 for (int j = 0; j < 6; ++j) sd.WxKsoft[i * 7 + j] += lvt * sd.Hv[i * 6 + j];
             for (int i = 0; i < 7; ++i) sd.gxKsoft[i] = gx[i];
             const int rows[NTERM] = {0, 1, 3, 5, -1};
             for (int t = 0; t < NTERM; ++t) {
                 if (rows[t] >= 0) for (int i = 0; i < 7; ++i) sd.ta[t][i] = sd.aT[rows[t]][i];
-                else for (int i = 0; i < 7; ++i) sd.ta[t][i] = (i < 3) ? 2.0 * n.x[i] : 0.0;
+                else for (int i = 0; i < 7; ++i) sd.ta[t][i] = (i < 3) ? 2.0 * x[i] : 0.0;
             }
             sd.tw[0] = sig[0]; sd.tgh[0] = zh[0];
             sd.tw[1] = sig[1] + sig[2]; sd.tgh[1] = zh[1] - zh[2];
@@ -518,14 +630,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         }
         // the terminal node's slot carries the Hessian the recursion uses (the soft part stays in LDS for the residual)
         if (k == K - 1) { for (int i = 0; i < 49; ++i) nb[N_WX + i] = sd.WxK[i]; }
-        else {
-#pragma unroll
-            for (int i = 0; i < 49; ++i) nb[N_WX + i] = Wx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) nb[N_GX + i] = gx[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) nb[N_GU + i] = gu[i];
     }
     if (lane == 0) {
         const double tf = s.itg[G_TF];
@@ -538,7 +642,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         }
         sd.Wtf = W; sd.gtf = g;
     }
-    (void)wtf_part;
     __syncthreads();
 }
 
@@ -1011,24 +1114,48 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     __syncthreads();
 }
 
-// direction += trajectory of channel 0 + sum_j sol[j] * trajectory of channel 1+j ; one lane per (node, component)
-__device__ __noinline__ void combine_channels(const Sat &s, SatData &sd, int lane)
+// direction (+)= trajectory of channel 0 + sum_j sol[j] * trajectory of channel 1+j ; one lane per (node, component),
+// four components per lane and round so that their loads are in flight together.  `first` (the plain solve of an
+// iteration): the direction is written, with -lam as the starting value of the multiplier part (the first
+// right-hand side carries no multipliers); otherwise (refinement) the correction is added.
+__device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int lane, bool first)
 {
-    const int K = s.K;
+    const Sat s = s_in;
+    const int K = s.K, KP = s.KP;
     double sol[NBD];
 #pragma unroll
     for (int j = 0; j < NBD; ++j) sol[j] = sd.sol[j];
-    for (int e = lane; e < K * TR_N; e += 64) {
-        const int k = e / TR_N, i = e - k * TR_N;
-        if (k == K - 1 && i >= T_NU) continue;
-        cgf64 *tr = s.traj + (size_t)k * NCH * TR_N + i;
-        double v = tr[0];
+    gf64 *dr = wave_uniform(s.dr);
+    cgf64 *it = wave_uniform((cgf64 *)s.it), *traj = wave_uniform((cgf64 *)s.traj);
+    const int n = K * TR_N;
+    for (int e0 = 0; e0 < n; e0 += 256) {
+        double v[4], base[4];
+        int dst[4];
+        bool act[4];
 #pragma unroll
-        for (int j = 0; j < NBD; ++j) v += sol[j] * tr[(1 + j) * TR_N];
-        const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
-        s.dr[(size_t)k * IT_N + off] += v;
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + 64 * q + lane;
+            const int ec = (e < n) ? e : 0;
+            const int k = ec / TR_N, i = ec - k * TR_N;
+            act[q] = (e < n) && !(k == K - 1 && i >= T_NU);
+            cgf64 *tr = traj + (size_t)k * NCH * TR_N + i;
+            const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
+            dst[q] = off * KP + k;
+            // starting value: -lam for the multiplier part of the first solve, the current direction when refining
+            const double cur = first ? it[dst[q]] : dr[dst[q]];
+            base[q] = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
+            double acc = tr[0];
+#pragma unroll
+            for (int j = 0; j < NBD; ++j) acc += sol[j] * tr[(1 + j) * TR_N];
+            v[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (act[q]) dr[dst[q]] = base[q] + v[q];
     }
-    if (lane == 0) { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
+    if (lane == 0) {
+        if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = -s.itg[G_LVT] + sd.sol[1]; }
+        else { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
+    }
     __syncthreads();
 }
 
@@ -1112,20 +1239,21 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
     const double dtf = s.drg[G_TF];
     for (int k = lane; k < K; k += 64) {
         cgf64 *nb = s.nb + (size_t)k * NB_N;
-        cgf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        const auto ns = s.nsn(k);
+        const auto p = s.itn(k), d = s.drn(k);
         gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
         double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             lt[i] = (k <= K - 2) ? p[I_LAM + i] + d[I_LAM + i] : 0.0;
-            ltm[i] = (k >= 1) ? (p - IT_N)[I_LAM + i] + (d - IT_N)[I_LAM + i] : 0.0;
+            ltm[i] = (k >= 1) ? p.node(-1)[I_LAM + i] + d.node(-1)[I_LAM + i] : 0.0;
         }
         double gx[7], gu[3];
         if (k >= 1) {
             const double *W = (k == K - 1) ? (const double *)sd.WxKsoft : (const double *)(nb + N_WX);   // LDS or HBM: generic
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                double acc = ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]) + ltm[i];
+                double acc = ((k == K - 1) ? sd.gxKsoft[i] : ns[NS_GX + i]) + ltm[i];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) acc += W[i * 7 + j] * d[I_X + j];
                 gx[i] = acc;
@@ -1140,13 +1268,13 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double acc = nb[N_GU + i];
+            double acc = ns[NS_GU + i];
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc += nb[N_WU + i * 3 + j] * d[I_U + j];
             gu[i] = acc;
         }
         if (k >= 1) {
-            cgf64 *Bp = s.Bp(k - 1);
+            const auto Bp = s.Bpt(k - 1);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double acc = 0.0;
@@ -1156,8 +1284,8 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             }
         }
         if (k <= K - 2) {
-            cgf64 *A = s.A(k), *Bn = s.Bn(k), *Bp = s.Bp(k), *Sg = s.Sig(k);
-            cgf64 *dn = d + IT_N;
+            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k);
+            const auto dn = d.node(1);
             if (k >= 1) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
@@ -1177,13 +1305,13 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             double sl = 0.0;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                rec[R_RHO + i] = nb[N_RHO + i] + nb[N_D + i] * d[I_NU + i] - lt[i];
+                rec[R_RHO + i] = ns[NS_RHO + i] + ns[NS_D + i] * d[I_NU + i] - lt[i];
                 double acc = dn[I_X + i] - Sg[i] * dtf - d[I_NU + i];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) acc -= A[i * 7 + j] * d[I_X + j];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc -= Bn[i * 3 + j] * d[I_U + j] + Bp[i * 3 + j] * dn[I_U + j];
-                rec[R_AFF + i] = -nb[N_E + i] - acc;
+                rec[R_AFF + i] = -ns[NS_E + i] - acc;
                 sl += Sg[i] * lt[i];
             }
             gtf_part -= sl;
@@ -1194,7 +1322,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
     }
     gtf_rhs = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
-    cgf64 *dK = s.dr + (size_t)(K - 1) * IT_N;
+    const auto dK = s.drn(K - 1);
     double av = 0.0;
     for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
     rvt_rhs = -sd.cv - av;
@@ -1217,97 +1345,136 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
 }
 
 // Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
-// themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).
+// themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).  Lane k writes node k's record.
 __device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
 {
     const int K = s.K;
-    for (int e = lane; e < K * 24; e += 64) {
-        const int k = e / 24, i = e - k * 24;
-        cgf64 *nb = s.nb + (size_t)k * NB_N;
-        double v;
-        if (i < 7) v = (k == 0) ? 0.0 : ((k == K - 1) ? sd.gxKsoft[i] : nb[N_GX + i]);
-        else if (i < 10) v = nb[N_GU + i - 7];
-        else if (i < 17) v = (k <= K - 2) ? nb[N_RHO + i - 10] : 0.0;
-        else v = (k <= K - 2) ? -nb[N_E + i - 17] : 0.0;
-        s.ch[(size_t)k * CH_N + C_RHS + i] = v;
-    }
     gtf_rhs = sd.gtf;
     rvt_rhs = -sd.cv;
     for (int t = 0; t < NTERM; ++t) gterm[t] = sd.tgh[t];
-    __syncthreads();
-    if (lane == 0) {
-        gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
-        for (int t = 0; t < NTERM; ++t) {
-            const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
+    for (int k = lane; k < K; k += 64) {
+        const auto ns = s.nsn(k);
+        gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
+        const bool dyn = (k <= K - 2);
+        double gx[7], gu[3], rho[7], e[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { gx[i] = ns[NS_GX + i]; rho[i] = ns[NS_RHO + i]; e[i] = ns[NS_E + i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i] = ns[NS_GU + i];
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) gx[i] = 0.0;
         }
-        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_rhs * sd.avt[i];
+        if (k == K - 1) {
+            // terminal node: soft gradient + capped share of the rank-1 gradient terms and the AL shift
+            for (int i = 0; i < 7; ++i) gx[i] = sd.gxKsoft[i];
+            for (int t = 0; t < NTERM; ++t) {
+                const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+                for (int i = 0; i < 7; ++i) gx[i] += gterm[t] * share * sd.ta[t][i];
+            }
+            for (int i = 0; i < 7; ++i) gx[i] -= sd.gam * rvt_rhs * sd.avt[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { rec[R_GX + i] = gx[i]; rec[R_RHO + i] = dyn ? rho[i] : 0.0; rec[R_AFF + i] = dyn ? -e[i] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
     }
     __syncthreads();
 }
 
 // dt, ds, dz by back-substitution ("Linear solve") and the fraction-to-the-boundary step.
-__device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
+__device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane, bool &finite)
 {
     const int K = s.K;
-    double amax = 1.0;
+    double amax = 1.0, bad = 0.0;
+#define CHK(v) { if (!(fabs(v) < 1e300)) bad = 1.0; }
+    const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
 #define LIM(v, dv) { const double v_ = (v), d_ = (dv); if (d_ < 0.0) amax = fmin(amax, -tau * v_ / d_); }
     for (int k = lane; k < K; k += 64) {
-        NodeVals n;
-        load_node(s, k, 0.0, n);
-        cgf64 *nb = s.nb + (size_t)k * NB_N;
-        gf64 *d = s.dr + (size_t)k * IT_N;
+        const auto p = s.itn(k), d = s.drn(k), ns = s.nsn(k);
+        const auto rb = s.rbn(k);
+        // chunk 0: the three ball pairs
+        double x[7], dx[7];
         {
-            const double g = n.u[0] * n.u[0] + n.u[1] * n.u[1] + n.u[2] * n.u[2] - sd.b_u;
-            const double sig = n.zu / n.su, zh = mu / n.su + sig * (g + n.su);
-            const double dg = 2.0 * (n.u[0] * d[I_U] + n.u[1] * d[I_U + 1] + n.u[2] * d[I_U + 2]);
-            d[I_SU] = -(g + n.su) - dg; d[I_ZU] = zh + sig * dg - n.zu;
-            LIM(n.su, d[I_SU]); LIM(n.zu, d[I_ZU]);
+            double u[3], du[3], bs[6];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; dx[i] = d[I_X + i]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; du[i] = d[I_U + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) CHK(dx[i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) CHK(du[i]);
+            const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+            double o[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            {
+                const double su = bs[0], zu = bs[1];
+                const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
+                const double sig = zu / su, zh = mu / su + sig * (g + su);
+                const double dg = 2.0 * (u[0] * du[0] + u[1] * du[1] + u[2] * du[2]);
+                o[0] = -(g + su) - dg; o[1] = zh + sig * dg - zu;
+                LIM(su, o[0]); LIM(zu, o[1]);
+            }
+            if (k >= 1) {
+                const double srmax = bs[2], zrmax = bs[3];
+                const double g = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax;
+                const double sig = zrmax / srmax, zh = mu / srmax + sig * (g + srmax);
+                const double dg = 2.0 * (x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2]);
+                o[2] = -(g + srmax) - dg; o[3] = zh + sig * dg - zrmax;
+                LIM(srmax, o[2]); LIM(zrmax, o[3]);
+            }
+            if (k >= 1 && k <= K - 2) {
+                const double srmin = bs[4], zrmin = bs[5];
+                const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
+                const double sig = zrmin / srmin, zh = mu / srmin + sig * (g + srmin);
+                const double dg = -(rb0 * dx[0] + rb1 * dx[1] + rb2 * dx[2]);
+                o[4] = -(g + srmin) - dg; o[5] = zh + sig * dg - zrmin;
+                LIM(srmin, o[4]); LIM(zrmin, o[5]);
+            }
+            // pairs a node does not own keep the zero the direction record was reset to
+            d[I_SU] = o[0]; d[I_ZU] = o[1];
+            if (k >= 1) { d[I_SRMAX] = o[2]; d[I_ZRMAX] = o[3]; }
+            if (k >= 1 && k <= K - 2) { d[I_SRMIN] = o[4]; d[I_ZRMIN] = o[5]; }
         }
-        if (k >= 1) {
-            const double g = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rmax;
-            const double sig = n.zrmax / n.srmax, zh = mu / n.srmax + sig * (g + n.srmax);
-            const double dg = 2.0 * (n.x[0] * d[I_X] + n.x[1] * d[I_X + 1] + n.x[2] * d[I_X + 2]);
-            d[I_SRMAX] = -(g + n.srmax) - dg; d[I_ZRMAX] = zh + sig * dg - n.zrmax;
-            LIM(n.srmax, d[I_SRMAX]); LIM(n.zrmax, d[I_ZRMAX]);
-        }
-        if (k >= 1 && k <= K - 2) {
-            cgf64 *rb = s.rbh + (size_t)k * 3;
-            const double g = -(rb[0] * n.x[0] + rb[1] * n.x[1] + rb[2] * n.x[2]) - sd.b_rmin;
-            const double sig = n.zrmin / n.srmin, zh = mu / n.srmin + sig * (g + n.srmin);
-            const double dg = -(rb[0] * d[I_X] + rb[1] * d[I_X + 1] + rb[2] * d[I_X + 2]);
-            d[I_SRMIN] = -(g + n.srmin) - dg; d[I_ZRMIN] = zh + sig * dg - n.zrmin;
-            LIM(n.srmin, d[I_SRMIN]); LIM(n.zrmin, d[I_ZRMIN]);
-        }
+        CHUNK_END
+        // chunks 1..7: component i of the eliminated t and of the two L1 slack pairs
         if (k <= K - 2) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                const double dnu = d[I_NU + i];
-                const double dt = (-nb[N_GT + i] - nb[N_BB + i] * dnu) / nb[N_AA + i];
-                d[I_T + i] = dt;
-                const double g1 = n.nu[i] - n.t[i], g2 = -n.nu[i] - n.t[i];
-                const double s1 = n.ztp[i] / n.stp[i], s2 = n.ztn[i] / n.stn[i];
-                const double zh1 = mu / n.stp[i] + s1 * (g1 + n.stp[i]), zh2 = mu / n.stn[i] + s2 * (g2 + n.stn[i]);
+                const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
+                const double stn = p[I_STN + i], ztn = p[I_ZTN + i], dnu = d[I_NU + i], dlam = d[I_LAM + i];
+                const double gt = ns[NS_GT + i], bb = ns[NS_BB + i], aa = ns[NS_AA + i];
+                const double dt = (-gt - bb * dnu) / aa;
+                CHK(dnu); CHK(dlam); CHK(dt);
+                const double g1 = nu - tt, g2 = -nu - tt;
+                const double s1 = ztp / stp, s2 = ztn / stn;
+                const double zh1 = mu / stp + s1 * (g1 + stp), zh2 = mu / stn + s2 * (g2 + stn);
                 const double dg1 = dnu - dt, dg2 = -dnu - dt;
-                d[I_STP + i] = -(g1 + n.stp[i]) - dg1; d[I_ZTP + i] = zh1 + s1 * dg1 - n.ztp[i];
-                d[I_STN + i] = -(g2 + n.stn[i]) - dg2; d[I_ZTN + i] = zh2 + s2 * dg2 - n.ztn[i];
-                LIM(n.stp[i], d[I_STP + i]); LIM(n.ztp[i], d[I_ZTP + i]);
-                LIM(n.stn[i], d[I_STN + i]); LIM(n.ztn[i], d[I_ZTN + i]);
+                const double dstp = -(g1 + stp) - dg1, dztp = zh1 + s1 * dg1 - ztp;
+                const double dstn = -(g2 + stn) - dg2, dztn = zh2 + s2 * dg2 - ztn;
+                LIM(stp, dstp); LIM(ztp, dztp);
+                LIM(stn, dstn); LIM(ztn, dztn);
+                d[I_T + i] = dt;
+                d[I_STP + i] = dstp; d[I_ZTP + i] = dztp;
+                d[I_STN + i] = dstn; d[I_ZTN + i] = dztn;
+                CHUNK_END
             }
         }
         if (k == K - 1) {
             for (int j = 0; j < 6; ++j) {
                 double gj = -sd.bT[j], dg = 0.0;
-                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * n.x[i]; dg += sd.aT[j][i] * d[I_X + i]; }
+                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; dg += sd.aT[j][i] * dx[i]; }
                 const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
                 const double sig = zj / sj, zh = mu / sj + sig * (gj + sj);
                 s.drg[G_STERM + j] = -(gj + sj) - dg; s.drg[G_ZTERM + j] = zh + sig * dg - zj;
                 LIM(sj, s.drg[G_STERM + j]); LIM(zj, s.drg[G_ZTERM + j]);
             }
             const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
-            const double g = n.x[0] * n.x[0] + n.x[1] * n.x[1] + n.x[2] * n.x[2] - sd.b_rfmax;
+            const double g = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
             const double sig = zrf / srf, zh = mu / srf + sig * (g + srf);
-            const double dg = 2.0 * (n.x[0] * d[I_X] + n.x[1] * d[I_X + 1] + n.x[2] * d[I_X + 2]);
+            const double dg = 2.0 * (x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2]);
             s.drg[G_SRF] = -(g + srf) - dg; s.drg[G_ZRF] = zh + sig * dg - zrf;
             LIM(srf, s.drg[G_SRF]); LIM(zrf, s.drg[G_ZRF]);
         }
@@ -1322,8 +1489,11 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             LIM(sj, s.drg[G_STF + j]); LIM(zj, s.drg[G_ZTF + j]);
         }
     }
+    if (!(fabs(s.drg[G_TF]) < 1e300)) bad = 1.0;
 #undef LIM
+#undef CHK
     amax = wave_min(amax);
+    finite = (wave_max(bad) == 0.0);
     __syncthreads();
     return amax;
 }
@@ -1334,28 +1504,53 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
     const int K = s.K;
 #define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
                              z_ = fmax(fmin(z_, kKappaSigma * mu / s_), mu / (kKappaSigma * s_)); (sv) = s_; (zv) = z_; }
+    const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     for (int k = lane; k < K; k += 64) {
-        gf64 *p = s.it + (size_t)k * IT_N;
-        cgf64 *d = s.dr + (size_t)k * IT_N;
-        for (int i = 0; i < IT_N - 1; ++i) p[i] += a * d[i];
-        cgf64 *x = p + I_X, *u = p + I_U;
-        SAFE(p[I_SU], p[I_ZU], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u);
-        if (k >= 1) SAFE(p[I_SRMAX], p[I_ZRMAX], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rmax);
-        if (k >= 1 && k <= K - 2) {
-            cgf64 *rb = s.rbh + (size_t)k * 3;
-            SAFE(p[I_SRMIN], p[I_ZRMIN], -(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin);
+        const auto p = s.itn(k), d = s.drn(k);
+        const auto rb = s.rbn(k);
+        // chunk 0: x, u and the three ball pairs
+        {
+            double v[16], dv[16];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { v[i] = p[I_X + i]; dv[i] = d[I_X + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { v[10 + i] = p[I_SU + i]; dv[10 + i] = d[I_SU + i]; }
+            const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += a * dv[i];
+            const double *x = v, *u = v + 7;
+            SAFE(v[10], v[11], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u);
+            if (k >= 1) SAFE(v[12], v[13], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax);
+            if (k >= 1 && k <= K - 2) SAFE(v[14], v[15], -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) p[I_X + i] = v[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p[I_SU + i] = v[10 + i];
         }
-        if (k <= K - 2) {
-            for (int i = 0; i < 7; ++i) {
-                SAFE(p[I_STP + i], p[I_ZTP + i], p[I_NU + i] - p[I_T + i]);
-                SAFE(p[I_STN + i], p[I_ZTN + i], -p[I_NU + i] - p[I_T + i]);
+        CHUNK_END
+        // chunks 1..7: component i of nu, t, lam and of the two L1 slack pairs
+        const bool dyn = (k <= K - 2);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int off[7] = {I_NU + i, I_T + i, I_LAM + i, I_STP + i, I_ZTP + i, I_STN + i, I_ZTN + i};
+            double v[7], dv[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { v[q] = p[off[q]]; dv[q] = d[off[q]]; }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) v[q] += a * dv[q];
+            if (dyn) {
+                SAFE(v[3], v[4], v[0] - v[1]);
+                SAFE(v[5], v[6], -v[0] - v[1]);
             }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) p[off[q]] = v[q];
+            CHUNK_END
         }
     }
     __syncthreads();
     if (lane == 0) {
         for (int i = 0; i < GL_N; ++i) s.itg[i] += a * s.drg[i];
-        cgf64 *x = s.it + (size_t)(K - 1) * IT_N + I_X;
+        const auto x = s.itn(K - 1) + I_X;
         for (int j = 0; j < 6; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
@@ -1405,16 +1600,20 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
     s.stage = (cgf64 *)a.stage + (size_t)sat * (K - 1) * MPCX_STAGE_DOUBLES;
     s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * K;
     s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * K;
+    const int KP = padded_nodes(K);
+    s.KP = KP;
     gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
-    s.it = ws; ws += (size_t)K * IT_N;
-    s.dr = ws; ws += (size_t)K * IT_N;
+    s.it = ws; ws += (size_t)KP * IT_N;
+    s.dr = ws; ws += (size_t)KP * IT_N;
+    s.nbs = ws; ws += (size_t)KP * NS_N;
+    s.stT = ws; ws += (size_t)KP * MPCX_STAGE_DOUBLES;
+    s.rbh = ws; ws += (size_t)KP * 3;
     s.nb = ws; ws += (size_t)K * NB_N;
     s.fac = ws; ws += (size_t)K * FAC_N;
     s.ch = ws; ws += (size_t)K * CH_N;
     s.traj = ws; ws += (size_t)K * NCH * TR_N;
     s.itg = ws; ws += GL_N;
-    s.drg = ws; ws += GL_N;
-    s.rbh = ws;
+    s.drg = ws;
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
@@ -1428,14 +1627,19 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
 #endif
     }
     __syncthreads();
+    // field-major copy of the stage records for the node-parallel phases (read every iteration, written once)
+    for (int k = 0; k < K - 1; ++k) {
+        cgf64 *rec = s.A(k);
+        for (int e = lane; e < MPCX_STAGE_DOUBLES; e += 64) s.stT[e * KP + k] = rec[e];
+    }
     for (int k = lane; k < K; k += 64) {
         double x[7], u[3];
         for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * K + k];
         for (int i = 0; i < 3; ++i) u[i] = s.ubar[(size_t)i * K + k];
         const double rn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-        gf64 *rb = s.rbh + (size_t)k * 3;
+        const auto rb = s.rbn(k);
         for (int i = 0; i < 3; ++i) rb[i] = x[i] / rn;           // optimizer.py:129-130
-        gf64 *p = s.it + (size_t)k * IT_N, *d = s.dr + (size_t)k * IT_N;
+        const auto p = s.itn(k), d = s.drn(k);
         for (int i = 0; i < IT_N; ++i) { p[i] = 0.0; d[i] = 0.0; }
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
@@ -1493,7 +1697,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         }
         // Newton direction, with Hessian regularisation retries on breakdown
         bool have_dir = false;
-        double delta_w = 0.0;
+        double delta_w = 0.0, alpha = 1.0;
+        const double tau = fmax(0.99, 1.0 - mu);
         for (int trial = 0; trial < 10 && !have_dir; ++trial) {
             PT_BEGIN
             newton_blocks(s, sd, mu, delta_w, lane);
@@ -1506,15 +1711,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             bool ok = riccati_factor(s, sd, w, lane, true);          // factorisation + backward sweep of all 8 channels
             PT_END(2)
             if (ok) {
-                // direction := (0, ..., -lam, -lam_vt) so that the first residual carries no multipliers
-                for (int k = lane; k < K; k += 64) {
-                    gf64 *d = s.dr + (size_t)k * IT_N;
-                    cgf64 *p = s.it + (size_t)k * IT_N;
-                    for (int i = 0; i < IT_N; ++i) d[i] = 0.0;
-                    if (k <= K - 2) for (int i = 0; i < 7; ++i) d[I_LAM + i] = -p[I_LAM + i];
-                }
-                if (lane == 0) { for (int i = 0; i < GL_N; ++i) s.drg[i] = 0.0; s.drg[G_LVT] = -s.itg[G_LVT]; }
-                __syncthreads();
+                // the direction starts from (0, ..., -lam, -lam_vt) so that the first right-hand side carries no
+                // multipliers; combine_channels writes it with that starting value (no separate reset pass)
                 // iterative refinement only once a terminal barrier weight is stiff enough to cost digits
                 double twmax = 0.0;
                 for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
@@ -1543,28 +1741,20 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
                     if (!ok) break;
                     PT_BEGIN
                     border_solve(sd, gtf_rhs, rvt_rhs, gex, lane);
-                    combine_channels(s, sd, lane);
+                    combine_channels(s, sd, lane, pass == 0);
                     PT_END(7)
                 }
             }
             if (ok) {
-                // finite check on the direction
-                double bad = 0.0;
-                for (int k = lane; k < K; k += 64) {
-                    cgf64 *d = s.dr + (size_t)k * IT_N;
-                    for (int i = 0; i < I_STP; ++i) if (!(fabs(d[i]) < 1e300)) bad = 1.0;
-                }
-                if (!(fabs(s.drg[G_TF]) < 1e300)) bad = 1.0;
-                ok = (wave_max(bad) == 0.0);
+                // dt, ds, dz, the fraction-to-the-boundary step and the finite check on the direction
+                PT_BEGIN
+                alpha = finish_direction(s, sd, mu, tau, lane, ok);
+                PT_END(8)
             }
             if (ok) have_dir = true;
             else delta_w = (delta_w == 0.0) ? 1e-4 : delta_w * 10.0;
         }
         if (!have_dir) { status = MPCX_ST_NUMERIC; break; }
-        const double tau = fmax(0.99, 1.0 - mu);
-        PT_BEGIN
-        double alpha = finish_direction(s, sd, mu, tau, lane);
-        PT_END(8)
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
         const double rn0 = sqrt(r0.sq);
         const int nzc = n_ineq(K);
@@ -1585,7 +1775,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
 
     // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----
     for (int k = lane; k < K; k += 64) {
-        cgf64 *p = s.it + (size_t)k * IT_N;
+        const auto p = s.itn(k);
         for (int i = 0; i < 7; ++i) {
             a.X[(size_t)sat * 7 * K + (size_t)i * K + k] = p[I_X + i];
             a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
