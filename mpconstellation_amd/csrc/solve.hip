@@ -39,7 +39,7 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-3, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -685,8 +685,10 @@ struct StageOps {          // operands of one node, double-buffered in LDS
 constexpr int OPS_IN = 156;
 
 struct Scratch {   // LDS working set of the recursion
-    StageOps ops[2];
-    double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
+    union {                        // the factorisation and the stand-alone sweeps never run at the same time
+        StageOps ops[2];
+        double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
+    };
     double Pn[49], WlLi[98], PtA[49], Qyy[49];
     double PtBh[21], WxBp[21], Quy[21];
     double Quu[9];
@@ -1177,9 +1179,14 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
                 sd.Mb[1 + i][c - 1] = acc;
             }
         }
+        // row t reads wex (a.dx) - zeta = gex: divided by wex its entries stay O(1) however stiff the barrier term is
+        // (an LU with partial pivoting on the unscaled rows would pick its pivots by the 1e10-sized entries)
         for (int t = 0; t < NTERM; ++t) {
-            for (int j = 0; j < NBD; ++j) sd.Mb[2 + t][j] *= wex[t];
-            sd.Mb[2 + t][2 + t] -= 1.0;
+            if (wex[t] > 1.0) sd.Mb[2 + t][2 + t] -= 1.0 / wex[t];
+            else {
+                for (int j = 0; j < NBD; ++j) sd.Mb[2 + t][j] *= wex[t];
+                sd.Mb[2 + t][2 + t] -= 1.0;
+            }
         }
         int ok = 1;
         for (int p = 0; p < NBD; ++p) {
@@ -1213,7 +1220,10 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
             rb[1 + i] = -acc;
         }
         rb[1] += rvt_rhs;
-        for (int t = 0; t < NTERM; ++t) rb[2 + t] = rb[2 + t] * (sd.tw[t] - sd.twin[t]) - gex[t];
+        for (int t = 0; t < NTERM; ++t) {
+            const double wex = sd.tw[t] - sd.twin[t];
+            rb[2 + t] = (wex > 1.0) ? rb[2 + t] - gex[t] / wex : rb[2 + t] * wex - gex[t];
+        }
         // all row interchanges first (the stored multipliers are in final row order), then L, then U
         for (int p = 0; p < NBD; ++p) {
             const int piv = sd.piv[p];
@@ -1669,7 +1679,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
     }
     __syncthreads();
 
-    double mu = kMuInit;
+    double mu = kMuInit, dw_last = 0.0;
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
     for (int iter = 0;; ++iter) {
@@ -1698,8 +1708,13 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
         // Newton direction, with Hessian regularisation retries on breakdown
         bool have_dir = false;
         double delta_w = 0.0, alpha = 1.0;
+#ifdef MPCX_ITER_LOG
+        int fail_mask = 0;     // decimal digits: factor, border, finite-check failures of this iteration
+#endif
         const double tau = fmax(0.99, 1.0 - mu);
-        for (int trial = 0; trial < 10 && !have_dir; ++trial) {
+        // Hessian regularisation on breakdown follows ipopt's inertia-correction schedule: 0 first, then a third of
+        // the last value that worked (1e-4 the first time), growing by 8 (by 100 until some value has worked), up to 1e40
+        while (!have_dir && delta_w <= kDwMax) {
             PT_BEGIN
             newton_blocks(s, sd, mu, delta_w, lane);
             PT_END(1)
@@ -1710,6 +1725,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             PT_BEGIN
             bool ok = riccati_factor(s, sd, w, lane, true);          // factorisation + backward sweep of all 8 channels
             PT_END(2)
+#ifdef MPCX_ITER_LOG
+            if (!ok) fail_mask += 1;
+#endif
             if (ok) {
                 // the direction starts from (0, ..., -lam, -lam_vt) so that the first right-hand side carries no
                 // multipliers; combine_channels writes it with that starting value (no separate reset pass)
@@ -1738,9 +1756,26 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
                     sweep_forward(s, sd, w, 0, c1, lane);
                     if (pass == 0) ok = border_factor(sd, lane);
                     PT_END(4)
+#ifdef MPCX_ITER_LOG
+                    if (!ok) fail_mask += 100;
+#endif
                     if (!ok) break;
                     PT_BEGIN
                     border_solve(sd, gtf_rhs, rvt_rhs, gex, lane);
+#if defined(MPCX_ITER_LOG) && defined(MPCX_LOG_IT)
+                    // diagnostic build only: the border system of one chosen iteration into this satellite's NU block
+                    if (iter == MPCX_LOG_IT && pass == 0 && lane == 0) {
+                        double *lg = a.NU + (size_t)sat * 7 * K; int n = 0;
+                        for (int j = 0; j < NBD; ++j) lg[n++] = sd.sol[j];
+                        for (int j = 0; j < NTERM; ++j) lg[n++] = sd.tw[j];
+                        for (int j = 0; j < NTERM; ++j) lg[n++] = sd.twin[j];
+                        for (int j = 0; j < NCH; ++j) lg[n++] = sd.siglam[j];
+                        for (int c = 0; c < NCH; ++c) for (int j = 0; j < 7; ++j) lg[n++] = sd.xK[c][j];
+                        lg[n++] = gtf_rhs; lg[n++] = rvt_rhs;
+                        for (int j = 0; j < NTERM; ++j) lg[n++] = gterm[j];
+                        lg[n++] = sd.Wtf; lg[n++] = sd.gam; lg[n++] = delta_w;
+                    }
+#endif
                     combine_channels(s, sd, lane, pass == 0);
                     PT_END(7)
                 }
@@ -1750,15 +1785,26 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
                 PT_BEGIN
                 alpha = finish_direction(s, sd, mu, tau, lane, ok);
                 PT_END(8)
+#ifdef MPCX_ITER_LOG
+                if (!ok) fail_mask += 10000;
+#endif
             }
             if (ok) have_dir = true;
-            else delta_w = (delta_w == 0.0) ? 1e-4 : delta_w * 10.0;
+            else if (delta_w == 0.0) delta_w = (dw_last == 0.0) ? kDwFirst : fmax(kDwMin, dw_last / 3.0);
+            else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
         }
-        if (!have_dir) { status = MPCX_ST_NUMERIC; break; }
+        if (have_dir && delta_w > 0.0) dw_last = delta_w;
+        if (!have_dir) {
+#ifdef MPCX_ITER_LOG
+            if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = -1.0; lg[3] = delta_w; lg[4] = (double)fail_mask; }
+#endif
+            status = MPCX_ST_NUMERIC; break;
+        }
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
         const double rn0 = sqrt(r0.sq);
         const int nzc = n_ineq(K);
         for (int ls = 0; ls < 30; ++ls) {
+            if (0.5 * alpha < kAlphaFloor) break;      // a rejection could not shorten the step any more: take it
             ResAcc rt;
             PT_BEGIN
             eval_residual(s, sd, alpha, mu, lane, rt);
@@ -1768,6 +1814,10 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             if (dec && cen) break;
             alpha *= 0.5;
         }
+#ifdef MPCX_ITER_LOG
+        // diagnostic build only: iteration log (mu, E0, accepted step, regularisation) into this satellite's X block
+        if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
+#endif
         PT_BEGIN
         apply_step(s, sd, alpha, mu, lane);
         PT_END(9)
@@ -1777,8 +1827,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
     for (int k = lane; k < K; k += 64) {
         const auto p = s.itn(k);
         for (int i = 0; i < 7; ++i) {
+#ifndef MPCX_ITER_LOG
             a.X[(size_t)sat * 7 * K + (size_t)i * K + k] = p[I_X + i];
+#endif
+#if !(defined(MPCX_ITER_LOG) && defined(MPCX_LOG_IT))
             a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
+#endif
         }
         for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * K + (size_t)i * K + k] = p[I_U + i];
     }

@@ -33,7 +33,12 @@ Deliberate differences from ipopt's path (none changes the NLP or its KKT points
   with h = r x v; it is imposed as |v|^2 - (r.v)^2/|r|^2 - vt_des^2 = 0, which has the same zero set
   for h != 0, r != 0 (see vt_poly / vt_reduced below and the test that compares them).
 * globalisation: backtracking on the 2-norm of the perturbed KKT residual with one step length for
-  primal and dual variables plus a N_-inf(1e-3) centrality neighbourhood, instead of ipopt's filter.
+  primal and dual variables plus a N_-inf(1e-8) centrality neighbourhood, instead of ipopt's filter.  The
+  backtracking stops once the next trial would fall below ALPHA_FLOOR = 0.25 and that last trial is taken even
+  if it fails the decrease test (a strict merit rejects too many good steps of this non-convex problem: on 1024
+  satellites of the benchmark constellation the floor and the loose neighbourhood cut the mean iteration count
+  32.7 -> 21.6 and the maximum 48 -> 30 with every problem still converging; with no line search at all the
+  K = 60, tf = 2 fixture breaks down).
 * kappa_Sigma = 100 instead of ipopt's 1e10: with one step length for primal and dual variables a loose
   safeguard lets (s_i, z_i) pairs jam against the boundary (1 of the 64 benchmark satellites stalled at mu = 0.1);
   re-centring the multipliers after every step removed every stall and cut the mean iteration count 46 -> 41.
@@ -50,7 +55,9 @@ ST_OK, ST_MAXITER, ST_NUMERIC, ST_ACCEPTABLE = 0, 5, 6, 7
 BOUND_RELAX = 1e-8
 BOUND_PUSH = 1e-2
 KAPPA_SIGMA = 100.0
-GAMMA_NBHD = 1e-3
+GAMMA_NBHD = 1e-8
+DW_FIRST, DW_MIN, DW_MAX = 1e-4, 1e-20, 1e40     # ipopt first_hessian_perturbation, min_/max_hessian_perturbation
+ALPHA_FLOOR = 0.25    # backtracking never takes the step below this (unless the fraction to the boundary does)
 MU_INIT = 1.0
 KAPPA_EPS, KAPPA_MU, THETA_MU = 10.0, 0.2, 1.5     # ipopt barrier_tol_factor, mu_linear_decrease_factor, mu_superlinear_decrease_power
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
@@ -369,8 +376,13 @@ def riccati_solve(P, nb, F, rhs):
         rb[1 + i] = -(a @ chans[0][0][:, K - 1])
     rb[1] += rhs["rvt"]
     for j in range(N_TERM):
-        Mb[2 + j, :] *= wex[j]; rb[2 + j] *= wex[j]
-        Mb[2 + j, 2 + j] -= 1.0; rb[2 + j] -= gex[j]
+        if wex[j] > 1.0:
+            # row j reads wex (a.dx) - zeta = gex: divided by wex its entries stay O(1) however stiff the barrier
+            # term is (an LU with partial pivoting on the unscaled rows picks pivots by the 1e10-sized entries)
+            Mb[2 + j, 2 + j] -= 1.0 / wex[j]; rb[2 + j] -= gex[j] / wex[j]
+        else:
+            Mb[2 + j, :] *= wex[j]; rb[2 + j] *= wex[j]
+            Mb[2 + j, 2 + j] -= 1.0; rb[2 + j] -= gex[j]
     sol = np.linalg.solve(Mb, rb)
     comb = lambda i: chans[0][i] + sum(sol[c - 1] * chans[c][i] for c in range(1, 1 + nbd))
     return dict(X=comb(0), U=comb(1), NU=comb(2), lam=comb(3), tf=sol[0], lam_vt=sol[1])
@@ -494,10 +506,12 @@ def step(it, d, a):
 
 def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_refine=1, dense=False,
           verbose=False):
-    """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective)."""
+    """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective, n_regularised = number of
+    iterations whose factorisation broke down and needed delta_w > 0, first_regularised = index of the first, -1 if none)."""
     it = initial_iterate(P)
     mu = MU_INIT
     n_acc = 0; status = ST_MAXITER; k_it = 0
+    dw_last = 0.0; n_reg = 0; first_reg = -1
     for k_it in range(max_iter + 1):
         E0 = optimality_error(P, it, 0.0)[0]
         if verbose: print(f"it {k_it:3d} mu {mu:.1e} E0 {E0:.2e} tf {it.tf:.8f}")
@@ -508,16 +522,24 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         if k_it == max_iter: status = ST_ACCEPTABLE if E0 <= acceptable_tol else ST_MAXITER; break
         while optimality_error(P, it, mu)[0] <= KAPPA_EPS * mu and mu > tol / 10:
             mu = max(tol / 10, min(KAPPA_MU * mu, mu ** THETA_MU))
+        # Hessian regularisation on breakdown: ipopt's inertia-correction schedule (Waechter & Biegler 2006, Alg. IC):
+        # delta_w = 0 first, then a third of the last successful value (1e-4 the first time), growing by 8
+        # (by 100 until some value has worked), giving up above 1e40
         d = None; dw = 0.0
-        for trial in range(10):
+        while True:
             try:
                 d = newton_direction_dense(P, it, mu, dw) if dense else newton_direction(P, it, mu, dw, n_refine if dw == 0 else 0)
                 if all(np.isfinite(d[k]).all() for k in ("X", "U", "NU")) and np.isfinite(d["tf"]): break
                 d = None
             except np.linalg.LinAlgError:
                 d = None
-            dw = 1e-4 if dw == 0.0 else dw * 10
+            if dw == 0.0: dw = DW_FIRST if dw_last == 0.0 else max(DW_MIN, dw_last / 3.0)
+            else: dw *= 100.0 if dw_last == 0.0 else 8.0
+            if dw > DW_MAX: break
         if d is None: status = ST_NUMERIC; break
+        if dw > 0.0:
+            dw_last = dw; n_reg += 1
+            if first_reg < 0: first_reg = k_it
         tau = max(0.99, 1 - mu)
         a = 1.0
         for v, dv in ((it.s, d["s"]), (it.z, d["z"])):
@@ -526,11 +548,13 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
                 if neg.any(): a = min(a, (-tau * v[k][neg] / dv[k][neg]).min())
         r0 = residual_norm(P, it, mu)
         for ls in range(30):
+            if 0.5 * a < ALPHA_FLOOR: break            # a rejection could not shorten the step any more: take it
             n = step(it, d, a)
             prod = np.concatenate([(n.s[k] * n.z[k]).ravel() for k in n.s])
             if residual_norm(P, n, mu) <= (1 - 1e-4 * a) * r0 and prod.min() >= GAMMA_NBHD * min(mu, prod.mean()):
                 break
             a *= 0.5
+        if verbose: print(f"       step {a:.4f} delta_w {dw:.1e}")
         it = step(it, d, a)
         g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
         for k in it.s:
@@ -539,5 +563,5 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
     T = np.zeros((7, K)); T[:, :K - 1] = it.T
-    return dict(X=it.X, U=it.U, NU=NU, T=T, tf=it.tf, status=status, iters=k_it,
+    return dict(X=it.X, U=it.U, NU=NU, T=T, tf=it.tf, status=status, iters=k_it, n_regularised=n_reg, first_regularised=first_reg,
                 kkt=optimality_error(P, it, 0.0)[0], objective=P.objective(it.X, it.U, it.T, it.tf), iterate=it)

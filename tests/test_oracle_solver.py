@@ -72,7 +72,8 @@ def test_structured_solve_equals_dense(golden_dir):
         assert abs(a["tf"] - b["tf"]) <= 1e-7 * max(1.0, abs(b["tf"]))
     full = N.solve(P); dense = N.solve(P, dense=True)
     assert full["status"] == dense["status"] == 0
-    assert np.abs(full["X"] - dense["X"]).max() < 1e-9 and abs(full["tf"] - dense["tf"]) < 1e-9
+    # same iteration path, two linear solvers: rounding-level differences of the directions, amplified by the flat objective
+    assert np.abs(full["X"] - dense["X"]).max() < 1e-8 and abs(full["tf"] - dense["tf"]) < 1e-8
 
 
 def test_against_scipy_trust_constr(golden_dir):
@@ -94,5 +95,6 @@ def test_status_codes(golden_dir):
     P = problem(golden_dir, "tan_K20_tf2")
     r = N.solve(P, max_iter=4)
     assert r["status"] == N.ST_MAXITER and r["iters"] == 4
-    r = N.solve(P, tol=1e-15, acceptable_tol=1e-6, max_iter=120)      # below what fp64 reaches: stops at the acceptable level
+    # a tolerance fp64 does not reach: three consecutive iterates at the acceptable level end the run
+    r = N.solve(P, tol=1e-12, acceptable_tol=1e-6, acceptable_iter=3, max_iter=120)
     assert r["status"] == N.ST_ACCEPTABLE and r["kkt"] <= 1e-6
