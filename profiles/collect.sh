@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/<round>/ (run on the GPU box from the repo root):
+#   1. kernel trace + stats per workload (kernel durations the bench line's roofline.achieved must agree with)
+#   2. FETCH_SIZE and WRITE_SIZE in separate counter passes (TCC slots do not hold both), kernel trace only
+# Raw output goes to gpurun_out/prof/<round>/ ; profiles/summarize.py turns it into the committed summaries.
+set -e
+ROUND=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof/$ROUND
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for W in S64_K30 S4096_K30 S4096_K100_scp2; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W/stats" -o stats -- \
+    python3 "$REPO/bench.py" --workload $W --steps 5 --warmup 2 --no-also --no-cpu-baseline > "$OUT/$W.bench.log" 2>&1
+  echo "stats $W done"
+done
+for W in S64_K30 S4096_K30; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$W/$C" -o pmc -- \
+      python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --no-also --no-cpu-baseline > "$OUT/$W.$C.log" 2>&1
+    echo "pmc $C $W done"
+  done
+done
