@@ -23,6 +23,8 @@ WORKLOADS = {            # BASELINE.json configs: name -> (satellites per GPU, n
     "S4096_K100_scp2": (4096, 100, 2), # configs[3]: 2 SCP iterations with nonlinear re-rollout (control.py:166,183-227)
     "S8192_K30": (8192, 30, 1),        # configs[4] per GPU (65,536 over 8)
 }
+F64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak
+FLOP_PER_NODE_ITER = 18e3       # factorisation 8.7k + 8-channel sweeps 7k + node-parallel phases 2.4k
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table
 
 
@@ -174,6 +176,7 @@ def main():
         value = S_total * args.steps / elapsed
         B = algorithmic_bytes(K)
         achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
+        flops = FLOP_PER_NODE_ITER * K * float(iters.sum())   # of the last solve_kernel launch on this rank
         traffic = measured_traffic(args.workload)
         out = {
             "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve per SCP iteration)",
@@ -187,7 +190,11 @@ def main():
                          "kernel_ms": solve_ms,
                          "note": "algorithmic bytes = 8(27K+7)+8 per satellite per launch; duration = HIP events around solve_kernel on its "
                                  "launch stream; traffic = FETCH_SIZE+WRITE_SIZE of profiles/ (workspace re-reads: the kernel is "
-                                 "latency / fp64-VALU bound at 64 satellites and workspace-traffic bound at 4096, not algorithmic-HBM bound)"},
+                                 "bound by the latency / issue rate of one wave per satellite, not by algorithmic HBM bytes)",
+                         # what actually limits the kernel: fp64 vector arithmetic of ~18 kflop per node and interior-point
+                         # iteration against the 78.6 TFLOP/s fp64 vector peak
+                         "valu_f64": {"achieved": flops / (solve_ms * 1e-3) / 1e12, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": flops / (solve_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}},
             "solver": {"converged": int(stats[0].item()), "of": int(stats[1].item()),
                        "ipm_iterations_mean": float(iters.mean()), "ipm_iterations_max": int(iters.max()),
                        "kkt_max": float(kkt.max())},

@@ -690,6 +690,7 @@ struct Scratch {   // LDS working set of the recursion
         double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
     };
     double Pn[49], WlLi[98], PtA[49], Qyy[49];
+    double sink[64];               // target of the lanes that have nothing to write in a branch-free phase
     double PtBh[21], WxBp[21], Quy[21];
     double Quu[9];
 };
@@ -768,9 +769,47 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     const int sc = lane >> 3, sr = lane & 7;
     const bool sact = fuse_sweep && sr < 7;
     const int srr = (sr < 7) ? sr : 6, sr3 = (sr < 3) ? sr : 2;
-    ChanIn cur = chan_inputs(s, sd, K - 1, sc, sr, sact);
-    ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
+    // The fused backward sweep runs one node behind the factorisation: node k+1's sweep sits in the same straight-line
+    // block as node k's LDL^T chain, so that the two dependent chains fill each other's latency gaps.
+    ChanIn cur{0.0, 0.0, 0.0, 0.0};           // inputs of the node swept in this iteration (k+1)
+    ChanRaw nraw{0.0, 0.0, 0.0, 0.0};         // raw inputs of node k, in flight during iteration k
     double pnext = 0.0;
+    // one node of the sweep: t = p+ - G(rho + p+) + Pt aff ; qu = gu + Bpm^T gx + Bh^T t ; p = gx + A^T t - Kg^T qu
+    // (written in three pieces so that the first matrix-vector product can be spread over the pivots of the LDL^T)
+    double sw_G[7], sw_Pt[7], sw_v = 0.0, sw_t = 0.0;
+    auto sweep_begin = [&](const StageOps &o) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { sw_G[q] = o.G[srr * 7 + q]; sw_Pt[q] = o.Pt[srr * 7 + q]; }
+        sw_v = cur.rho + pnext; sw_t = pnext;
+    };
+    auto sweep_col = [&](int q) { sw_t += -sw_G[q] * __shfl(sw_v, q, 8) + sw_Pt[q] * __shfl(cur.aff, q, 8); };
+    auto sweep_finish = [&](const StageOps &o, int j, double &pp, double &qu) {
+        const bool dynj = (j <= K - 2);
+        double Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { Acol[q] = o.A[q * 7 + srr]; Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.Bh[q * 3 + sr3]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + srr];
+        double tt = sw_t;
+        if (!dynj || !sact) tt = 0.0;
+        qu = cur.gu;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(tt, q, 8);
+        if (sr >= 3 || !sact) qu = 0.0;
+        pp = cur.gx;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) pp += Acol[q] * __shfl(tt, q, 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
+    };
+    auto sweep_store = [&](int j, double pp, double qu) {
+        if (sact) {
+            gf64 *ch = s.ch + (size_t)j * CH_N;
+            ch[C_P + sc * 7 + sr] = pp;
+            if (sr < 3) ch[C_QU + sc * 3 + sr] = qu;
+            pnext = pp;
+        }
+    };
     // operand prefetch: node k's (A, Bn | Bpm | Wx, Wu, D) -> registers -> LDS buffer.  Three branch-free loads per
     // lane: A, Bn are the head of stage record k, Bpm = B_kp of record k-1 (same offset), Wx|Wu|D the head of the
     // Newton-block record; what node k does not have (no dynamics at K-1, no Bpm at 0) is zeroed when stashed.
@@ -797,22 +836,26 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     __syncthreads();
     const int mi = lane / 7, mj = lane - 7 * mi;
     const int xc = (lane < 7) ? lane : 6;                 // column of [Pn | I] this lane substitutes (lanes 0..13)
+    // P1 roles: lanes 0..20 element e of Bh = A Bpm + Bn, lanes 32..52 element e of WxBp = Wx Bpm, one common body
+    const bool p1_bh = lane < 21, p1_wx = lane >= 32 && lane < 53;
+    const int p1_e = p1_wx ? lane - 32 : (p1_bh ? lane : 0), p1_i = p1_e / 3, p1_j = p1_e - 3 * p1_i;
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
         gf64 *fac = s.fac + (size_t)k * FAC_N;
         FT_DECL
-        if (k >= 1) { fetch(k - 1); if (fuse_sweep) nraw = chan_fetch(s, k - 1, sc, srr, sr3); }
+        if (k >= 1) fetch(k - 1);
         const bool dyn = (k <= K - 2);
+        if (fuse_sweep && dyn) nraw = chan_fetch(s, k, sc, srr, sr3);
         FT_MARK(0)
         // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm
-        if (lane < 21) {
-            const int i = lane / 3, j = lane - 3 * i;
-            o.Bh[lane] = dyn ? o.Bn[lane] + dotN<7>(o.A + i * 7, 1, o.Bpm + j, 3) : 0.0;
-        } else if (lane >= 32 && lane < 53) {
-            const int e = lane - 32, i = e / 3, j = e - 3 * i;
-            w.WxBp[e] = dotN<7>(o.Wx + i * 7, 1, o.Bpm + j, 3);
+        {
+            const double dot = dotN<7>((p1_wx ? o.Wx : o.A) + p1_i * 7, 1, o.Bpm + p1_j, 3);
+            const double val = p1_wx ? dot : (dyn ? o.Bn[p1_e] + dot : 0.0);
+            double *dst = p1_wx ? &w.WxBp[p1_e] : (p1_bh ? &o.Bh[p1_e] : &w.sink[lane]);
+            *dst = val;
         }
         double rd[7] = {0, 0, 0, 0, 0, 0, 0};
+        double sw_p = 0.0, sw_qu = 0.0;
         if (dyn) {
             // P2: LDL^T of M = D + Pn, redundantly in the registers of every lane (broadcast LDS reads, no exchange):
             // m holds the lower triangle, the strict part ends up as Lt.  Same arithmetic as the oracle's ldl_solve7.
@@ -821,8 +864,13 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             for (int i = 0, n = 0; i < 7; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j, ++n) m[n] = w.Pn[i * 7 + j] + (i == j ? o.D[i] : 0.0);
+            // fused backward sweep of node k+1 (its matrices are still in the other operand buffer), interleaved
+            // with the pivots: one column of its first matrix-vector product per pivot
+            const StageOps &on = w.ops[(k + 1) & 1];
+            if (fuse_sweep) sweep_begin(on);
 #pragma unroll
             for (int pp = 0; pp < 7; ++pp) {
+                if (fuse_sweep) sweep_col(pp);
                 const double d = m[pp * (pp + 1) / 2 + pp];
                 if (!(d > 0.0)) good = false;
                 rd[pp] = rcp_pos(d);
@@ -848,11 +896,15 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             for (int pp = 1; pp < 7; ++pp)
 #pragma unroll
                 for (int q = 0; q < pp; ++q) x[pp] -= m[pp * (pp + 1) / 2 + q] * x[q];
-            if (lane < 14) {
+            {
+                double *dst = (lane < 14) ? &w.WlLi[lane] : &w.sink[lane];
+                const int st = (lane < 14) ? 14 : 0;
 #pragma unroll
-                for (int pp = 0; pp < 7; ++pp) w.WlLi[pp * 14 + lane] = x[pp];
+                for (int pp = 0; pp < 7; ++pp) dst[pp * st] = x[pp];
             }
+            if (fuse_sweep) sweep_finish(on, k + 1, sw_p, sw_qu);
         }
+        if (fuse_sweep && dyn) sweep_store(k + 1, sw_p, sw_qu);
         wsync();
         FT_MARK(1)
         if (dyn) {
@@ -917,41 +969,20 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             w.Pn[lane] = pk; fac[F_A + lane] = o.A[lane];
         }
         FT_MARK(7)
-        if (fuse_sweep) {
-            double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                Grow[q] = o.G[srr * 7 + q]; Ptrow[q] = o.Pt[srr * 7 + q]; Acol[q] = o.A[q * 7 + srr];
-                Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.Bh[q * 3 + sr3];
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + srr];
-            const double v = cur.rho + pnext;
-            double t = pnext;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) t += -Grow[q] * __shfl(v, q, 8) + Ptrow[q] * __shfl(cur.aff, q, 8);
-            if (!dyn || !sact) t = 0.0;
-            double qu = cur.gu;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(t, q, 8);
-            if (sr >= 3 || !sact) qu = 0.0;
-            double pp = cur.gx;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) pp += Acol[q] * __shfl(t, q, 8);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
-            if (sact) {
-                gf64 *ch = s.ch + (size_t)k * CH_N;
-                ch[C_P + sc * 7 + sr] = pp;
-                if (sr < 3) ch[C_QU + sc * 3 + sr] = qu;
-                pnext = pp;
-            }
-            if (k >= 1) cur = chan_mask(nraw, sc, sr, sact);
-        }
+        // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
+        if (fuse_sweep) cur = dyn ? chan_mask(nraw, sc, sr, sact) : chan_inputs(s, sd, K - 1, sc, sr, sact);
         FT_MARK(8)
         if (k >= 1) stash(w.ops[(k - 1) & 1], k - 1);
         wsync();
         FT_MARK(9)
+    }
+    if (fuse_sweep) {             // the sweep of node 0
+        double sw_p, sw_qu;
+        sweep_begin(w.ops[0]);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) sweep_col(q);
+        sweep_finish(w.ops[0], 0, sw_p, sw_qu);
+        sweep_store(0, sw_p, sw_qu);
     }
     __syncthreads();
     return __all(good);
