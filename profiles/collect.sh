@@ -2,6 +2,7 @@
 # Collects the rocprofv3 evidence kept under profiles/<round>/ (run on the GPU box from the repo root):
 #   1. kernel trace + stats per workload (kernel durations the bench line's roofline.achieved must agree with)
 #   2. FETCH_SIZE and WRITE_SIZE in separate counter passes (TCC slots do not hold both), kernel trace only
+#   3. two passes of 8 SQ counters each: instruction mix / fp64 operation counts, and wait / active cycles
 # Raw output goes to gpurun_out/prof/<round>/ ; profiles/summarize.py turns it into the committed summaries.
 set -e
 ROUND=${1:-r01}
@@ -14,9 +15,12 @@ for W in S64_K30 S4096_K30 S4096_K100_scp2; do
     python3 "$REPO/bench.py" --workload $W --steps 5 --warmup 2 --no-also --no-cpu-baseline > "$OUT/$W.bench.log" 2>&1
   echo "stats $W done"
 done
+SQ_A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"
+SQ_B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F64"
 for W in S64_K30 S4096_K30; do
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$W/$C" -o pmc -- \
+  for C in FETCH_SIZE WRITE_SIZE SQ_A SQ_B; do
+    case $C in SQ_A) LIST=$SQ_A;; SQ_B) LIST=$SQ_B;; *) LIST=$C;; esac
+    rocprofv3 --kernel-trace --pmc $LIST --output-format csv -d "$OUT/$W/$C" -o pmc -- \
       python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --no-also --no-cpu-baseline > "$OUT/$W.$C.log" 2>&1
     echo "pmc $C $W done"
   done

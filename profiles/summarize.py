@@ -49,6 +49,32 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
             traffic["workloads"][w][short] = {"fetch_KB": f_kb, "write_KB": w_kb, "hbm_bytes_per_launch": (f_kb + w_kb) * 1024.0}
 if traffic["workloads"]:
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+# SQ passes: per kernel, counter values summed over the rows of one dispatch, averaged over dispatches
+sq = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes), bench.py --steps 1 --warmup 1 --no-also; wave-level "
+              "instruction counts; SQ_WAIT_* / SQ_ACTIVE_* / SQ_BUSY_CYCLES in quad-cycles summed over SEs/XCDs as reported",
+      "workloads": {}}
+for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
+    w = os.path.basename(os.path.dirname(wdir))
+    per = defaultdict(dict)
+    for c in ("SQ_A", "SQ_B"):
+        cc = find(os.path.join(wdir, c), "counter_collection.csv")
+        if not cc: continue
+        acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+        for r in csv.DictReader(open(cc)):
+            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, cnt in acc.items():
+            for name, disp in cnt.items():
+                per[k.split("::")[-1]][name] = sum(disp.values()) / len(disp)
+    keep = {k: v for k, v in per.items() if "solve_kernel" in k or "discretize_kernel" in k}
+    if keep:
+        for k, v in keep.items():
+            if "SQ_INSTS_VALU_FMA_F64" in v:
+                v["fp64_flop_64lanes"] = 64.0 * (2 * v["SQ_INSTS_VALU_FMA_F64"] + v.get("SQ_INSTS_VALU_MUL_F64", 0) + v.get("SQ_INSTS_VALU_ADD_F64", 0))
+        sq["workloads"][w] = keep
+if sq["workloads"]:
+    json.dump(sq, open(os.path.join(dst, "pmc_sq.json"), "w"), indent=1)
+    print(json.dumps(sq["workloads"], indent=1))
 print(json.dumps(traffic["workloads"], indent=1))
 for f in sorted(glob.glob(os.path.join(dst, "*_kernel_stats.csv"))):
     print("==", os.path.basename(f)); print(open(f).read())
