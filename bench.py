@@ -202,6 +202,17 @@ def main():
         if n_scp > 1:
             out["scp_iterations_per_s"] = value * n_scp
         h = run.host
+        if world == 1 and not args.no_also:
+            # the same step through the host-pointer entry point (numpy in / numpy out): staging allocation, H2D of the
+            # inputs and D2H of the results inside the timed region -- reported beside `value`, never as `value`
+            from mpconstellation_amd import mpc_step_batch
+            mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
+            t0 = time.perf_counter()
+            for _ in range(3): mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
+            dt = (time.perf_counter() - t0) / 3
+            out["host_pointer_entry"] = {"value": S / dt * (1 if n_scp == 1 else 1.0 / n_scp), "unit": "satellite-MPC-steps/s",
+                                         "ms_per_call": dt * 1e3,
+                                         "note": "mpcx_mpc_step_batch: one SCP iteration per call, PCIe transfers and staging included"}
         if world == 1 and not args.no_also and args.workload == "S64_K30":
             del run
             torch.cuda.empty_cache()
