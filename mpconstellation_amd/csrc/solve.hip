@@ -116,26 +116,37 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// 1/d for d > 0 well inside the normal range: hardware seed + three Newton steps (the full IEEE division
+// sequence with its scaling/fix-up is not needed for pivots and determinants)
+__device__ __forceinline__ double rcp_pos(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    return r;
+}
+
 // c~ = |v|^2 - (r.v)^2/|r|^2 - vt_des^2 (same zero set as the quartic of optimizer.py:492-517)
 __device__ void vt_reduced(const double *x, double vt_des, double &c, double *g6, double *H36)
 {
     const double *r = x, *v = x + 3;
     const double q = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
     const double rv = r[0] * v[0] + r[1] * v[1] + r[2] * v[2];
-    c = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - rv * rv / q - vt_des * vt_des;
+    const double iq = 1.0 / q, iq2 = iq * iq, iq3 = iq2 * iq;       // one division, the powers of 1/q by products
+    c = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - rv * rv * iq - vt_des * vt_des;
     if (!g6) return;
     for (int i = 0; i < 3; ++i) {
-        g6[i] = -2.0 * rv * v[i] / q + 2.0 * rv * rv * r[i] / (q * q);
-        g6[3 + i] = 2.0 * v[i] - 2.0 * rv * r[i] / q;
+        g6[i] = -2.0 * rv * v[i] * iq + 2.0 * rv * rv * r[i] * iq2;
+        g6[3 + i] = 2.0 * v[i] - 2.0 * rv * r[i] * iq;
     }
     if (!H36) return;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             const double I = (i == j) ? 1.0 : 0.0;
-            const double Hvv = 2.0 * I - 2.0 * r[i] * r[j] / q;
-            const double Hrr = -2.0 * v[i] * v[j] / q + 4.0 * rv * (v[i] * r[j] + r[i] * v[j]) / (q * q) +
-                               2.0 * rv * rv * I / (q * q) - 8.0 * rv * rv * r[i] * r[j] / (q * q * q);
-            const double Hrv = -2.0 * v[i] * r[j] / q - 2.0 * rv * I / q + 4.0 * rv * r[i] * r[j] / (q * q);
+            const double Hvv = 2.0 * I - 2.0 * r[i] * r[j] * iq;
+            const double Hrr = -2.0 * v[i] * v[j] * iq + 4.0 * rv * (v[i] * r[j] + r[i] * v[j]) * iq2 +
+                               2.0 * rv * rv * I * iq2 - 8.0 * rv * rv * r[i] * r[j] * iq3;
+            const double Hrv = -2.0 * v[i] * r[j] * iq - 2.0 * rv * I * iq + 4.0 * rv * r[i] * r[j] * iq2;
             H36[i * 6 + j] = Hrr;
             H36[(3 + i) * 6 + 3 + j] = Hvv;
             H36[i * 6 + 3 + j] = Hrv;
@@ -504,7 +515,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             double Wu[9];
             {
                 const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
-                const double sig = zu / su, zh = mu / su + sig * (g + su);
+                const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zh;
@@ -516,13 +527,14 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             if (k >= 1) {
                 const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
                 const double g = r2 - b_rmax;
-                sig_rmax = zrmax / srmax; zh_rmax = mu / srmax + sig_rmax * (g + srmax);
+                const double isr = rcp_pos(srmax);
+                sig_rmax = zrmax * isr; zh_rmax = mu * isr + sig_rmax * (g + srmax);
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) Wx3[i] = ((i & 3) == 0) ? 2.0 * w_tr + delta_w : 0.0;
             if (inner) {
                 const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
-                const double sig = zrmin / srmin, zh = mu / srmin + sig * (g + srmin);
+                const double isr = rcp_pos(srmin), sig = zrmin * isr, zh = mu * isr + sig * (g + srmin);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     gx[i] += 2.0 * x[i] * zh_rmax - rbv[i] * zh;
@@ -562,10 +574,12 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
                 const double stn = p[I_STN + i], ztn = p[I_ZTN + i];
                 const double g1 = nu - tt, g2 = -nu - tt;
-                const double s1 = ztp / stp, s2 = ztn / stn;
-                const double zh1 = mu / stp + s1 * (g1 + stp), zh2 = mu / stn + s2 * (g2 + stn);
+                const double ip = rcp_pos(stp), in = rcp_pos(stn);      // slacks are positive: reciprocal + products
+                const double s1 = ztp * ip, s2 = ztn * in;
+                const double zh1 = mu * ip + s1 * (g1 + stp), zh2 = mu * in + s2 * (g2 + stn);
                 const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
-                const double dd = 4.0 * s1 * s2 / aa;
+                const double ia = rcp_pos(aa);
+                const double dd = 4.0 * s1 * s2 * ia;
                 double acc = sg * tf + xv + nu;
 #pragma unroll
                 for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
@@ -573,7 +587,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
                 nb[N_D + i] = dd; ns[NS_D + i] = dd;
                 ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
-                ns[NS_RHO + i] = (zh1 - zh2) - (bb / aa) * gt;
+                ns[NS_RHO + i] = (zh1 - zh2) - (bb * ia) * gt;
                 ns[NS_E + i] = xn[i] - acc;
                 CHUNK_END
             }
@@ -652,16 +666,6 @@ __device__ __forceinline__ double dot_el(const double *A, int ar, int ac, const 
     double acc = 0.0;
     for (int l = 0; l < Kd; ++l) acc += A[i * ar + l * ac] * B[l * br + j * bc];
     return acc;
-}
-
-// 1/d for d > 0 well inside the normal range: hardware seed + three Newton steps (the full IEEE division
-// sequence with its scaling/fix-up is not needed for pivots and determinants)
-__device__ __forceinline__ double rcp_pos(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-#pragma unroll
-    for (int n = 0; n < 3; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
-    return r;
 }
 
 // symmetric 3x3 inverse with positive-definiteness test (leading minors)
@@ -1453,7 +1457,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             {
                 const double su = bs[0], zu = bs[1];
                 const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
-                const double sig = zu / su, zh = mu / su + sig * (g + su);
+                const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
                 const double dg = 2.0 * (u[0] * du[0] + u[1] * du[1] + u[2] * du[2]);
                 o[0] = -(g + su) - dg; o[1] = zh + sig * dg - zu;
                 LIM(su, o[0]); LIM(zu, o[1]);
@@ -1461,7 +1465,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             if (k >= 1) {
                 const double srmax = bs[2], zrmax = bs[3];
                 const double g = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax;
-                const double sig = zrmax / srmax, zh = mu / srmax + sig * (g + srmax);
+                const double isr = rcp_pos(srmax), sig = zrmax * isr, zh = mu * isr + sig * (g + srmax);
                 const double dg = 2.0 * (x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2]);
                 o[2] = -(g + srmax) - dg; o[3] = zh + sig * dg - zrmax;
                 LIM(srmax, o[2]); LIM(zrmax, o[3]);
@@ -1469,7 +1473,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             if (k >= 1 && k <= K - 2) {
                 const double srmin = bs[4], zrmin = bs[5];
                 const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
-                const double sig = zrmin / srmin, zh = mu / srmin + sig * (g + srmin);
+                const double isr = rcp_pos(srmin), sig = zrmin * isr, zh = mu * isr + sig * (g + srmin);
                 const double dg = -(rb0 * dx[0] + rb1 * dx[1] + rb2 * dx[2]);
                 o[4] = -(g + srmin) - dg; o[5] = zh + sig * dg - zrmin;
                 LIM(srmin, o[4]); LIM(zrmin, o[5]);
@@ -1487,11 +1491,12 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
                 const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
                 const double stn = p[I_STN + i], ztn = p[I_ZTN + i], dnu = d[I_NU + i], dlam = d[I_LAM + i];
                 const double gt = ns[NS_GT + i], bb = ns[NS_BB + i], aa = ns[NS_AA + i];
-                const double dt = (-gt - bb * dnu) / aa;
+                const double dt = (-gt - bb * dnu) * rcp_pos(aa);
                 CHK(dnu); CHK(dlam); CHK(dt);
                 const double g1 = nu - tt, g2 = -nu - tt;
-                const double s1 = ztp / stp, s2 = ztn / stn;
-                const double zh1 = mu / stp + s1 * (g1 + stp), zh2 = mu / stn + s2 * (g2 + stn);
+                const double ip = rcp_pos(stp), in = rcp_pos(stn);
+                const double s1 = ztp * ip, s2 = ztn * in;
+                const double zh1 = mu * ip + s1 * (g1 + stp), zh2 = mu * in + s2 * (g2 + stn);
                 const double dg1 = dnu - dt, dg2 = -dnu - dt;
                 const double dstp = -(g1 + stp) - dg1, dztp = zh1 + s1 * dg1 - ztp;
                 const double dstn = -(g2 + stn) - dg2, dztn = zh2 + s2 * dg2 - ztn;
@@ -1544,7 +1549,8 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
 {
     const int K = s.K;
 #define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
-                             z_ = fmax(fmin(z_, kKappaSigma * mu / s_), mu / (kKappaSigma * s_)); (sv) = s_; (zv) = z_; }
+                             const double c_ = mu * rcp_pos(s_); \
+                             z_ = fmax(fmin(z_, kKappaSigma * c_), c_ * (1.0 / kKappaSigma)); (sv) = s_; (zv) = z_; }
     const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     for (int k = lane; k < K; k += 64) {
         const auto p = s.itn(k), d = s.drn(k);
