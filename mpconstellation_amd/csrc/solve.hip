@@ -4,16 +4,18 @@
 // 219-613: the NLP that pyomo transcribes and ipopt solves) for S satellites at once.
 //
 // One wavefront (64 lanes) per satellite runs the whole primal-dual interior-point iteration:
-//  * stage-parallel phases (KKT residuals, barrier Hessian blocks, slack/multiplier updates, step
-//    length, line-search trials) map one lane to one temporal node;
+//  * node-parallel phases (KKT residuals, barrier Hessian blocks, slack/multiplier updates, step
+//    length, line-search trials) map one lane to one temporal node and work on field-major arrays
+//    (coalesced), written as chunks "loads -> arithmetic -> stores" so that a chunk's loads are in flight together;
 //  * the structure-exploiting linear solve is a Riccati recursion in the shifted state
 //    y_k = x_k - Bp_{k-1} u_k (absorbs the first-order hold), 7x7 / 7x3 / 3x3 blocks staged in LDS
-//    with one lane per matrix element; the virtual control nu_k is eliminated per stage by a 7x7
-//    Cholesky; the free final time, the tangential-velocity equality and the five stiff rank-1
-//    terminal barrier terms form a 7x7 border solved by LU with partial pivoting; eight
-//    linear-term sweeps (1 right-hand side + 7 border columns) run side by side in the 8 lane
-//    groups of the wave; one step of iterative refinement on the reduced KKT system.
-// Per-satellite state lives in a global-memory workspace (HBM/L2 resident, ~4.8 KB per node); no MFMA.
+//    with one lane per matrix element and node k-1's operands prefetched while node k is worked on; the virtual
+//    control nu_k is eliminated per stage by a 7x7 LDL^T (redundantly in the registers of every lane); the free
+//    final time, the tangential-velocity equality and the five stiff rank-1 terminal barrier terms form a 7x7 border
+//    solved by LU with partial pivoting; eight linear-term sweeps (1 right-hand side + 7 border columns) run side
+//    by side in the 8 lane groups of the wave, the backward one fused into the factorisation loop; iterative
+//    refinement on the reduced KKT system only once a terminal weight is stiff enough to cost digits.
+// Per-satellite state lives in a global-memory workspace (ws_doubles: 224 KB at K = 30); no MFMA.
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
 
@@ -660,14 +662,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
 }
 
 // ---- tiny dense helpers on LDS matrices --------------------------------------------------------
-// element (i,j) of sum_l A[i*ar + l*ac] * B[l*br + j*bc], l < Kd
-__device__ __forceinline__ double dot_el(const double *A, int ar, int ac, const double *B, int br, int bc, int i, int j, int Kd)
-{
-    double acc = 0.0;
-    for (int l = 0; l < Kd; ++l) acc += A[i * ar + l * ac] * B[l * br + j * bc];
-    return acc;
-}
-
 // symmetric 3x3 inverse with positive-definiteness test (leading minors)
 __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 {

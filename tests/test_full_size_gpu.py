@@ -1,0 +1,117 @@
+"""Size-independent properties of the hot path at BASELINE.json's full single-GPU sizes (configs[2] S=4096, K=30;
+configs[3] shape K=100 on a 512-satellite block), and the edge cases of the boundary (minimum horizon, a single
+satellite, rejected arguments).  Everything goes through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import oracle_lib as O
+import nlp_ipm as N
+
+pytestmark = pytest.mark.gpu
+
+
+def workload(S_total, K, first=0, count=None):
+    from mpconstellation_amd import _ffi
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+    from mpconstellation_amd.simulator import propagate_batch
+    count = S_total - first if count is None else count
+    y0, consts = normalize_batch(constellation_states(S_total, first=first, count=count))
+    xbar, st, _ = propagate_batch(y0, np.ones(count), consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K)
+    assert (st == 0).all()
+    ubar = np.ascontiguousarray(tangential_thrust(xbar, 0.5))
+    return xbar, ubar, consts, np.linalg.norm(xbar[:, :3, -1], axis=1)
+
+
+def dyn_defect(A, Bp, Bn, Sig, xi, X, U, NU, tf):
+    """max |x_{k+1} - (A_k x_k + B_kn u_k + B_kp u_{k+1} + Sigma_k tf + xi_k + nu_k)| per satellite (optimizer.py:327-342)"""
+    pred = (np.einsum("skij,sjk->sik", A, X[:, :, :-1]) + np.einsum("skij,sjk->sik", Bn, U[:, :, :-1]) +
+            np.einsum("skij,sjk->sik", Bp, U[:, :, 1:]) + Sig * tf[:, None, None] + xi + NU[:, :, :-1])
+    return np.abs(X[:, :, 1:] - pred).max(axis=(1, 2))
+
+
+@pytest.mark.parametrize("S,K", [(4096, 30), (512, 100)])
+def test_full_size_properties(S, K):
+    from mpconstellation_amd import mpc_step_batch, Discretizer
+    xbar, ubar, consts, r_des = workload(S, K)
+    tf = np.ones(S)
+    res = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    # every problem converges to the solver tolerance
+    assert (res.status == 0).all() and res.kkt.max() <= 1e-8
+    assert res.iters.max() <= 60
+    # feasibility of the reference NLP, with the stage data recomputed by the discretize entry point
+    A, Bp, Bn, Sig, xi, st = Discretizer(None).discretize_batch(xbar, ubar, tf, consts)
+    assert (st == 0).all()
+    assert dyn_defect(A, Bp, Bn, Sig, xi, res.X, res.U, res.NU, res.tf).max() < 1e-8
+    assert np.abs(res.X[:, :, 0] - xbar[:, :, 0]).max() == 0.0                               # x_0 fixed   :344-345
+    assert (res.X[:, 6, -1] >= 0.1 - 1e-6).all()                                             # final mass  :351-352
+    assert np.linalg.norm(res.U, axis=1).max() <= 5 + 1e-6                                   # thrust ball :379-381
+    rn = np.linalg.norm(res.X[:, :3, :], axis=1)
+    assert rn.max() <= 5 + 1e-6                                                              # r_max       :393-395
+    assert np.abs(rn[:, -1] - r_des).max() <= 0.01 + 1e-6                                    # eps_r       :398-403
+    assert (res.tf > 0).all() and (res.tf <= 5 + 1e-6).all()                                 # tf range    :588
+    assert (np.abs(res.NU) <= 1e-6).all()                                                    # no virtual control needed
+    h = np.cross(res.X[:, :3, -1], res.X[:, 3:6, -1])
+    vt_des = np.sqrt(consts[:, 0] / r_des)
+    assert np.abs(np.linalg.norm(h, axis=1) / rn[:, -1] - vt_des).max() < 1e-7               # tangential speed :492-517
+    # the objective does not exceed the (feasible up to its linearisation defect) reference's: tf decreases
+    assert (res.tf < 1.0).all()
+    # determinism: the same launch twice is bit-identical
+    res2 = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    assert np.array_equal(res.X, res2.X) and np.array_equal(res.U, res2.U) and np.array_equal(res.tf, res2.tf)
+    assert np.array_equal(res.iters, res2.iters)
+
+
+def test_satellites_are_independent_units():
+    """What the multi-GPU sharding relies on: a satellite's result does not depend on which batch, which position or
+    which block it is solved in (bit for bit)."""
+    from mpconstellation_amd import mpc_step_batch
+    S, K = 1024, 30
+    xbar, ubar, consts, r_des = workload(S, K)
+    tf = np.ones(S)
+    whole = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    perm = np.random.default_rng(7).permutation(S)
+    shuf = mpc_step_batch(xbar[perm], ubar[perm], tf, consts[perm], r_des[perm])
+    assert np.array_equal(whole.X[perm], shuf.X) and np.array_equal(whole.U[perm], shuf.U)
+    assert np.array_equal(whole.tf[perm], shuf.tf) and np.array_equal(whole.iters[perm], shuf.iters)
+    # contiguous blocks as the ranks of an 8-GPU job would take them, generated per block
+    from mpconstellation_amd.sharding import shard_block
+    for rank in (0, 3, 7):
+        first, count = shard_block(S, 8, rank)
+        xb, ub, cb, rb = workload(S, K, first, count)
+        assert np.array_equal(xb, xbar[first:first + count])
+        part = mpc_step_batch(xb, ub, np.ones(count), cb, rb)
+        assert np.array_equal(part.X, whole.X[first:first + count]) and np.array_equal(part.tf, whole.tf[first:first + count])
+
+
+def test_minimum_horizon_and_single_satellite():
+    """K = 3 is the shortest horizon the solver accepts (one interior node); one satellite per call is the reference's
+    own use of Optimizer.  Same path as the oracle (no factorisation breaks down on these), compared at 1e-9."""
+    from mpconstellation_amd import mpc_step_batch
+    for K, sat in ((3, 0), (3, 5), (4, 0)):
+        xbar, ubar, consts, r_des = workload(64, K, sat, 1)
+        res = mpc_step_batch(xbar, ubar, [1.0], consts, r_des)
+        od = O.discretize(xbar[0], ubar[0], 1.0, consts[0])
+        P = N.MpcProblem(xbar[0], ubar[0], 1.0, consts[0][0], od, O.constraint_terms(xbar[0], ubar[0], consts[0][0]),
+                         {"r_des": float(r_des[0])})
+        ref = N.solve(P)
+        assert ref["status"] == 0 and res.status[0] == 0 and ref["n_regularised"] == 0
+        assert res.X.shape == (1, 7, K) and res.U.shape == (1, 3, K) and res.NU.shape == (1, 7, K)
+        assert np.abs(res.X[0] - ref["X"]).max() < 5e-6 and np.abs(res.U[0] - ref["U"]).max() < 5e-6
+        assert abs(res.tf[0] - ref["tf"]) < 5e-6
+
+
+def test_rejected_arguments(golden_dir):
+    from mpconstellation_amd import mpc_step_batch
+    from mpconstellation_amd._ffi import MpcxError
+    d = np.load(os.path.join(golden_dir, "disc_K2_dimensional.npz"))
+    x, u, cst = d["x"], d["u"], d["const"]
+    with pytest.raises(MpcxError):                       # K = 2: no interior node, the solver refuses (MPCX_E_BADARG)
+        mpc_step_batch(x[None], u[None], [1.0], cst[None], [1.0])
+    with pytest.raises(ValueError):                      # wrong shapes never reach the C ABI
+        mpc_step_batch(np.zeros((1, 6, 5)), np.zeros((1, 3, 5)), [1.0], np.zeros((1, 8)), [1.0])
+    with pytest.raises((MpcxError, ValueError)):         # empty batch
+        mpc_step_batch(np.zeros((0, 7, 5)), np.zeros((0, 3, 5)), np.zeros(0), np.zeros((0, 8)), np.zeros(0))
