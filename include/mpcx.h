@@ -99,8 +99,14 @@ int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double
 typedef struct {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr;
     double tol, acceptable_tol;
-    int32_t max_iter, acceptable_iter, n_refine, reserved;
+    int32_t max_iter, acceptable_iter, n_refine, flags;   /* flags: MPCX_SOLVE_* */
 } mpcx_solve_opts;
+
+/* By default the solver launches its per-satellite workgroups longest-first, ordered by the iteration counts of
+ * the previous solve of the same batch size on this context (consecutive MPC steps pose similar problems; with a
+ * few satellites per wave slot the launch ends when the slowest slot does).  Results never depend on the launch
+ * order.  This flag keeps the plain index order. */
+#define MPCX_SOLVE_INDEX_ORDER 1
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 size_t mpcx_solve_workspace_bytes(int S, int K);

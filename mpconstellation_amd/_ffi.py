@@ -36,7 +36,7 @@ class SolveOpts(C.Structure):
     """mpcx_solve_opts (include/mpcx.h)"""
     _fields_ = [(n, C.c_double) for n in ("min_mass", "u_max", "r_min", "r_max", "eps_r", "eps_vr", "eps_vn",
                                           "tf_max", "w_nu", "w_tr", "tol", "acceptable_tol")] + \
-               [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "n_refine", "reserved")]
+               [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "n_refine", "flags")]
 
 
 _po = C.POINTER(SolveOpts)

@@ -34,6 +34,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return MPCX_E_HIP;
     mpcx_ctx *c = new mpcx_ctx();
     c->device = device; c->err[0] = 0; c->ws = nullptr; c->ws_bytes = 0;
+    c->prev_iters = nullptr; c->order = nullptr; c->order_S = 0; c->order_valid = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         snprintf(g_create_err, sizeof g_create_err, "hipStreamCreate failed");
@@ -49,6 +50,8 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
+    if (ctx->order) (void)hipFree(ctx->order);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -14,6 +14,10 @@ struct mpcx_ctx {
     // grow-only device workspace reused by the solver / fused step (never freed between calls)
     void *ws;
     size_t ws_bytes;
+    // launch order of the solver's workgroups: the previous solve's iteration counts (library-owned copy) sorted
+    // longest first; valid only for a following solve of the same batch size
+    int32_t *prev_iters, *order;
+    int order_S, order_valid;
 };
 
 inline int ctx_fail(mpcx_ctx *ctx, int code, const char *msg)

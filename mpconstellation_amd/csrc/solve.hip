@@ -54,6 +54,7 @@ struct SolveArgs {
     SolveOpts o;
     double *X, *U, *NU, *tf_out, *kkt;
     int32_t *status, *iters;
+    const int32_t *order;     // workgroup b solves satellite order[b]; nullptr = index order
     double *ws;
     size_t ws_stride;
 };
@@ -1606,6 +1607,24 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
     __syncthreads();
 }
 
+// Launch order: satellites sorted by the previous solve's iteration count, longest first (counting sort, one block).
+// The order inside one count is whatever the atomics give; the solver's results do not depend on the order.
+__global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t *prev_iters, int32_t *order)
+{
+    __shared__ int hist[256], base[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < S; i += 1024) atomicAdd(&hist[min(max(prev_iters[i], 0), 255)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int key = 255; key >= 0; --key) { base[key] = acc; acc += hist[key]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += 1024) order[atomicAdd(&base[min(max(prev_iters[i], 0), 255)], 1)] = i;
+}
+
 // a satellite whose discretisation failed reports that code instead of the solver's
 __global__ void merge_status_kernel(int S, const int32_t *dstat, int32_t *status)
 {
@@ -1633,8 +1652,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
     __shared__ SatData sd;
     __shared__ Scratch w;
     const int lane = threadIdx.x;
-    const int sat = blockIdx.x;
-    if (sat >= a.S) return;
+    if ((int)blockIdx.x >= a.S) return;
+    const int sat = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const int K = a.K;
     Sat s;
     s.K = K;
@@ -1900,7 +1919,7 @@ extern "C" void mpcx_default_solve_opts(mpcx_solve_opts *o)
     // reference defaults: optimizer.py:178-188; ipopt defaults: tol 1e-8, acceptable_tol 1e-6
     o->min_mass = 0.1; o->u_max = 5.0; o->r_min = 0.99; o->r_max = 5.0; o->eps_r = 0.01;
     o->eps_vr = 1e-5; o->eps_vn = 1e-5; o->tf_max = 5.0; o->w_nu = 1000.0; o->w_tr = 0.002;
-    o->tol = 1e-8; o->acceptable_tol = 1e-6; o->max_iter = 200; o->acceptable_iter = 15; o->n_refine = 1;
+    o->tol = 1e-8; o->acceptable_tol = 1e-6; o->max_iter = 200; o->acceptable_iter = 15; o->n_refine = 1; o->flags = 0;
 }
 
 extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
@@ -1923,8 +1942,29 @@ extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *s
     a.o = to_dev_opts(opts);
     a.X = X; a.U = U; a.NU = NU; a.tf_out = tf_out; a.kkt = kkt; a.status = status; a.iters = iters;
     a.ws = (double *)workspace; a.ws_stride = ws_doubles(K);
+    // longest-first launch order from the previous solve's iteration counts (include/mpcx.h, MPCX_SOLVE_INDEX_ORDER)
+    const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER);
+    a.order = nullptr;
+    if (adaptive) {
+        if (ctx->order_S != S) {
+            if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
+            if (ctx->order) (void)hipFree(ctx->order);
+            ctx->prev_iters = ctx->order = nullptr; ctx->order_S = 0; ctx->order_valid = 0;
+            MPCX_HIP(ctx, hipMalloc((void **)&ctx->prev_iters, (size_t)S * sizeof(int32_t)));
+            MPCX_HIP(ctx, hipMalloc((void **)&ctx->order, (size_t)S * sizeof(int32_t)));
+            ctx->order_S = S;
+        }
+        if (ctx->order_valid) {
+            hipLaunchKernelGGL(launch_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, ctx->prev_iters, ctx->order);
+            a.order = ctx->order;
+        }
+    }
     hipLaunchKernelGGL(solve_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, a);
     MPCX_HIP(ctx, hipGetLastError());
+    if (adaptive) {
+        MPCX_HIP(ctx, hipMemcpyAsync(ctx->prev_iters, iters, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        ctx->order_valid = 1;
+    }
     return MPCX_OK;
 }
 

@@ -77,6 +77,12 @@ def test_satellites_are_independent_units():
     shuf = mpc_step_batch(xbar[perm], ubar[perm], tf, consts[perm], r_des[perm])
     assert np.array_equal(whole.X[perm], shuf.X) and np.array_equal(whole.U[perm], shuf.U)
     assert np.array_equal(whole.tf[perm], shuf.tf) and np.array_equal(whole.iters[perm], shuf.iters)
+    # the launch order (longest first by the previous solve's iteration counts, the default from the second call on;
+    # MPCX_SOLVE_INDEX_ORDER = 1 keeps the index order) does not change a single bit either
+    again = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    fifo = mpc_step_batch(xbar, ubar, tf, consts, r_des, flags=1)
+    for r in (again, fifo):
+        assert np.array_equal(whole.X, r.X) and np.array_equal(whole.NU, r.NU) and np.array_equal(whole.iters, r.iters)
     # contiguous blocks as the ranks of an 8-GPU job would take them, generated per block
     from mpconstellation_amd.sharding import shard_block
     for rank in (0, 3, 7):
