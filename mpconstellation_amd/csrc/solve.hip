@@ -309,8 +309,15 @@ struct ResAcc {   // accumulators of one residual evaluation
 // loads of later chunks on top, which would spill.
 #define CHUNK_END __builtin_amdgcn_sched_barrier(0);
 
+// Two lanes per node in the node-parallel phases: lane (half, kl) = (lane >> 5, lane & 31) works on node kl (+32, ...);
+// the part of a node's work that is a loop over the 7 state components is split between the two halves (components
+// 4*half + r, r = 0..3, the eighth being a masked dummy), both halves running the same instructions; what cannot be
+// split is computed by both and accounted once (half 0).  Partial sums meet through a lane ^ 32 shuffle.
+#define HALF_OF(lane) ((lane) >> 5)
+#define NODE_OF(lane) ((lane) & 31)
+
 // Perturbed KKT residual F_mu at (iterate + a*direction): ipopt's scaled error pieces and the
-// 2-norm used by the line search.  Lane k handles node k.  Results are wave-uniform.
+// 2-norm used by the line search.  Results are wave-uniform.
 __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
 {
     const int K = s.K;
@@ -320,132 +327,143 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     const double lvt = s.itg[G_LVT] + a * s.drg[G_LVT];
     const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     const bool z = (a == 0.0);
+    const int half = HALF_OF(lane);
+    const bool h0 = (half == 0);
 #define ACC_D(v) { const double q_ = (v); dual = fmax(dual, fabs(q_)); sq += q_ * q_; }
 #define ACC_P(v) { const double q_ = (v); prim = fmax(prim, fabs(q_)); sq += q_ * q_; }
 #define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; comp = fmax(comp, fabs(q_)); sq += q_ * q_; \
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
 #define TRIAL(P, D, off) trial_value(P, D, off, a, z)
-    for (int k = lane; k < K; k += 64) {
+    for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), d = s.drn(k);
         const bool has_prev = (k >= 1), dyn = (k <= K - 2);
-        // ---- chunk 0: states, thrust, neighbours' pieces, ball slacks ----
-        double x[7], u[3], gx[7], gu[3], lm[7], un[3], xn[7];
+        // ---- chunk 0 (both halves, accounted by half 0): states, thrust, ball slacks, objective gradient ----
+        double x[7], u[3], gx[7], gu[3], un[3];
 #pragma unroll
         for (int i = 0; i < 7; ++i) x[i] = TRIAL(p, d, I_X + i);
 #pragma unroll
         for (int i = 0; i < 3; ++i) u[i] = TRIAL(p, d, I_U + i);
         const double su = TRIAL(p, d, I_SU), zu = TRIAL(p, d, I_ZU), srmax = TRIAL(p, d, I_SRMAX), zrmax = TRIAL(p, d, I_ZRMAX);
         const double srmin = TRIAL(p, d, I_SRMIN), zrmin = TRIAL(p, d, I_ZRMIN);
-        {
-            const auto pm = p.node(has_prev ? -1 : 0) + I_LAM, dm = d.node(has_prev ? -1 : 0) + I_LAM;
-            const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
+        const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { lm[i] = TRIAL(pm, dm, i); xn[i] = TRIAL(pn, dn, I_X + i); }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
-        }
+        for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
         const auto rb = s.rbn(k);
         const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * K + k]) + (has_prev ? lm[i] : 0.0);
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * K + k]);
 #pragma unroll
         for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * u[i] * zu;
-        // thrust ball, every node
-        ACC_P(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u + su);
-        ACC_C(su, zu);
         if (has_prev) {
-            const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-            ACC_P(r2 - b_rmax + srmax);
-            ACC_C(srmax, zrmax);
 #pragma unroll
             for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrmax;
-            if (dyn) {
-                ACC_P(-(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin + srmin);
-                ACC_C(srmin, zrmin);
-                gx[0] -= rb0 * zrmin; gx[1] -= rb1 * zrmin; gx[2] -= rb2 * zrmin;
+            if (dyn) { gx[0] -= rb0 * zrmin; gx[1] -= rb1 * zrmin; gx[2] -= rb2 * zrmin; }
+        }
+        if (h0) {
+            ACC_P(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u + su);       // thrust ball, every node
+            ACC_C(su, zu);
+            if (has_prev) {
+                ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax + srmax);
+                ACC_C(srmax, zrmax);
+                if (dyn) {
+                    ACC_P(-(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin + srmin);
+                    ACC_C(srmin, zrmin);
+                }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) gx[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gu[i] = 0.0;
         }
         CHUNK_END
-        // ---- chunk 1: - Bp_{k-1}^T lam_{k-1} on u_k ----
-        if (has_prev) {
-            const auto Bp = s.Bpt(k - 1);
-            double b[21];
-#pragma unroll
-            for (int e = 0; e < 21; ++e) b[e] = Bp[e];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) acc += b[i * 3 + j] * lm[i];
-                gu[j] -= acc;
-            }
-        }
-        CHUNK_END
-        // ---- chunks 2..8: dynamics row i (optimizer.py:327-342), its multiplier, the L1 pair of nu_i ----
-        if (dyn) {
-            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k), xi = s.xit(k);
+        // ---- four rounds: component i = 4*half + r of the dynamics row (optimizer.py:327-342), of its multiplier, of
+        //      the L1 pair of nu_i, and of the previous row's multiplier (+lam_{k-1} on x_k, -Bp_{k-1}^T lam_{k-1} on u_k)
+        {
+            const auto A = s.At(dyn ? k : 0), Bn = s.Bnt(dyn ? k : 0), Bp = s.Bpt(dyn ? k : 0), Sg = s.Sigt(dyn ? k : 0), xi = s.xit(dyn ? k : 0);
+            const auto Bm = s.Bpt(has_prev ? k - 1 : 0);
+            const auto pm = p.node(has_prev ? -1 : 0), dm = d.node(has_prev ? -1 : 0);
             double sl = 0.0;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                double ar[7], bn[3], bp[3];
+            for (int r = 0; r < 4; ++r) {
+                const int iv = 4 * half + r;
+                const bool valid = iv < 7;
+                const int i = valid ? iv : 6;
+                double ar[7], bn[3], bp[3], bm[3];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) ar[j] = A[i * 7 + j];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; }
+                for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; bm[j] = Bm[i * 3 + j]; }
                 const double sg = Sg[i], xv = xi[i];
                 const double nu = TRIAL(p, d, I_NU + i), tt = TRIAL(p, d, I_T + i), lam = TRIAL(p, d, I_LAM + i);
                 const double stp = TRIAL(p, d, I_STP + i), ztp = TRIAL(p, d, I_ZTP + i);
                 const double stn = TRIAL(p, d, I_STN + i), ztn = TRIAL(p, d, I_ZTN + i);
-                double acc = sg * tf + xv + nu;
+                const double xn = TRIAL(pn, dn, I_X + i);
+                const double lmv = TRIAL(pm, dm, I_LAM + i);
+                const double lm = (valid && has_prev) ? lmv : 0.0;
+                // previous row's multiplier
+                gx[r] += half ? 0.0 : lm; gx[(4 + r) % 7] += (half && valid) ? lm : 0.0;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
+                for (int j = 0; j < 3; ++j) gu[j] -= bm[j] * lm;
+                if (valid && dyn) {
+                    double acc = sg * tf + xv + nu;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
-                ACC_P(xn[i] - acc);
-                sl += sg * lam;
-                lsum += fabs(lam);
-                // nu / t stationarity
-                ACC_D(ztp - ztn - lam);
-                ACC_D(w_nu - ztp - ztn);
-                ACC_P(nu - tt + stp);
-                ACC_P(-nu - tt + stn);
-                ACC_C(stp, ztp);
-                ACC_C(stn, ztn);
+                    for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) gx[j] -= ar[j] * lam;
+                    for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
+                    ACC_P(xn - acc);
+                    sl += sg * lam;
+                    lsum += fabs(lam);
+                    // nu / t stationarity
+                    ACC_D(ztp - ztn - lam);
+                    ACC_D(w_nu - ztp - ztn);
+                    ACC_P(nu - tt + stp);
+                    ACC_P(-nu - tt + stn);
+                    ACC_C(stp, ztp);
+                    ACC_C(stn, ztn);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) gu[j] -= bn[j] * lam;
+                    for (int j = 0; j < 7; ++j) gx[j] -= ar[j] * lam;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) gu[j] -= bn[j] * lam;
+                }
                 CHUNK_END
             }
             gtf_part -= sl;
         }
-        if (k == K - 1) {
-            // terminal inequalities, final-radius ball, vt equality
-            double cv, g6[6];
-            vt_reduced(x, sd.vt_des, cv, g6, nullptr);
-            ACC_P(cv);
+        // the two halves' parts of the stationarity rows meet in half 0
 #pragma unroll
-            for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
-            lsum += fabs(lvt);
-            for (int j = 0; j < 6; ++j) {
-                const double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
-                const double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
-                double gj = -sd.bT[j];
-                for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; gx[i] += sd.aT[j][i] * zj; }
-                ACC_P(gj + sj);
-                ACC_C(sj, zj);
+        for (int i = 0; i < 7; ++i) gx[i] += __shfl_xor(gx[i], 32, 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[i] += __shfl_xor(gu[i], 32, 64);
+        if (h0) {
+            if (k == K - 1) {
+                // terminal inequalities, final-radius ball, vt equality
+                double cv, g6[6];
+                vt_reduced(x, sd.vt_des, cv, g6, nullptr);
+                ACC_P(cv);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
+                lsum += fabs(lvt);
+                for (int j = 0; j < 6; ++j) {
+                    const double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
+                    const double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
+                    double gj = -sd.bT[j];
+                    for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; gx[i] += sd.aT[j][i] * zj; }
+                    ACC_P(gj + sj);
+                    ACC_C(sj, zj);
+                }
+                const double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
+                ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax + srf);
+                ACC_C(srf, zrf);
+                for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrf;
             }
-            const double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
-            ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax + srf);
-            ACC_C(srf, zrf);
-            for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrf;
-        }
-        if (has_prev) {
+            if (has_prev) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) ACC_D(gx[i]);
-        }
+                for (int i = 0; i < 7; ++i) ACC_D(gx[i]);
+            }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ACC_D(gu[i]);
+            for (int i = 0; i < 3; ++i) ACC_D(gu[i]);
+        }
     }
     // tf stationarity and range constraints (lane 0 adds them after the reduction of gtf_part)
     double gtf = wave_sum(gtf_part);
@@ -487,13 +505,16 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
     const int K = s.K;
     const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     const double tf = s.itg[G_TF];
-    for (int k = lane; k < K; k += 64) {
+    const int half = HALF_OF(lane);
+    const bool h0 = (half == 0);
+    for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
         gf64 *nb = s.nb + (size_t)k * NB_N;
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
         // ---- chunk 0: objective, thrust ball, radius balls; next node's x, u for the dynamics residual ----
-        double x[7], u[3], xn[7], un[3], gx[7], gu[3], Wx3[9];
+        // (chunk 0 is computed by both halves and stored by half 0)
+        double x[7], u[3], un[3], gx[7], gu[3], Wx3[9];
         double zh_rmax = 0.0, sig_rmax = 0.0, zrmax;
         {
             double bs[6], xb[7], ub[3];
@@ -504,8 +525,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
 #pragma unroll
             for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
             const auto pn = p.node(dyn ? 1 : 0);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) xn[i] = pn[I_X + i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) un[i] = pn[I_U + i];
             const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
@@ -546,13 +565,15 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                         Wx3[i * 3 + j] += (i == j ? 2.0 * zrmax : 0.0) + sig_rmax * 4.0 * x[i] * x[j] + sig * rbv[i] * rbv[j];
                 }
             }
+            if (h0) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
+                for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
+                for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
-            if (k != K - 1) {
+                for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
+            }
+            if (h0 && k != K - 1) {
                 // stage Hessian of x: diagonal + the 3x3 position block (the terminal node's slot is written below)
 #pragma unroll
                 for (int i = 0; i < 7; ++i)
@@ -562,12 +583,17 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             }
         }
         CHUNK_END
-        // ---- chunks 1..7: component i of the virtual-control block (t eliminated, D and rho kept without
-        //      multipliers) and of the dynamics residual e_k ----
-        if (dyn) {
-            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k), xi = s.xit(k);
+        // ---- four rounds: component i = 4*half + r of the virtual-control block (t eliminated, D and rho kept
+        //      without multipliers) and of the dynamics residual e_k ----
+        {
+            const auto A = s.At(dyn ? k : 0), Bn = s.Bnt(dyn ? k : 0), Bp = s.Bpt(dyn ? k : 0), Sg = s.Sigt(dyn ? k : 0), xi = s.xit(dyn ? k : 0);
+            const auto pn = p.node(dyn ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int r = 0; r < 4; ++r) {
+                const int iv = 4 * half + r;
+                const bool valid = (iv < 7) && dyn;
+                const int i = (iv < 7) ? iv : 6;
+                const double xni = pn[I_X + i];
                 double ar[7], bn[3], bp[3];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) ar[j] = A[i * 7 + j];
@@ -588,18 +614,18 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
-                nb[N_D + i] = dd; ns[NS_D + i] = dd;
-                ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
-                ns[NS_RHO + i] = (zh1 - zh2) - (bb * ia) * gt;
-                ns[NS_E + i] = xn[i] - acc;
+                if (valid) {
+                    nb[N_D + i] = dd; ns[NS_D + i] = dd;
+                    ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
+                    ns[NS_RHO + i] = (zh1 - zh2) - (bb * ia) * gt;
+                    ns[NS_E + i] = xni - acc;
+                }
                 CHUNK_END
             }
         }
-        if (k == K - 1) {
-            double Wx[49];
-            for (int i = 0; i < 49; ++i) Wx[i] = 0.0;
-            for (int i = 0; i < 7; ++i) Wx[i * 8] = 2.0 * w_tr + delta_w;
-            // terminal node: soft Hessian / gradient + the five rank-1 barrier terms
+        if (h0 && k == K - 1) {
+            // terminal node: soft gradient, the five rank-1 barrier terms, the pieces of the terminal Hessians (the
+            // 7x7 matrices themselves are assembled by 49 lanes after the loop)
             double cv, g6[6];
             vt_reduced(x, sd.vt_des, cv, g6, sd.Hv);
             sd.cv = cv;
@@ -615,10 +641,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
             const double grf = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
             const double sigrf = zrf / srf, zhrf = mu / srf + sigrf * (grf + srf);
-            for (int i = 0; i < 49; ++i) sd.WxKsoft[i] = Wx[i];
-            for (int i = 0; i < 3; ++i) sd.WxKsoft[i * 8] += 2.0 * (zrmax + zrf);
-            for (int i = 0; i < 6; ++i)
-                for (int j = 0; j < 6; ++j) sd.WxKsoft[i * 7 + j] += lvt * sd.Hv[i * 6 + j];
+            sd.red[0] = 2.0 * (zrmax + zrf);          // diagonal of the two radius balls at the terminal node
+            sd.red[1] = lvt;
             for (int i = 0; i < 7; ++i) sd.gxKsoft[i] = gx[i];
             const int rows[NTERM] = {0, 1, 3, 5, -1};
             for (int t = 0; t < NTERM; ++t) {
@@ -630,23 +654,27 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             sd.tw[2] = sig[3] + sig[4]; sd.tgh[2] = zh[3] - zh[4];
             sd.tw[3] = sig[5]; sd.tgh[3] = zh[5];
             sd.tw[4] = sig_rmax + sigrf; sd.tgh[4] = zh_rmax + zhrf;
-            // Hessian used inside the recursion: capped share of the rank-1 weights + AL term for vt
-            for (int i = 0; i < 49; ++i) sd.WxK[i] = sd.WxKsoft[i];
-            for (int t = 0; t < NTERM; ++t) {
-                const double wi = fmin(sd.tw[t], kTermCap);
-                sd.twin[t] = wi;
-                for (int i = 0; i < 7; ++i)
-                    for (int j = 0; j < 7; ++j) sd.WxK[i * 7 + j] += wi * sd.ta[t][i] * sd.ta[t][j];
-            }
+            // capped share of the rank-1 weights kept inside the recursion, AL weight of the vt row
+            for (int t = 0; t < NTERM; ++t) sd.twin[t] = fmin(sd.tw[t], kTermCap);
             double hn = 0.0, an = 0.0;
             for (int i = 0; i < 36; ++i) hn += sd.Hv[i] * sd.Hv[i];
             for (int i = 0; i < 6; ++i) an += g6[i] * g6[i];
             sd.gam = (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
-            for (int i = 0; i < 7; ++i)
-                for (int j = 0; j < 7; ++j) sd.WxK[i * 7 + j] += sd.gam * sd.avt[i] * sd.avt[j];
         }
-        // the terminal node's slot carries the Hessian the recursion uses (the soft part stays in LDS for the residual)
-        if (k == K - 1) { for (int i = 0; i < 49; ++i) nb[N_WX + i] = sd.WxK[i]; }
+    }
+    __syncthreads();
+    // terminal Hessians, one lane per element: soft part (objective, radius balls, lam_vt * Hessian of the vt row) for
+    // the residuals; + capped rank-1 terms + AL term for the recursion, which reads it from the terminal node's slot
+    if (lane < 49) {
+        const int i = lane / 7, j = lane - 7 * i;
+        double soft = (i == j) ? 2.0 * w_tr + delta_w + (i < 3 ? sd.red[0] : 0.0) : 0.0;
+        if (i < 6 && j < 6) soft += sd.red[1] * sd.Hv[i * 6 + j];
+        double full = soft;
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) full += sd.twin[t] * sd.ta[t][i] * sd.ta[t][j];
+        full += sd.gam * sd.avt[i] * sd.avt[j];
+        sd.WxKsoft[lane] = soft; sd.WxK[lane] = full;
+        s.nb[(size_t)(K - 1) * NB_N + N_WX + lane] = full;
     }
     if (lane == 0) {
         const double tf = s.itg[G_TF];
@@ -1430,10 +1458,12 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
 #define CHK(v) { if (!(fabs(v) < 1e300)) bad = 1.0; }
     const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
 #define LIM(v, dv) { const double v_ = (v), d_ = (dv); if (d_ < 0.0) amax = fmin(amax, -tau * v_ / d_); }
-    for (int k = lane; k < K; k += 64) {
+    const int half = HALF_OF(lane);
+    const bool h0 = (half == 0);
+    for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), d = s.drn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
-        // chunk 0: the three ball pairs
+        // chunk 0 (both halves compute, half 0 stores; the step limit and the finite flag are idempotent): the ball pairs
         double x[7], dx[7];
         {
             double u[3], du[3], bs[6];
@@ -1474,20 +1504,26 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
                 LIM(srmin, o[4]); LIM(zrmin, o[5]);
             }
             // pairs a node does not own keep the zero the direction record was reset to
-            d[I_SU] = o[0]; d[I_ZU] = o[1];
-            if (k >= 1) { d[I_SRMAX] = o[2]; d[I_ZRMAX] = o[3]; }
-            if (k >= 1 && k <= K - 2) { d[I_SRMIN] = o[4]; d[I_ZRMIN] = o[5]; }
+            if (h0) {
+                d[I_SU] = o[0]; d[I_ZU] = o[1];
+                if (k >= 1) { d[I_SRMAX] = o[2]; d[I_ZRMAX] = o[3]; }
+                if (k >= 1 && k <= K - 2) { d[I_SRMIN] = o[4]; d[I_ZRMIN] = o[5]; }
+            }
         }
         CHUNK_END
-        // chunks 1..7: component i of the eliminated t and of the two L1 slack pairs
-        if (k <= K - 2) {
+        // four rounds: component i = 4*half + r of the eliminated t and of the two L1 slack pairs
+        {
+            const bool dyn = (k <= K - 2);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int r = 0; r < 4; ++r) {
+                const int iv = 4 * half + r;
+                const bool valid = (iv < 7) && dyn;
+                const int i = (iv < 7) ? iv : 6;
                 const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
                 const double stn = p[I_STN + i], ztn = p[I_ZTN + i], dnu = d[I_NU + i], dlam = d[I_LAM + i];
                 const double gt = ns[NS_GT + i], bb = ns[NS_BB + i], aa = ns[NS_AA + i];
                 const double dt = (-gt - bb * dnu) * rcp_pos(aa);
-                CHK(dnu); CHK(dlam); CHK(dt);
+                if (valid) { CHK(dnu); CHK(dlam); CHK(dt); }
                 const double g1 = nu - tt, g2 = -nu - tt;
                 const double ip = rcp_pos(stp), in = rcp_pos(stn);
                 const double s1 = ztp * ip, s2 = ztn * in;
@@ -1495,15 +1531,17 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
                 const double dg1 = dnu - dt, dg2 = -dnu - dt;
                 const double dstp = -(g1 + stp) - dg1, dztp = zh1 + s1 * dg1 - ztp;
                 const double dstn = -(g2 + stn) - dg2, dztn = zh2 + s2 * dg2 - ztn;
-                LIM(stp, dstp); LIM(ztp, dztp);
-                LIM(stn, dstn); LIM(ztn, dztn);
-                d[I_T + i] = dt;
-                d[I_STP + i] = dstp; d[I_ZTP + i] = dztp;
-                d[I_STN + i] = dstn; d[I_ZTN + i] = dztn;
+                if (valid) {
+                    LIM(stp, dstp); LIM(ztp, dztp);
+                    LIM(stn, dstn); LIM(ztn, dztn);
+                    d[I_T + i] = dt;
+                    d[I_STP + i] = dstp; d[I_ZTP + i] = dztp;
+                    d[I_STN + i] = dstn; d[I_ZTN + i] = dztn;
+                }
                 CHUNK_END
             }
         }
-        if (k == K - 1) {
+        if (h0 && k == K - 1) {
             for (int j = 0; j < 6; ++j) {
                 double gj = -sd.bT[j], dg = 0.0;
                 for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; dg += sd.aT[j][i] * dx[i]; }
@@ -1547,10 +1585,12 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
                              const double c_ = mu * rcp_pos(s_); \
                              z_ = fmax(fmin(z_, kKappaSigma * c_), c_ * (1.0 / kKappaSigma)); (sv) = s_; (zv) = z_; }
     const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
-    for (int k = lane; k < K; k += 64) {
+    const int half = HALF_OF(lane);
+    const bool h0 = (half == 0);
+    for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), d = s.drn(k);
         const auto rb = s.rbn(k);
-        // chunk 0: x, u and the three ball pairs
+        // chunk 0 (both halves compute, half 0 stores): x, u and the three ball pairs
         {
             double v[16], dv[16];
 #pragma unroll
@@ -1564,16 +1604,21 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
             SAFE(v[10], v[11], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u);
             if (k >= 1) SAFE(v[12], v[13], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax);
             if (k >= 1 && k <= K - 2) SAFE(v[14], v[15], -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin);
+            if (h0) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) p[I_X + i] = v[i];
+                for (int i = 0; i < 10; ++i) p[I_X + i] = v[i];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) p[I_SU + i] = v[10 + i];
+                for (int i = 0; i < 6; ++i) p[I_SU + i] = v[10 + i];
+            }
         }
         CHUNK_END
-        // chunks 1..7: component i of nu, t, lam and of the two L1 slack pairs
+        // four rounds: component i = 4*half + r of nu, t, lam and of the two L1 slack pairs
         const bool dyn = (k <= K - 2);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int r = 0; r < 4; ++r) {
+            const int iv = 4 * half + r;
+            const bool valid = iv < 7;
+            const int i = valid ? iv : 6;
             const int off[7] = {I_NU + i, I_T + i, I_LAM + i, I_STP + i, I_ZTP + i, I_STN + i, I_ZTN + i};
             double v[7], dv[7];
 #pragma unroll
@@ -1584,8 +1629,10 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
                 SAFE(v[3], v[4], v[0] - v[1]);
                 SAFE(v[5], v[6], -v[0] - v[1]);
             }
+            if (valid) {
 #pragma unroll
-            for (int q = 0; q < 7; ++q) p[off[q]] = v[q];
+                for (int q = 0; q < 7; ++q) p[off[q]] = v[q];
+            }
             CHUNK_END
         }
     }
