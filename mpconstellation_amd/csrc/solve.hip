@@ -33,7 +33,11 @@ enum { N_WX = 0, N_WU = 49, N_D = 58, NB_N = 65 };
 enum { NS_AA = 0, NS_BB = 7, NS_GT = 14, NS_RHO = 21, NS_GX = 28, NS_GU = 35, NS_E = 38, NS_D = 45, NS_N = 52 };
 // factorisation per node
 // factorisation per node, stored in exactly the order the sweeps stage it through LDS (one contiguous block)
-enum { F_A = 0, F_G = 49, F_PT = 98, F_MINV = 147, F_KG = 196, F_BH = 217, F_BPM = 238, F_QI = 259, F_D = 268, FAC_USED = 275, FAC_N = 280 };
+// (what the factorisation produces: G, Minv, Kg, Bh, Qi, and Pt for the refinement's backward sweep) ...
+enum { F_G = 0, F_MINV = 49, F_KG = 98, F_BH = 119, F_QI = 140, F_PT = 149, FAC_USED = 198, FAC_N = 200 };
+// ... followed, in the sweeps' LDS copy only, by the node's inputs fetched from where they already are: A (head of the
+// stage record; the 15 doubles after it are B_kn, unused), Bpm (B_kp of the record before) and D (Newton record)
+enum { F_A = 256, F_BPM = 320, F_D = 341, FLAT_N = 384 };
 // channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
 enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, CH_N = 104 };
 // stored trajectory of one channel at one node
@@ -714,7 +718,7 @@ constexpr int OPS_IN = 156;
 struct Scratch {   // LDS working set of the recursion
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
         StageOps ops[2];
-        double flat[2][FAC_N];     // sweep operands of one node, double-buffered (same layout as the fac record)
+        double flat[2][FLAT_N];    // sweep operands of one node, double-buffered (fac record + A, Bpm, D)
     };
     double Pn[49], WlLi[98], PtA[49], Qyy[49];
     double sink[64];               // target of the lanes that have nothing to write in a branch-free phase
@@ -788,7 +792,7 @@ __device__ __forceinline__ ChanIn chan_mask(const ChanRaw &cr, int c, int r, boo
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
 // With fuse_sweep the backward linear-term sweep of all 8 channels rides along: node k's p_k, qu_k are formed
 // right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
-__device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratch &w, int lane, bool fuse_sweep)
+__device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
 {
     const Sat s = s_in;   // private copy: lives in registers, is not re-read after every LDS fence
     const int K = s.K;
@@ -948,11 +952,12 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
                 }
                 const double pt = 0.5 * ((w.Pn[lane] - a1) + (w.Pn[mj * 7 + mi] - a1t));
                 o.Pt[lane] = pt; o.G[lane] = a2; o.Minv[lane] = a3;
-                fac[F_PT + lane] = pt; fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
+                fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
+                if (keep_pt) fac[F_PT + lane] = pt;
             }
             wsync();
         } else {
-            if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_PT + lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; }
+            if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; if (keep_pt) fac[F_PT + lane] = 0.0; }
             wsync();
         }
         FT_MARK(3)
@@ -975,26 +980,30 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; w.Quu[e] += dotN<7>(o.Bh + i, 3, w.PtBh + j, 3); }
         wsync();
         FT_MARK(5)
-        // P7+P8: every lane inverts the 3x3 itself; Kg = Qi Quy
+        // P7-P9: every lane inverts the 3x3 itself; P_k = sym(Qyy - Quy^T Qi Quy) straight from its own two columns of
+        // Quy (no exchange of the gain on the way); the gain Kg = Qi Quy goes to LDS / the factor record for the sweeps
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
+        if (lane < 49) {
+            double qi[3], qj[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + mi]; qj[l] = w.Quy[l * 7 + mj]; }
+            double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, mj)
+                const double ki = Qi[l * 3] * qi[0] + Qi[l * 3 + 1] * qi[1] + Qi[l * 3 + 2] * qi[2];     // Kg(l, mi)
+                a1 -= qi[l] * kj; a2 -= qj[l] * ki;
+            }
+            w.Pn[lane] = 0.5 * (a1 + a2);
+        }
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
             const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
-            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane]; fac[F_BPM + lane] = o.Bpm[lane];
+            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane];
         }
         if (lane < 9) fac[F_QI + lane] = Qi[lane];
-        if (lane < 7) fac[F_D + lane] = o.D[lane];
-        wsync();
         FT_MARK(6)
-        // P9: P_k = sym(Qyy - Quy^T Kg)
-        if (lane < 49) {
-            double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
-#pragma unroll
-            for (int l = 0; l < 3; ++l) { a1 -= w.Quy[l * 7 + mi] * o.Kg[l * 7 + mj]; a2 -= w.Quy[l * 7 + mj] * o.Kg[l * 7 + mi]; }
-            const double pk = 0.5 * (a1 + a2);
-            w.Pn[lane] = pk; fac[F_A + lane] = o.A[lane];
-        }
         FT_MARK(7)
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
         if (fuse_sweep) cur = dyn ? chan_mask(nraw, sc, sr, sact) : chan_inputs(s, sd, K - 1, sc, sr, sact);
@@ -1019,21 +1028,30 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
 // Stage matrices are staged through a double-buffered LDS copy (prefetched one node ahead); each lane reads
 // its own rows/columns into registers and the channel vectors travel by ds_bpermute inside the 8-lane group,
 // so a node costs one barrier (the buffer swap).
-struct SweepPre { double v[5]; };
+struct SweepPre { double v[6]; };
 
 __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
+    const int K = s.K;
     cgf64 *fac = s.fac + (size_t)k * FAC_N;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre.v[q] = fac[lane + 64 * q];
-    pre.v[4] = (lane + 256 < FAC_USED) ? fac[lane + 256] : 0.0;
+    for (int q = 0; q < 3; ++q) pre.v[q] = fac[lane + 64 * q];
+    pre.v[3] = fac[(lane + 192 < FAC_N) ? lane + 192 : FAC_N - 1];
+    // A: head of stage record k; Bpm: B_kp of record k-1; D: Newton record k (what a node lacks is zeroed when stashed)
+    cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
+    cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
+    cgf64 *nb = s.nb + (size_t)k * NB_N;
+    pre.v[4] = stk[lane];
+    cgf64 *p5 = (lane < 21) ? stm + 70 + lane : nb + N_D + ((lane < 28) ? lane - 21 : 0);
+    pre.v[5] = *p5;
 }
 
-__device__ __forceinline__ void sweep_stash_mats(double *f, int lane, const SweepPre &pre)
+__device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int lane, const SweepPre &pre)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) f[lane + 64 * q] = pre.v[q];
-    if (lane + 256 < FAC_N) f[lane + 256] = pre.v[4];
+    f[F_A + lane] = (k <= K - 2) ? pre.v[4] : 0.0;
+    f[F_BPM + lane] = ((lane < 21) ? (k >= 1) : (k <= K - 2)) ? pre.v[5] : 0.0;
 }
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
@@ -1046,7 +1064,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
     sweep_fetch_mats(s, K - 1, lane, pre);
-    sweep_stash_mats(w.flat[(K - 1) & 1], lane, pre);
+    sweep_stash_mats(w.flat[(K - 1) & 1], K, K - 1, lane, pre);
     ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
     double pnext = 0.0;
     __syncthreads();
@@ -1082,7 +1100,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
             if (r < 3) ch[C_QU + c * 3 + r] = qu;
             pnext = p;
         }
-        if (k >= 1) sweep_stash_mats(w.flat[(k - 1) & 1], lane, pre);
+        if (k >= 1) sweep_stash_mats(w.flat[(k - 1) & 1], K, k - 1, lane, pre);
         cur = nxt;
         wsync();
     }
@@ -1100,7 +1118,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
     sweep_fetch_mats(s, 0, lane, pre);
-    sweep_stash_mats(w.flat[0], lane, pre);
+    sweep_stash_mats(w.flat[0], K, 0, lane, pre);
     ChanIn cur = chan_inputs(s, sd, 0, c, r, act);
     ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
     // qu_k, p_{k+1} and Sigma_k of the lane's channel / component: branch-free loads, masked after arrival
@@ -1160,7 +1178,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
         }
         FT_MARK(13)
         if (k + 1 < K) {
-            sweep_stash_mats(w.flat[(k + 1) & 1], lane, pre);
+            sweep_stash_mats(w.flat[(k + 1) & 1], K, k + 1, lane, pre);
             cur = chan_mask(nraw, c, r, act);
             quc = (act && r < 3) ? qun : 0.0; pnc = (act && k + 1 <= K - 2) ? pnn : 0.0; sgc = sgn;
         }
@@ -1819,8 +1837,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             PT_BEGIN
             initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);      // right-hand side of the first solve = the Newton blocks
             PT_END(5)
+            // iterative refinement only once a terminal barrier weight is stiff enough to cost digits
+            double twmax = 0.0;
+            for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
+            const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
             PT_BEGIN
-            bool ok = riccati_factor(s, sd, w, lane, true);          // factorisation + backward sweep of all 8 channels
+            bool ok = riccati_factor(s, sd, w, lane, true, passes > 1);   // factorisation + backward sweep of all 8 channels
             PT_END(2)
 #ifdef MPCX_ITER_LOG
             if (!ok) fail_mask += 1;
@@ -1828,10 +1850,6 @@ __global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
             if (ok) {
                 // the direction starts from (0, ..., -lam, -lam_vt) so that the first right-hand side carries no
                 // multipliers; combine_channels writes it with that starting value (no separate reset pass)
-                // iterative refinement only once a terminal barrier weight is stiff enough to cost digits
-                double twmax = 0.0;
-                for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
-                const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
                 for (int pass = 0; pass < passes && ok; ++pass) {
                     if (pass > 0) {
                         PT_BEGIN
