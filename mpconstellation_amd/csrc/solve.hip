@@ -695,17 +695,31 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
 }
 
 // ---- tiny dense helpers on LDS matrices --------------------------------------------------------
-// symmetric 3x3 inverse with positive-definiteness test (leading minors)
+// Inverse of a symmetric positive definite 3x3 through its LDL^T factorisation; false if a pivot is not positive.
+// (Q_uu carries the thrust-ball barrier term sigma 4 u u^T, which reaches 1e12 when the ball is active: the cofactor
+// formula and a determinant test lose every digit there and report breakdowns that are not; the pivots do not.)
 __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 {
     const double a = Q[0], b = Q[1], c = Q[2], d = Q[4], e = Q[5], f = Q[8];
-    const double m2 = a * d - b * b;
-    const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
-    const bool ok = (a > 0.0) && (m2 > 0.0) && (det > 0.0);
-    const double id = ok ? rcp_pos(det) : 0.0;
-    Qi[0] = (d * f - e * e) * id; Qi[1] = (c * e - b * f) * id; Qi[2] = (b * e - c * d) * id;
-    Qi[3] = Qi[1]; Qi[4] = (a * f - c * c) * id; Qi[5] = (b * c - a * e) * id;
-    Qi[6] = Qi[2]; Qi[7] = Qi[5]; Qi[8] = (a * d - b * b) * id;
+    const double d1 = a;
+    const double r1 = rcp_pos(d1 > 0.0 ? d1 : 1.0);
+    const double l21 = b * r1, l31 = c * r1;
+    const double d2 = d - l21 * b;
+    const double r2 = rcp_pos(d2 > 0.0 ? d2 : 1.0);
+    const double t32 = e - l31 * b;
+    const double l32 = t32 * r2;
+    const double d3 = f - l31 * c - l32 * t32;
+    const double r3 = rcp_pos(d3 > 0.0 ? d3 : 1.0);
+    const bool ok = (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+    // rows of L^-1 (unit lower): m1 = (1, 0, 0), m2 = (-l21, 1, 0), m3 = (l21 l32 - l31, -l32, 1); Qi = sum_k m_k m_k^T / d_k
+    const double m31 = l21 * l32 - l31, m32 = -l32, m21 = -l21;
+    Qi[0] = r1 + m21 * m21 * r2 + m31 * m31 * r3;
+    Qi[1] = m21 * r2 + m31 * m32 * r3;
+    Qi[2] = m31 * r3;
+    Qi[4] = r2 + m32 * m32 * r3;
+    Qi[5] = m32 * r3;
+    Qi[8] = r3;
+    Qi[3] = Qi[1]; Qi[6] = Qi[2]; Qi[7] = Qi[5];
     return ok;
 }
 

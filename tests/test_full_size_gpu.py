@@ -65,6 +65,25 @@ def test_full_size_properties(S, K):
     assert np.array_equal(res.iters, res2.iters)
 
 
+def test_saturated_thrust_scenarios_converge():
+    """References flown at 3x the benchmark's thrust: the optimal thrust profile leans on its bounds and Q_uu gets
+    barrier weights many orders above its objective part.  Regression for the 3x3 inverse: with the cofactor formula
+    and a determinant test a fifth of these reported breakdowns that were not and ended in MPCX_ST_NUMERIC."""
+    from mpconstellation_amd import mpc_step_batch, _ffi
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+    from mpconstellation_amd.simulator import propagate_batch
+    S, K = 256, 30
+    y0, consts = normalize_batch(constellation_states(4096, first=0, count=S))
+    for thrust, tf in ((1.5, 2.0), (1.5, 0.5)):
+        xbar, st, _ = propagate_batch(y0, np.full(S, tf), consts, (_ffi.CTRL_TANGENTIAL, np.array([thrust]), 0, None), K)
+        assert (st == 0).all()
+        ubar = np.ascontiguousarray(tangential_thrust(xbar, thrust))
+        r_des = np.linalg.norm(xbar[:, :3, -1], axis=1)
+        res = mpc_step_batch(xbar, ubar, np.full(S, tf), consts, r_des)
+        assert (res.status == 0).sum() >= S - 1 and np.sort(res.kkt)[S - 2] <= 1e-8
+        assert np.linalg.norm(res.U, axis=1).max() <= 5 + 1e-6
+
+
 def test_satellites_are_independent_units():
     """What the multi-GPU sharding relies on: a satellite's result does not depend on which batch, which position or
     which block it is solved in (bit for bit)."""
