@@ -123,13 +123,14 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// 1/d for d > 0 well inside the normal range: hardware seed + three Newton steps (the full IEEE division
-// sequence with its scaling/fix-up is not needed for pivots and determinants)
+// 1/d for d > 0 well inside the normal range: hardware seed + two Newton steps (the full IEEE division sequence
+// with its scaling / fix-up is not needed for pivots, slacks and determinants).  Measured on gfx950 over 1e-40..1e40
+// (tools/rcp_accuracy.hip): seed 4.5e-8 relative, one step 2.1e-15, two steps 1.1e-16 = half an ulp.
 __device__ __forceinline__ double rcp_pos(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
 #pragma unroll
-    for (int n = 0; n < 3; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    for (int n = 0; n < 2; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
     return r;
 }
 
