@@ -207,7 +207,10 @@ __device__ __forceinline__ void node_integrand(const RhsCtx &p, double *rec, con
 }
 
 template <int LAYOUT>
-__global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a)
+#ifndef MPCX_DISC_WAVES
+#define MPCX_DISC_WAVES 1      // waves per SIMD the register allocation is bounded for (360 registers at 1)
+#endif
+__global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArgs a)
 {
     __shared__ double lds[8 * kRec];
     const int lane = threadIdx.x;
