@@ -955,17 +955,19 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         FT_MARK(1)
         if (dyn) {
             FT_MARK(2)
-            // P4: Pt = sym(Pn - X1^T R X1) ; G = X1^T R X2 ; Minv = X2^T R X2 with R = diag(1/d)
+            // P4: Pt = Pn - X1^T R X1 ; G = X1^T R X2 ; Minv = X2^T R X2 with R = diag(1/d).  Pt is symmetric by
+            // construction: lanes (i,j) and (j,i) evaluate the same expression in (min, max) order on a symmetric Pn
             if (lane < 49) {
-                double a1 = 0.0, a1t = 0.0, a2 = 0.0, a3 = 0.0;
+                const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
+                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int l = 0; l < 7; ++l) {
-                    const double x1i = w.WlLi[l * 14 + mi], x1j = w.WlLi[l * 14 + mj];
+                    const double x1i = w.WlLi[l * 14 + mi], x1lo = w.WlLi[l * 14 + lo], x1hi = w.WlLi[l * 14 + hi];
                     const double x2i = w.WlLi[l * 14 + 7 + mi], x2j = w.WlLi[l * 14 + 7 + mj];
-                    a1 += x1i * (rd[l] * x1j); a1t += x1j * (rd[l] * x1i);
+                    a1 += x1lo * (rd[l] * x1hi);
                     a2 += x1i * (rd[l] * x2j); a3 += x2i * (rd[l] * x2j);
                 }
-                const double pt = 0.5 * ((w.Pn[lane] - a1) + (w.Pn[mj * 7 + mi] - a1t));
+                const double pt = w.Pn[lo * 7 + hi] - a1;
                 o.Pt[lane] = pt; o.G[lane] = a2; o.Minv[lane] = a3;
                 fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
                 if (keep_pt) fac[F_PT + lane] = pt;
@@ -1000,17 +1002,20 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
         if (lane < 49) {
+            const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
             double qi[3], qj[3];
 #pragma unroll
-            for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + mi]; qj[l] = w.Quy[l * 7 + mj]; }
-            double a1 = w.Qyy[lane], a2 = w.Qyy[mj * 7 + mi];
+            for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
+            // (qi, qj) = columns (min, max) of Quy: lanes (i,j) and (j,i) evaluate the same expression, P_k is
+            // symmetric by construction; Qyy is symmetrised through the same (min, max) read (rounding-level asymmetry
+            // of A^T (Pt A) otherwise)
+            double a1 = 0.5 * (w.Qyy[lane] + w.Qyy[mj * 7 + mi]);
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
-                const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, mj)
-                const double ki = Qi[l * 3] * qi[0] + Qi[l * 3 + 1] * qi[1] + Qi[l * 3 + 2] * qi[2];     // Kg(l, mi)
-                a1 -= qi[l] * kj; a2 -= qj[l] * ki;
+                const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, hi)
+                a1 -= qi[l] * kj;
             }
-            w.Pn[lane] = 0.5 * (a1 + a2);
+            w.Pn[lane] = a1;
         }
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
