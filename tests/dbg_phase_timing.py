@@ -23,7 +23,7 @@ tot = t[:, 0].sum()
 print("iters", r.iters[0], "status", r.status[0], "total cycles(100MHz ticks?)", tot)
 for n, (cyc, cnt) in zip(names, t):
     if cnt: print(f"{n:28s} {cyc/tot*100:6.2f}%  calls {int(cnt):5d}  per call {cyc/cnt:10.0f}")
-fn = ["fetch issue", "P1 Bh,WxBp,LDL", "P3 fwd subst", "P4 Pt,G,Minv", "P5", "P6", "P7+8 inv3,Kg", "P9 P_k", "fused bwd sweep", "stash+sync",
+fn = ["fetch issue", "P1-3 Bh,WxBp,LDL,subst + bwd sweep of k+1", "(mark only)", "P4 Pt,G,Minv", "P5", "P6", "P7-9 inv3,P_k,Kg", "(mark only)", "sweep inputs", "stash+sync",
       "fwd: fetch", "fwd: u,x", "fwd: yhat,nu,lam", "fwd: store", "fwd: stash", "-"]
 f = r.NU[0].ravel()[24:40]
 nn = max(1, int(t[2, 1])) * x.shape[1]
