@@ -202,6 +202,8 @@ def main():
         if n_scp > 1:
             out["scp_iterations_per_s"] = value * n_scp
         h = run.host
+        # device results of the timed steps (first SCP iteration's inputs are the host arrays only when n_scp == 1)
+        dev_res = (run.d_X.cpu().numpy(), run.d_U.cpu().numpy(), run.d_tfo.cpu().numpy(), status) if n_scp == 1 else None
         if world == 1 and not args.no_also:
             # the same step through the host-pointer entry point (numpy in / numpy out): staging allocation, H2D of the
             # inputs and D2H of the results inside the timed region -- reported beside `value`, never as `value`
@@ -225,29 +227,43 @@ def main():
                                          "traffic": measured_traffic("S4096_K30"),
                                          "note": "BASELINE configs[2], same run, 3 steps after 1 warm-up"}}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample)
+            out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)
+            if err: out["trajectory_error_vs_cpu_oracle"] = err
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
 
-def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n):
+def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n, dev_res=None):
     """The CPU oracle (oracle/: C discretize + numpy interior point) timed on one host core on the first n
-    satellites of the same workload.  Reported baseline only; pyomo+ipopt are not installed on this image."""
+    satellites of the same workload.  Reported baseline only; pyomo+ipopt are not installed on this image.
+    With the device results of the same satellites it also returns BASELINE.json's 'trajectory error' against the
+    stand-in for ipopt (the oracle): max and 99th percentile over the sample of max_k |x_gpu - x_cpu|_inf etc."""
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib as O
     import nlp_ipm as N
     n = min(n, xbar.shape[0])
     t0 = time.perf_counter(); ok = 0
+    ex, eu, et = [], [], []
     for i in range(n):
         d = O.discretize(xbar[i], ubar[i], float(tfbar[i]), consts[i])
         terms = O.constraint_terms(xbar[i], ubar[i], consts[i][0])
         P = N.MpcProblem(xbar[i], ubar[i], float(tfbar[i]), consts[i][0], d, terms, {"r_des": float(r_des[i])})
         r = N.solve(P)
         ok += int(r["status"] in (0, 7))
+        if dev_res is not None and r["status"] == 0 and dev_res[3][i] == 0:
+            ex.append(np.abs(dev_res[0][i] - r["X"]).max()); eu.append(np.abs(dev_res[1][i] - r["U"]).max())
+            et.append(abs(dev_res[2][i] - r["tf"]))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": 1, "kind": "port",
+    base = {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": 1, "kind": "port",
             "sample": f"first {n} satellites of the workload, oracle/ (C discretize + numpy IPM), {ok}/{n} converged, {dt:.1f} s"}
+    err = None
+    if ex:
+        q = lambda v: {"max": float(np.max(v)), "p99": float(np.percentile(v, 99))}
+        err = {"x": q(ex), "u": q(eu), "tf": q(et), "satellites": len(ex), "stated_tolerance": 5e-6,
+               "note": "normalised units; both sides converged to ipopt's scaled error 1e-8 on a flat objective (w_tr = 0.002); "
+                       "the reference's ipopt itself is not available on this image (parity unpinned, DESIGN.md section 2)"}
+    return base, err
 
 
 if __name__ == "__main__":

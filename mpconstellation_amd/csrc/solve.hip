@@ -1731,7 +1731,10 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 #define PT_END(i)
 #endif
 
-__global__ __launch_bounds__(64, 2) void solve_kernel(SolveArgs a)
+#ifndef MPCX_SOLVE_WAVES
+#define MPCX_SOLVE_WAVES 2     // waves per SIMD the register allocation is bounded for (256 registers; 3 was measured slower)
+#endif
+__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
 {
     PT_DECL
     __shared__ SatData sd;
