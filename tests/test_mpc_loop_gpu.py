@@ -46,3 +46,43 @@ def test_run_batched_and_csv(tmp_path, monkeypatch):
     assert arr.shape == (40, 7)
     ids = [f for f in files if str(sats[1].id) in f]
     assert np.allclose(np.loadtxt(ids[0], delimiter=","), scale.redim_state(data[sats[1].id]).T)
+
+
+def test_scp_update_vs_oracle_chain():
+    """OptimalController.update (control.py:166-235: reference rollout, then 2 x (extract_uk, discretize, solve, nonlinear
+    re-rollout under the optimised FOH sequence)) on the device against the same chain built from the CPU oracle's
+    pieces (the second iteration's problem depends on the first one's solution and on a rollout through it)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import oracle_lib as O, nlp_ipm as N
+    from mpconstellation_amd import Satellite, SatelliteScale, OptimalController
+    sat = Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+    base_res, horizon, r_des = 15, 2, 1.2
+    c = OptimalController(sats=[sat], base_res=base_res, tf_horizon=horizon, tf_interval=1, plot_inter=False,
+                          opt_verbose=False, r_des=r_des)
+    c.update()
+    assert c.last_status == [0, 0]
+    # the oracle chain
+    scale = SatelliteScale(sat=sat)
+    cst = scale.get_normalized_constants().as_vector()
+    y0 = scale.normalize_state(sat.get_state_vector())
+    K = int(base_res * horizon)
+    ctrl = O.make_ctrl(2, thrust=(0.5, 0.0, 0.0))
+    x = O.propagate(y0, horizon, cst, ctrl, K)[0]; t = np.linspace(0, 1, K)
+    tf_u = horizon
+    for i in range(2):
+        u_bar = O.extract_uk(x, t, ctrl)
+        d = O.discretize(x, u_bar, tf_u, cst)
+        P = N.MpcProblem(x, u_bar, tf_u, cst[0], d, O.constraint_terms(x, u_bar, cst[0]),
+                         {"r_des": r_des, "eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": horizon})
+        r = N.solve(P)
+        assert r["status"] == 0
+        tf_u = r["tf"]
+        ctrl = O.make_ctrl(3, useq=np.ascontiguousarray(r["U"]), end_tau=1.0)
+        Kn = int(base_res * tf_u)
+        x = O.propagate(y0, tf_u, cst, ctrl, Kn)[0]; t = np.linspace(0, 1, Kn)
+    assert c.opt_trajectory.shape == r["X"].shape
+    # observed 2.8e-10 / 1.3e-11; asserted at the solver tolerance
+    assert np.abs(c.opt_trajectory - r["X"]).max() < 5e-6
+    assert abs(c.sequence_controller.end_tau - r["tf"]) < 5e-6           # end_tau = tf_u / tf_interval, tf_interval = 1
+    assert c.horizon == 1.0
