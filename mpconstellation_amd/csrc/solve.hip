@@ -1028,11 +1028,13 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
         if (fuse_sweep) cur = dyn ? chan_mask(nraw, sc, sr, sact) : chan_inputs(s, sd, K - 1, sc, sr, sact);
         FT_MARK(8)
+        // a breakdown (every lane sees the same pivots) ends the sweep here: the caller retries with a larger delta_w
+        if (!__all(good)) break;
         if (k >= 1) stash(w.ops[(k - 1) & 1], k - 1);
         wsync();
         FT_MARK(9)
     }
-    if (fuse_sweep) {             // the sweep of node 0
+    if (fuse_sweep && __all(good)) {             // the sweep of node 0
         double sw_p, sw_qu;
         sweep_begin(w.ops[0]);
 #pragma unroll
