@@ -10,7 +10,7 @@
  * vectors generated from the reference itself (tests/golden/make_golden.py).
  * Solve half (S3-S7): the reference hands the NLP to pyomo + ipopt (both
  * unpinned, neither installed here) => PARITY UNPINNED at that boundary; see
- * nlp.c / ipm.c headers and DESIGN.md.
+ * oracle/nlp_ipm.py (the numpy restatement of that half) and DESIGN.md.
  */
 #ifndef MPC_ORACLE_H
 #define MPC_ORACLE_H
