@@ -82,8 +82,8 @@ struct SatData {
     double WxKsoft[49], gxKsoft[7];
     double ta[NTERM][7], tw[NTERM], tgh[NTERM], twin[NTERM];
     double avt[7], Hv[36], cv, gam, Wtf, gtf;
-    double Mb[NBD][NBD];     // LU of the border matrix
-    int piv[NBD];
+    double Mb[NBD][NBD];     // border matrix, then its L D L^T factors (unit lower part, 1/d on the diagonal)
+    double Sb[NBD][NBD];     // the border matrix itself (for the residual of the refinement step in border_solve)
     double siglam[NCH], xK[NCH][7];
     double sol[NBD];
     double red[8];
@@ -1259,81 +1259,136 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int 
     __syncthreads();
 }
 
-// Border matrix from the unit channels (1..7), LU with partial pivoting by lane 0.
+// The bordered system ("Solver algorithm"): unknowns dtf, the multiplier of the vt row and one zeta per
+// terminal barrier term with excess weight.  Kept in the order (vt, zeta_1..5, dtf) = channels (2, 3..7, 1): in that
+// order the matrix is symmetric, its leading 6x6 block (constraint-type rows, zeta rows in their 1/wex form) is
+// negative definite and the Schur complement of dtf is positive exactly when the reduced KKT matrix has the inertia
+// of a convex problem.  An LDL^T without pivoting in that order (stable for such quasi-definite matrices) therefore
+// serves three purposes: the solve, the inertia check ipopt gets from its linear solver -- every constraint pivot
+// negative, dtf's positive (Sylvester); a wrong inertia is reported like a breakdown and regularised by delta_w,
+// without it the iteration can alternate between a descent and an ascent direction in tf on short-arc references --
+// and it runs redundantly in the registers of every lane.  A zeta without excess weight is decoupled (pivot -1).
+__device__ __forceinline__ int border_channel(int q) { return q == NBD - 1 ? 1 : 2 + q; }
+
 __device__ __noinline__ bool border_factor(SatData &sd, int lane)
 {
-    if (lane == 0) {
-        double wex[NTERM];
-        for (int t = 0; t < NTERM; ++t) wex[t] = sd.tw[t] - sd.twin[t];
-        for (int i = 0; i < NBD; ++i)
-            for (int j = 0; j < NBD; ++j) sd.Mb[i][j] = 0.0;
-        sd.Mb[0][0] = sd.Wtf;
-        for (int c = 1; c <= NBD; ++c) sd.Mb[0][c - 1] -= sd.siglam[c];
-        for (int i = 0; i < 1 + NTERM; ++i) {
-            const double *a = (i == 0) ? sd.avt : sd.ta[i - 1];
-            for (int c = 1; c <= NBD; ++c) {
-                double acc = 0.0;
-                for (int q = 0; q < 7; ++q) acc += a[q] * sd.xK[c][q];
-                sd.Mb[1 + i][c - 1] = acc;
-            }
-        }
-        // row t reads wex (a.dx) - zeta = gex: divided by wex its entries stay O(1) however stiff the barrier term is
-        // (an LU with partial pivoting on the unscaled rows would pick its pivots by the 1e10-sized entries)
-        for (int t = 0; t < NTERM; ++t) {
-            if (wex[t] > 1.0) sd.Mb[2 + t][2 + t] -= 1.0 / wex[t];
-            else {
-                for (int j = 0; j < NBD; ++j) sd.Mb[2 + t][j] *= wex[t];
-                sd.Mb[2 + t][2 + t] -= 1.0;
-            }
-        }
-        int ok = 1;
-        for (int p = 0; p < NBD; ++p) {
-            int piv = p; double best = fabs(sd.Mb[p][p]);
-            for (int i = p + 1; i < NBD; ++i) if (fabs(sd.Mb[i][p]) > best) { best = fabs(sd.Mb[i][p]); piv = i; }
-            sd.piv[p] = piv;
-            if (!(best > 0.0)) { ok = 0; break; }
-            if (piv != p) for (int j = 0; j < NBD; ++j) { const double t = sd.Mb[p][j]; sd.Mb[p][j] = sd.Mb[piv][j]; sd.Mb[piv][j] = t; }
-            for (int i = p + 1; i < NBD; ++i) {
-                const double m = sd.Mb[i][p] / sd.Mb[p][p];
-                sd.Mb[i][p] = m;
-                for (int j = p + 1; j < NBD; ++j) sd.Mb[i][j] -= m * sd.Mb[p][j];
-            }
-        }
-        sd.flag = ok ? 0 : 1;
+    // assembly, one lane per entry: rows 0..5 measure a . x_K of the unit channels, row 6 the tf stationarity
+    if (lane < NBD * NBD) {
+        const int p = lane / NBD, q = lane - NBD * p;
+        const int c = border_channel(q);
+        double v;
+        if (p < NBD - 1) {
+            const double *a = (p == 0) ? sd.avt : sd.ta[p - 1];
+            v = 0.0;
+#pragma unroll
+            for (int l = 0; l < 7; ++l) v += a[l] * sd.xK[c][l];
+        } else v = (q == NBD - 1 ? sd.Wtf : 0.0) - sd.siglam[c];
+        sd.Mb[p][q] = v; sd.Sb[p][q] = v;    // Sb keeps the matrix for the refinement step of border_solve
     }
     __syncthreads();
-    return sd.flag == 0;
+    double S[NBD][NBD];
+#pragma unroll
+    for (int p = 0; p < NBD; ++p)
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) S[p][q] = sd.Mb[p][q];
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) {
+        const double wex = sd.tw[t] - sd.twin[t];
+        const bool on = wex > 0.0;
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) if (!on && q != 1 + t) { S[1 + t][q] = 0.0; S[q][1 + t] = 0.0; }
+        S[1 + t][1 + t] = on ? S[1 + t][1 + t] - 1.0 / wex : -1.0;
+    }
+    bool ok = true;
+    double rd[NBD];
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) {
+        const double d = S[p][p];
+        if (p == NBD - 1) { if (!(d > 0.0)) ok = false; } else if (!(d < 0.0)) ok = false;
+        rd[p] = 1.0 / d;
+#pragma unroll
+        for (int i = p + 1; i < NBD; ++i) {
+            const double m = S[i][p] * rd[p];
+#pragma unroll
+            for (int j = p + 1; j < NBD; ++j) S[i][j] -= m * S[p][j];
+            S[i][p] = m;                                  // unit lower factor
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {                                       // factors for border_solve (also of the refinement passes)
+#pragma unroll
+        for (int p = 0; p < NBD; ++p) {
+            sd.Mb[p][p] = rd[p];
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) sd.Mb[i][p] = S[i][p];
+        }
+    }
+    __syncthreads();
+    return ok;
 }
 
-// Right-hand side of the border system from channel 0, then solve with the stored LU.
+// Right-hand side of the border system from channel 0, then L D L^T solve with the stored factors and one step of
+// iterative refinement against the matrix itself (every lane, in registers); sd.sol in channel order (dtf, vt
+// multiplier, zeta_1..5).
 __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const double *gex, int lane)
 {
-    if (lane == 0) {
-        double rb[NBD];
-        rb[0] = -gtf_rhs + sd.siglam[0];
-        for (int i = 0; i < 1 + NTERM; ++i) {
-            const double *a = (i == 0) ? sd.avt : sd.ta[i - 1];
-            double acc = 0.0;
-            for (int q = 0; q < 7; ++q) acc += a[q] * sd.xK[0][q];
-            rb[1 + i] = -acc;
-        }
-        rb[1] += rvt_rhs;
-        for (int t = 0; t < NTERM; ++t) {
-            const double wex = sd.tw[t] - sd.twin[t];
-            rb[2 + t] = (wex > 1.0) ? rb[2 + t] - gex[t] / wex : rb[2 + t] * wex - gex[t];
-        }
-        // all row interchanges first (the stored multipliers are in final row order), then L, then U
-        for (int p = 0; p < NBD; ++p) {
-            const int piv = sd.piv[p];
-            if (piv != p) { const double t = rb[p]; rb[p] = rb[piv]; rb[piv] = t; }
-        }
+    double rb[NBD], x[NBD], r[NBD];
+#pragma unroll
+    for (int p = 0; p < NBD - 1; ++p) {
+        const double *a = (p == 0) ? sd.avt : sd.ta[p - 1];
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) acc += a[l] * sd.xK[0][l];
+        rb[p] = -acc;
+    }
+    rb[0] += rvt_rhs;
+    double iw[NTERM];
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) {
+        const double wex = sd.tw[t] - sd.twin[t];
+        iw[t] = (wex > 0.0) ? 1.0 / wex : 0.0;
+        rb[1 + t] = (wex > 0.0) ? rb[1 + t] - gex[t] * iw[t] : 0.0;
+    }
+    rb[NBD - 1] = -gtf_rhs + sd.siglam[0];
+    auto ldl_solve = [&](double (&v)[NBD]) {
+#pragma unroll
         for (int p = 0; p < NBD; ++p)
-            for (int i = p + 1; i < NBD; ++i) rb[i] -= sd.Mb[i][p] * rb[p];
-        for (int p = NBD - 1; p >= 0; --p) {
-            double acc = rb[p];
-            for (int j = p + 1; j < NBD; ++j) acc -= sd.Mb[p][j] * sd.sol[j];
-            sd.sol[p] = acc / sd.Mb[p][p];
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) v[i] -= sd.Mb[i][p] * v[p];
+#pragma unroll
+        for (int p = 0; p < NBD; ++p) v[p] *= sd.Mb[p][p];
+#pragma unroll
+        for (int p = NBD - 1; p >= 0; --p)
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) v[p] -= sd.Mb[i][p] * v[i];
+    };
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) x[p] = rb[p];
+    ldl_solve(x);
+    // r = rb - S x with S rebuilt from the kept matrix (zeta rows in their 1/wex form, decoupled ones as -1)
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) {
+        double acc = rb[p];
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) {
+            double s = sd.Sb[p][q];
+            const int tp = p - 1, tq = q - 1;
+            const bool offp = (tp >= 0 && tp < NTERM) && !(iw[tp < 0 ? 0 : (tp >= NTERM ? 0 : tp)] > 0.0);
+            const bool offq = (tq >= 0 && tq < NTERM) && !(iw[tq < 0 ? 0 : (tq >= NTERM ? 0 : tq)] > 0.0);
+            if (p == q && tp >= 0 && tp < NTERM) s = offp ? -1.0 : s - iw[tp];
+            else if (offp || offq) s = 0.0;
+            acc -= s * x[q];
         }
+        r[p] = acc;
+    }
+    ldl_solve(r);
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) x[p] += r[p];
+    __syncthreads();
+    if (lane == 0) {
+        sd.sol[0] = x[NBD - 1];
+#pragma unroll
+        for (int p = 0; p < NBD - 1; ++p) sd.sol[1 + p] = x[p];
     }
     __syncthreads();
 }

@@ -345,6 +345,52 @@ def riccati_channel(P, nb, F, gx, gu, rho, aff):
     return X, U, NU, LAM
 
 
+def border_ldl_solve(Mb, rb, wex, gex):
+    """The bordered system in the order (vt, zeta_1..5, dtf) -- Mb, rb come in channel order (dtf, vt, zetas) --
+    with the zeta rows in their 1/w_excess form (a zeta without excess weight is decoupled: pivot -1, value 0).
+    In that order the matrix is symmetric, its constraint-type block is negative definite and dtf's Schur complement
+    is positive exactly when the reduced KKT matrix has the inertia of a convex problem: an L D L^T without pivoting
+    gives the solution AND, by Sylvester, the inertia ipopt reads off its linear solver (all constraint pivots
+    negative, the last positive).  A wrong inertia raises LinAlgError like a breakdown of the recursion and is
+    regularised by delta_w; without the check the iteration can alternate between a descent and an ascent direction
+    in tf (seen on short-arc references).  Same arithmetic as border_factor / border_solve of the device kernel."""
+    n = Mb.shape[0]
+    order = list(range(1, n)) + [0]
+    S = Mb[np.ix_(order, order)].copy(); r = rb[order].copy()
+    for t in range(N_TERM):
+        if wex[t] > 0.0:
+            S[1 + t, 1 + t] -= 1.0 / wex[t]; r[1 + t] -= gex[t] / wex[t]
+        else:
+            S[1 + t, :] = 0.0; S[:, 1 + t] = 0.0; S[1 + t, 1 + t] = -1.0; r[1 + t] = 0.0
+    L = np.eye(n); rd = np.zeros(n)
+    for p in range(n):
+        d = S[p, p]
+        if (p < n - 1 and not d < 0.0) or (p == n - 1 and not d > 0.0):
+            raise np.linalg.LinAlgError("wrong inertia of the border system")
+        rd[p] = 1.0 / d
+        for i in range(p + 1, n):
+            m = S[i, p] * rd[p]
+            S[i, p + 1:] -= m * S[p, p + 1:]
+            L[i, p] = m
+    S0 = Mb[np.ix_(order, order)].copy()
+    for t in range(N_TERM):
+        if wex[t] > 0.0: S0[1 + t, 1 + t] -= 1.0 / wex[t]
+        else: S0[1 + t, :] = 0.0; S0[:, 1 + t] = 0.0; S0[1 + t, 1 + t] = -1.0
+
+    def ldl_solve(v):
+        v = v.copy()
+        for p in range(n):
+            v[p + 1:] -= L[p + 1:, p] * v[p]
+        v *= rd
+        for p in range(n - 1, -1, -1):
+            v[p] -= L[p + 1:, p] @ v[p + 1:]
+        return v
+    x = ldl_solve(r)
+    x = x + ldl_solve(r - S0 @ x)                                   # one step of iterative refinement
+    sol = np.zeros(n); sol[0] = x[n - 1]; sol[1:] = x[:n - 1]
+    return sol
+
+
 def riccati_solve(P, nb, F, rhs):
     """Solve the reduced KKT system for a right-hand side
     rhs = dict(gx (7,K), gu (3,K), rho (7,K-1), aff (7,K-1), gtf, rvt, gterm (N_TERM,)).
@@ -375,15 +421,7 @@ def riccati_solve(P, nb, F, rhs):
         for c in range(1, 1 + nbd): Mb[1 + i, c - 1] += a @ chans[c][0][:, K - 1]
         rb[1 + i] = -(a @ chans[0][0][:, K - 1])
     rb[1] += rhs["rvt"]
-    for j in range(N_TERM):
-        if wex[j] > 1.0:
-            # row j reads wex (a.dx) - zeta = gex: divided by wex its entries stay O(1) however stiff the barrier
-            # term is (an LU with partial pivoting on the unscaled rows picks pivots by the 1e10-sized entries)
-            Mb[2 + j, 2 + j] -= 1.0 / wex[j]; rb[2 + j] -= gex[j] / wex[j]
-        else:
-            Mb[2 + j, :] *= wex[j]; rb[2 + j] *= wex[j]
-            Mb[2 + j, 2 + j] -= 1.0; rb[2 + j] -= gex[j]
-    sol = np.linalg.solve(Mb, rb)
+    sol = border_ldl_solve(Mb, rb, wex, gex)
     comb = lambda i: chans[0][i] + sum(sol[c - 1] * chans[c][i] for c in range(1, 1 + nbd))
     return dict(X=comb(0), U=comb(1), NU=comb(2), lam=comb(3), tf=sol[0], lam_vt=sol[1])
 
