@@ -1,0 +1,20 @@
+"""diagnostic (not a test): convergence statistics with the options OptimalController passes (control.py:192-197):
+orbit raising to r_des with eps_r 1e-6, eps_vr 1e-16, tf_max = horizon"""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from mpconstellation_amd import mpc_step_batch, _ffi
+from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+from mpconstellation_amd.simulator import propagate_batch
+S = 1024
+y0, consts = normalize_batch(constellation_states(4096, first=0, count=S))
+for K, tf in ((30, 2.0), (60, 2.0), (30, 1.0)):
+    for r_des in (1.05, 1.2, 1.5):
+        xbar, st, _ = propagate_batch(y0, np.full(S, tf), consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K)
+        ubar = np.ascontiguousarray(tangential_thrust(xbar, 0.5))
+        opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": tf}
+        res = mpc_step_batch(xbar, ubar, np.full(S, tf), consts, np.full(S, r_des), options=opts)
+        u, c = np.unique(res.status, return_counts=True)
+        ok = res.status == 0
+        print(f"K {K} tf {tf} r_des {r_des}: status {dict(zip(u.tolist(), c.tolist()))} iters mean {res.iters.mean():.1f} max {res.iters.max()} "
+              f"kkt max(ok) {res.kkt[ok].max() if ok.any() else float('nan'):.2e} max|nu|(ok) {np.abs(res.NU[ok]).max() if ok.any() else float('nan'):.1e}")
