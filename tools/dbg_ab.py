@@ -1,0 +1,24 @@
+"""diagnostic (not a test): A/B timing of two builds of libmpcx.so on the same box, alternating runs
+usage: python tools/dbg_ab.py libA.so libB.so [workload ...]"""
+import os, sys, subprocess
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+libs = [os.path.abspath(a) for a in sys.argv[1:3]]
+wls = sys.argv[3:] or ["S64_K30", "S4096_K30"]
+code = '''
+import sys
+sys.path.insert(0, "%s")
+from mpconstellation_amd import _ffi
+_ffi.LIB_PATH = "%s"
+import torch, bench
+for wl in %r:
+    r = bench.Runner(wl, 0, 1, 0)
+    best = 1e9
+    for rep in range(3):
+        el, ms = bench.measure(r, 5, 2, 1)
+        best = min(best, ms)
+    print("%s", wl, "solve_kernel best of 3x5: %%.3f ms" %% best)
+    del r; torch.cuda.empty_cache()
+'''
+for rnd in range(2):
+    for lib in libs:
+        subprocess.check_call([sys.executable, "-c", code % (ROOT, lib, wls, os.path.basename(lib))])
