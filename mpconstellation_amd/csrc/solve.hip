@@ -12,7 +12,7 @@
 //    with one lane per matrix element and node k-1's operands prefetched while node k is worked on; the virtual
 //    control nu_k is eliminated per stage by a 7x7 LDL^T (redundantly in the registers of every lane); the free
 //    final time, the tangential-velocity equality and the five stiff rank-1 terminal barrier terms form a 7x7 border
-//    solved by LU with partial pivoting; eight linear-term sweeps (1 right-hand side + 7 border columns) run side
+//    solved by a symmetric quasi-definite LDL^T whose pivot signs also give the inertia; eight linear-term sweeps (1 right-hand side + 7 border columns) run side
 //    by side in the 8 lane groups of the wave, the backward one fused into the factorisation loop; iterative
 //    refinement on the reduced KKT system only once a terminal weight is stiff enough to cost digits.
 // Per-satellite state lives in a global-memory workspace (ws_doubles: 224 KB at K = 30); no MFMA.
