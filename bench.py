@@ -219,13 +219,19 @@ def main():
             del run
             torch.cuda.empty_cache()
             r2 = Runner("S4096_K30", 0, 1, local_rank)
+            r2.opts.flags = 1                                   # MPCX_SOLVE_INDEX_ORDER: plain index launch order
+            e2i, s2i = measure(r2, 3, 1, 1)
+            r2.opts.flags = 0; r2.solve_events = []
             e2, s2 = measure(r2, 3, 1, 1)
             st2, it2, _ = r2.solver_stats()
             out["also"] = {"S4096_K30": {"value": 4096 * 3 / e2, "unit": "satellite-MPC-steps/s", "ms_per_step": e2 / 3 * 1e3,
                                          "solve_kernel_ms": s2, "converged": int(((st2 == 0) | (st2 == 7)).sum()), "of": 4096,
                                          "ipm_iterations_mean": float(it2.mean()),
                                          "traffic": measured_traffic("S4096_K30"),
-                                         "note": "BASELINE configs[2], same run, 3 steps after 1 warm-up"}}
+                                         "index_launch_order": {"ms_per_step": e2i / 3 * 1e3, "solve_kernel_ms": s2i},
+                                         "note": "BASELINE configs[2], same run, 3 steps after 1 warm-up; default launch order = "
+                                                 "longest first by the previous solve's iteration counts (an exact predictor here: "
+                                                 "every step solves the same problems); index_launch_order = without it"}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)
             if err: out["trajectory_error_vs_cpu_oracle"] = err
