@@ -16,6 +16,7 @@
 //    by side in the 8 lane groups of the wave, the backward one fused into the factorisation loop; iterative
 //    refinement on the reduced KKT system only once a terminal weight is stiff enough to cost digits.
 // Per-satellite state lives in a global-memory workspace (ws_doubles: 224 KB at K = 30); no MFMA.
+#include <cstddef>
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
 
@@ -724,9 +725,14 @@ __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
     return ok;
 }
 
-struct StageOps {          // operands of one node, double-buffered in LDS
-    double A[49], Bn[21], Bpm[21], Wx[49], Wu[9], D[7];   // prefetched inputs, contiguous in fetch order (OPS_IN)
-    double G[49], Pt[49], Minv[49], Bh[21], Kg[21];
+// Operands of one node, double-buffered in LDS.  A and Bh live side by side as F = [A | Bh] (7 x 10, row stride FS),
+// Wx and Wx Bpm as G2 = [Wx | WxBp]: with them Pt F, Bpm^T G2 and F^T (Pt F) give every Q block in three rounds of
+// dot products of one access pattern each (see the factorisation loop).
+constexpr int FS = 10;
+struct StageOps {
+    double F[7 * FS], G2[7 * FS];
+    double Bn[21], Bpm[21], Wu[9], D[7];                  // the rest of the prefetched inputs (fetch order A Bn Bpm Wx Wu D)
+    double G[49], Pt[49], Minv[49], Kg[21];
 };
 constexpr int OPS_IN = 156;
 
@@ -735,10 +741,12 @@ struct Scratch {   // LDS working set of the recursion
         StageOps ops[2];
         double flat[2][FLAT_N];    // sweep operands of one node, double-buffered (fac record + A, Bpm, D)
     };
-    double Pn[49], WlLi[98], PtA[49], Qyy[49];
+    double Pn[49], WlLi[98], Qyy[49];
+    double T[7 * FS];              // Pt F = [Pt A | Pt Bh]
     double sink[64];               // target of the lanes that have nothing to write in a branch-free phase
-    double PtBh[21], WxBp[21], Quy[21];
+    double Quy[21];
     double Quu[9];
+    double zero;                   // constant 0 (addend of the tasks that have none)
 };
 
 template <int N>
@@ -833,7 +841,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         const bool dynj = (j <= K - 2);
         double Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { Acol[q] = o.A[q * 7 + srr]; Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.Bh[q * 3 + sr3]; }
+        for (int q = 0; q < 7; ++q) { Acol[q] = o.F[q * FS + srr]; Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.F[q * FS + 7 + sr3]; }
 #pragma unroll
         for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + srr];
         double tt = sw_t;
@@ -869,22 +877,47 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         cgf64 *p2 = nb + (e2 < OPS_IN ? e2 - 91 : 0);
         pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
     };
+    // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7]
+    auto ops_slot = [](int e) -> int {
+        if (e < 49) return (int)offsetof(StageOps, F) + 8 * ((e / 7) * FS + e % 7);
+        if (e < 70) return (int)offsetof(StageOps, Bn) + 8 * (e - 49);
+        if (e < 91) return (int)offsetof(StageOps, Bpm) + 8 * (e - 70);
+        if (e < 140) return (int)offsetof(StageOps, G2) + 8 * (((e - 91) / 7) * FS + (e - 91) % 7);
+        if (e < 149) return (int)offsetof(StageOps, Wu) + 8 * (e - 140);
+        return (int)offsetof(StageOps, D) + 8 * ((e < OPS_IN) ? e - 149 : 0);
+    };
+    const int slot0 = ops_slot(lane), slot1 = ops_slot(e1), slot2 = ops_slot(e2);
     auto stash = [&](StageOps &o, int k) {
         const bool dynk = (k <= K - 2);
-        double *in = o.A;
-        in[lane] = dynk ? pre[0] : 0.0;
-        in[e1] = ((e1 < 70) ? dynk : (e1 < 91) ? (k >= 1) : true) ? pre[1] : 0.0;
-        if (e2 < OPS_IN) in[e2] = (e2 < 149 || dynk) ? pre[2] : 0.0;
+        char *base = (char *)&o;
+        *(double *)(base + slot0) = dynk ? pre[0] : 0.0;
+        *(double *)(base + slot1) = ((e1 < 70) ? dynk : (e1 < 91) ? (k >= 1) : true) ? pre[1] : 0.0;
+        if (e2 < OPS_IN) *(double *)(base + slot2) = (e2 < 149 || dynk) ? pre[2] : 0.0;
     };
     fetch(K - 1);
     stash(w.ops[(K - 1) & 1], K - 1);
     for (int e = lane; e < 49; e += 64) w.Pn[e] = 0.0;
+    if (lane == 0) w.zero = 0.0;
     __syncthreads();
     const int mi = lane / 7, mj = lane - 7 * mi;
     const int xc = (lane < 7) ? lane : 6;                 // column of [Pn | I] this lane substitutes (lanes 0..13)
-    // P1 roles: lanes 0..20 element e of Bh = A Bpm + Bn, lanes 32..52 element e of WxBp = Wx Bpm, one common body
+    // P1 roles: lanes 0..20 element e of Bh = A Bpm + Bn (into F), lanes 32..52 element e of Wx Bpm (into G2), one body
     const bool p1_bh = lane < 21, p1_wx = lane >= 32 && lane < 53;
     const int p1_e = p1_wx ? lane - 32 : (p1_bh ? lane : 0), p1_i = p1_e / 3, p1_j = p1_e - 3 * p1_i;
+    // P5 roles: first round task lane of the 70 of T = Pt F; second round lanes 0..5 the other 6 (row 6, columns 4..9),
+    // lanes 6..35 element (r, j) of Bpm^T G2 (j < 7: Quy0, j >= 7: Quu0)
+    const int p5_i = lane / FS, p5_j = lane - FS * p5_i;
+    const bool p5b_t = lane < 6, p5b_g = lane >= 6 && lane < 36;
+    const int p5b_q = p5b_g ? lane - 6 : 0;
+    const int p5b_r = p5b_q / FS;
+    const int p5b_j = p5b_t ? 4 + lane : p5b_q - FS * p5b_r;
+    const int p5b_sa = p5b_t ? 1 : 3;
+    const bool p5b_wu = p5b_g && p5b_j >= 7, p5b_qy = p5b_g && p5b_j < 7;
+    // P6 roles: lane t < 55 is entry (i, j), i <= j, of the 10 x 10 matrix S = F^T T
+    int p6_i = 0, p6_j = 0;
+    { int tt = lane; for (int i = 0; i < FS; ++i) { const int n = FS - i; if (tt < n) { p6_i = i; p6_j = i + tt; break; } tt -= n; } }
+    const bool p6_on = lane < 55;
+    const bool p6_qyy = p6_on && p6_j < 7, p6_quy = p6_on && p6_i < 7 && p6_j >= 7, p6_quu = p6_on && p6_i >= 7;
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
         gf64 *fac = s.fac + (size_t)k * FAC_N;
@@ -895,9 +928,9 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         FT_MARK(0)
         // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm
         {
-            const double dot = dotN<7>((p1_wx ? o.Wx : o.A) + p1_i * 7, 1, o.Bpm + p1_j, 3);
+            const double dot = dotN<7>((p1_wx ? o.G2 : o.F) + p1_i * FS, 1, o.Bpm + p1_j, 3);
             const double val = p1_wx ? dot : (dyn ? o.Bn[p1_e] + dot : 0.0);
-            double *dst = p1_wx ? &w.WxBp[p1_e] : (p1_bh ? &o.Bh[p1_e] : &w.sink[lane]);
+            double *dst = p1_wx ? &o.G2[p1_i * FS + 7 + p1_j] : (p1_bh ? &o.F[p1_i * FS + 7 + p1_j] : &w.sink[lane]);
             *dst = val;
         }
         double rd[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -978,23 +1011,29 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             wsync();
         }
         FT_MARK(3)
-        // P5: PtA, PtBh, Quu0 = Wu + Bpm^T WxBp, Quy0 = Bpm^T Wx
-        if (lane < 49) w.PtA[lane] = dotN<7>(o.Pt + mi * 7, 1, o.A + mj, 7);
-        if (lane < 21) {
-            const int i = lane / 3, j = lane - 3 * i;
-            w.PtBh[lane] = dotN<7>(o.Pt + i * 7, 1, o.Bh + j, 3);
-            const int r = lane / 7, c = lane - 7 * r;
-            w.Quy[lane] = dotN<7>(o.Bpm + r, 3, o.Wx + c, 7);
-        } else if (lane >= 32 && lane < 41) {
-            const int e = lane - 32, i = e / 3, j = e - 3 * i;
-            w.Quu[e] = o.Wu[e] + dotN<7>(o.Bpm + i, 3, w.WxBp + j, 3);
+        // P5: T = Pt F (70 dot products of one pattern: 64 in the first round, 6 in the second) and
+        //     [Quy0 | Quu0 - Wu] = Bpm^T G2 (30, second round, lanes 6..35)
+        w.T[p5_i * FS + p5_j] = dotN<7>(o.Pt + p5_i * 7, 1, o.F + p5_j, FS);
+        {
+            const double *a = p5b_t ? o.Pt + 42 : o.Bpm + p5b_r;
+            const double *b = (p5b_t ? o.F : o.G2) + p5b_j;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 7; ++l) acc += a[l * p5b_sa] * b[l * FS];
+            const double *add = p5b_wu ? &o.Wu[p5b_r * 3 + p5b_j - 7] : &w.zero;
+            double *dst = p5b_t ? &w.T[6 * FS + p5b_j] : (p5b_wu ? &w.Quu[p5b_r * 3 + p5b_j - 7] : (p5b_qy ? &w.Quy[p5b_r * 7 + p5b_j] : &w.sink[lane]));
+            *dst = *add + acc;
         }
         wsync();
         FT_MARK(4)
-        // P6: Quu += Bh^T PtBh ; Quy += Bh^T PtA ; Qyy = Wx + A^T PtA
-        if (lane < 49) w.Qyy[lane] = o.Wx[lane] + dotN<7>(o.A + mi, 7, w.PtA + mj, 7);
-        if (lane < 21) { const int r = lane / 7, c = lane - 7 * r; w.Quy[lane] += dotN<7>(o.Bh + r, 3, w.PtA + c, 7); }
-        else if (lane >= 32 && lane < 41) { const int e = lane - 32, i = e / 3, j = e - 3 * i; w.Quu[e] += dotN<7>(o.Bh + i, 3, w.PtBh + j, 3); }
+        // P6: the upper triangle of S = F^T T (55 dot products of one pattern): Qyy = Wx + A^T Pt A (upper part only, read
+        //     back through (min, max)), Quy += Bh^T Pt A, Quu += Bh^T Pt Bh (upper part: all the 3x3 inverse reads)
+        {
+            const double sdot = dotN<7>(o.F + p6_i, FS, w.T + p6_j, FS);
+            double *dst = p6_qyy ? &w.Qyy[p6_i * 7 + p6_j] : (p6_quy ? &w.Quy[(p6_j - 7) * 7 + p6_i] : (p6_quu ? &w.Quu[(p6_i - 7) * 3 + p6_j - 7] : &w.sink[lane]));
+            const double *add = p6_qyy ? &o.G2[p6_i * FS + p6_j] : dst;
+            *dst = *add + sdot;
+        }
         wsync();
         FT_MARK(5)
         // P7-P9: every lane inverts the 3x3 itself; P_k = sym(Qyy - Quy^T Qi Quy) straight from its own two columns of
@@ -1009,7 +1048,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             // (qi, qj) = columns (min, max) of Quy: lanes (i,j) and (j,i) evaluate the same expression, P_k is
             // symmetric by construction; Qyy is symmetrised through the same (min, max) read (rounding-level asymmetry
             // of A^T (Pt A) otherwise)
-            double a1 = 0.5 * (w.Qyy[lane] + w.Qyy[mj * 7 + mi]);
+            double a1 = w.Qyy[lo * 7 + hi];
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, hi)
@@ -1020,7 +1059,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
             const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
-            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.Bh[lane];
+            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.F[(lane / 3) * FS + 7 + lane % 3];
         }
         if (lane < 9) fac[F_QI + lane] = Qi[lane];
         FT_MARK(6)
