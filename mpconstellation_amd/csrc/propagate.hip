@@ -155,9 +155,16 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         }
         const double en = rms7(ev);
         if (en < 1.0) {
-            double factor = (en == 0.0) ? RK_MAX_FACTOR : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(en, -0.2));
-            if (rejected) factor = fmin(1.0, factor);
-            h_abs = h_try * factor;
+            // scipy: factor = min(MAX_FACTOR, SAFETY * en^-0.2) (1 if the step before was rejected), h_abs = h_try * factor,
+            // then h_abs is clipped to max_step at the top of the next step.  When this step already was max_step long
+            // and en <= 0.5 < SAFETY^5, the factor is >= 1 and the clip undoes it whatever its value: same h_abs,
+            // bit for bit, without the pow (the usual case: max_step = 1e-3 keeps en around 1e-9).
+            if (en <= 0.5 && h_try >= a.max_step) h_abs = h_try;
+            else {
+                double factor = (en == 0.0) ? RK_MAX_FACTOR : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(en, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs = h_try * factor;
+            }
             rejected = false;
             // dense output at the t_eval points in (t, t_new]  (scipy RkDenseOutput, rk.py:552-574)
             while (ei < n_eval) {
