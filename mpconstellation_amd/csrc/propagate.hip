@@ -112,7 +112,9 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     double *yo = a.y_out + (size_t)sat * 7 * n_eval;
     for (int iter = 0; iter < 4000000; ++iter) {
         if (t == t_bound) break;
-        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        // scipy: min_step = 10 |nextafter(t, inf) - t| <= 10 ulp(1) = 2.3e-15 for t in [0, 1]; it only guards against
+        // vanishing steps, so it is evaluated only when h_abs could be anywhere near it
+        const double min_step = (h_abs > 1e-12) ? 0.0 : 10.0 * fabs(nextafter(t, INFINITY) - t);
         if (!rejected) {
             if (h_abs > a.max_step) h_abs = a.max_step;
             else if (h_abs < min_step) h_abs = min_step;
