@@ -9,7 +9,8 @@ from .optimizer import Optimizer, mpc_step_batch, solve_batch
 from .control import (Controller, ConstantThrustController, ConstantTangentialThrustController,
                       SequenceController, OptimalController)
 from .simulator import Simulator, propagate_batch
+from .constellation_mpc import ConstellationMPC
 
 __all__ = ["Constants", "Satellite", "SatelliteScale", "Discretizer", "Optimizer", "mpc_step_batch", "solve_batch",
            "Controller", "ConstantThrustController", "ConstantTangentialThrustController", "SequenceController",
-           "OptimalController", "Simulator", "propagate_batch"]
+           "OptimalController", "Simulator", "propagate_batch", "ConstellationMPC"]

@@ -1,0 +1,135 @@
+"""ConstellationMPC -- the reference's MPC loop for a whole constellation at once.
+
+The reference runs OptimalController.update (control.py:166-235) for ONE satellite (`self.sats[0]`, :162) and
+Simulator.run_segment calls it once per satellite in a Python loop (simulator.py:58-60).  Here every step of that loop
+is one batched device call over all satellites, each with its own SatelliteScale (so each sees MU = 4 pi^2):
+
+    reference rollout (tangential 0.5)  ->  SCPn x [ extract u_bar, discretise + solve, re-rollout under the
+    optimised first-order-hold sequence over tf_u ]  ->  fly the segment under the truth model, update the states.
+
+The number of nodes of the second SCP iteration is int(base_res * tf_u) and differs between satellites, as does the
+length of the thrust table played back during the segment; satellites are grouped by node count and every group is
+one batch, so each satellite gets exactly the result of the single-satellite path (tests/test_mpc_loop_gpu.py)."""
+import numpy as np
+
+from . import _ffi
+from .constellation import tangential_thrust
+from .optimizer import mpc_step_batch
+from .satellite_scale import SatelliteScale
+from .simulator import propagate_batch
+
+
+def foh_resample(u, n):
+    """SequenceController(u, tf_u, tf_sim=tf_u).get_u_func() evaluated at linspace(0, 1, n) (control.py:103-131:
+    first-order hold with Python's float floor division, the last column at tau == 1) for a batch u (S,3,K)."""
+    S, _, K = u.shape
+    tau = np.linspace(0, 1, n)
+    dtau = 1 / (K - 1)
+    out = np.empty((S, 3, n))
+    for i, tq in enumerate(tau):
+        if tq == 1:
+            out[:, :, i] = u[:, :, -1]
+            continue
+        k = int(tq // dtau)
+        tau_k = k / (K - 1); tau_kp1 = (k + 1) / (K - 1)
+        lam_n = (tau_kp1 - tq) / (tau_kp1 - tau_k); lam_p = (tq - tau_k) / (tau_kp1 - tau_k)
+        out[:, :, i] = lam_n * u[:, :, k] + lam_p * u[:, :, k + 1]
+    return out
+
+
+class ConstellationMPC:
+    def __init__(self, sats, base_res=100, tf_horizon=1, tf_interval=1, r_des=1.5, scp_iterations=2, sim_base_res=100,
+                 include_drag=True, include_J2=True, device=0):
+        self.sats = list(sats)
+        self.scales = [SatelliteScale(sat=s) for s in self.sats]
+        self.consts = np.stack([sc.get_normalized_constants().as_vector() for sc in self.scales])
+        self.base_res, self.sim_base_res = base_res, sim_base_res
+        self.horizon, self.interval = tf_horizon, tf_interval
+        self.r_des = np.broadcast_to(np.asarray(r_des, dtype=np.float64), (len(self.sats),)).copy()
+        self.scp_iterations = scp_iterations
+        self.include_drag, self.include_J2 = include_drag, include_J2
+        self.device = device
+        self.sim_data, self.sim_time = {}, {}
+        self.last_status = None
+        self.plan_u, self.plan_tf, self.plan_x = None, None, None
+
+    def _y0(self):
+        return np.stack([sc.normalize_state(s.get_state_vector()) for sc, s in zip(self.scales, self.sats)])
+
+    # ---- OptimalController.update for every satellite ----
+    def update(self):
+        S = len(self.sats)
+        y0 = self._y0()
+        K = int(self.base_res * self.horizon)
+        x, st, _ = propagate_batch(y0, self.horizon, self.consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K,
+                                   False, False, 0.001, self.device)
+        self._check(st)
+        u_bar = tangential_thrust(x, 0.5)                                  # extract_uk of the tangential controller
+        tf_u = np.full(S, float(self.horizon))
+        groups = {K: np.arange(S)}
+        xs = {K: x}; us = {K: u_bar}
+        self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
+        plan_u = [None] * S; plan_x = [None] * S
+        opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": self.horizon}     # control.py:192-197
+        for it in range(self.scp_iterations):
+            nxt_groups, nxt_x, nxt_u = {}, {}, {}
+            for Kg, idx in groups.items():
+                res = mpc_step_batch(xs[Kg], us[Kg], tf_u[idx], self.consts[idx], self.r_des[idx], options=opts, device=self.device)
+                self.last_status[it, idx] = res.status
+                tf_u[idx] = res.tf
+                for j, s in enumerate(idx):
+                    plan_u[s] = res.U[j]; plan_x[s] = res.X[j]
+                # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
+                Kn = (self.base_res * res.tf).astype(int)
+                for kn in np.unique(Kn):
+                    sel = np.nonzero(Kn == kn)[0]; gi = idx[sel]
+                    xr, st, _ = propagate_batch(y0[gi], tf_u[gi], self.consts[gi], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0), int(kn),
+                                                False, False, 0.001, self.device)
+                    self._check(st)
+                    ur = foh_resample(res.U[sel], int(kn))              # extract_uk of SequenceController(tf_sim = tf_u)
+                    if int(kn) in nxt_groups:
+                        nxt_groups[int(kn)] = np.concatenate([nxt_groups[int(kn)], gi])
+                        nxt_x[int(kn)] = np.concatenate([nxt_x[int(kn)], xr]); nxt_u[int(kn)] = np.concatenate([nxt_u[int(kn)], ur])
+                    else:
+                        nxt_groups[int(kn)] = gi; nxt_x[int(kn)] = xr; nxt_u[int(kn)] = ur
+            groups, xs, us = nxt_groups, nxt_x, nxt_u
+        self.plan_u, self.plan_x, self.plan_tf = plan_u, plan_x, tf_u.copy()
+        if self.horizon - self.interval > 0.1:                               # control.py:234-235
+            self.horizon -= self.interval
+
+    # ---- Simulator.run_segment for every satellite: plan, fly tf under the truth model, update the states ----
+    def run_segment(self, tf=1):
+        self.update()
+        n_eval = int(self.sim_base_res * tf)
+        S = len(self.sats)
+        y0 = self._y0()
+        Ku = np.array([u.shape[1] for u in self.plan_u])
+        y = np.empty((S, 7, n_eval))
+        for ku in np.unique(Ku):
+            gi = np.nonzero(Ku == ku)[0]
+            useq = np.stack([self.plan_u[s] for s in gi])
+            end_tau = self.plan_tf[gi] / self.interval                     # SequenceController(tf_u, tf_sim = interval)
+            yy, st, _ = propagate_batch(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, useq, int(ku), end_tau), n_eval,
+                                        self.include_drag, self.include_J2, 0.001, self.device)
+            self._check(st)
+            y[gi] = yy
+        t = np.linspace(0, 1, n_eval)
+        for i, (sat, sc) in enumerate(zip(self.sats, self.scales)):
+            sat.update_state_vector(sc.redim_state(y[i][:, -1]))
+            if sat.id in self.sim_data:
+                time = t + self.sim_time[sat.id][-1] * tf + 0.0000001       # simulator.py:69-76
+                self.sim_data[sat.id] = np.concatenate([self.sim_data[sat.id], y[i]], axis=1)
+                self.sim_time[sat.id] = np.concatenate([self.sim_time[sat.id], time])
+            else:
+                self.sim_data[sat.id] = y[i]; self.sim_time[sat.id] = t.copy()
+
+    def run_segments(self, tf=1, num_segments=1):
+        for _ in range(num_segments):
+            self.run_segment(tf=tf / float(num_segments))
+
+    @staticmethod
+    def _check(status):
+        if (status == 1).any():
+            raise Exception("ERROR: INVALID SATELLITE MASS")               # simulator.py:135-136
+        if (status != 0).any():
+            raise RuntimeError(f"propagation failed: {[_ffi.STATUS_TEXT.get(int(c), c) for c in status if c]}")
