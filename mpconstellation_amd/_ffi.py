@@ -90,13 +90,15 @@ def load():
     return _lib
 
 
-def context(device=0):
-    """One mpcx context per (process, device)."""
+def context(device=0, slot=0):
+    """One mpcx context per (process, device, slot).  Calls on different contexts are thread-safe and run on their own
+    streams (include/mpcx.h): host threads that want to overlap small launches take different slots."""
     lib = load()
+    device = (device, slot) if slot else device
     with _lock:
         if device not in _ctxs:
             h = _vp()
-            rc = lib.mpcx_create(device, C.byref(h))
+            rc = lib.mpcx_create(device[0] if isinstance(device, tuple) else device, C.byref(h))
             if rc != 0:
                 raise MpcxError(f"mpcx_create(device={device}) failed ({rc}): "
                                 f"{lib.mpcx_last_error(None).decode()}")

@@ -10,6 +10,8 @@ is one batched device call over all satellites, each with its own SatelliteScale
 The number of nodes of the second SCP iteration is int(base_res * tf_u) and differs between satellites, as does the
 length of the thrust table played back during the segment; satellites are grouped by node count and every group is
 one batch, so each satellite gets exactly the result of the single-satellite path (tests/test_mpc_loop_gpu.py)."""
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from . import _ffi
@@ -35,6 +37,21 @@ def foh_resample(u, n):
         lam_n = (tau_kp1 - tq) / (tau_kp1 - tau_k); lam_p = (tq - tau_k) / (tau_kp1 - tau_k)
         out[:, :, i] = lam_n * u[:, :, k] + lam_p * u[:, :, k + 1]
     return out
+
+
+def _concurrently(fn, jobs, device, **kw):
+    """Several batched calls at once.  A rollout is ~1000 sequential RK45 steps and a solve ~25-50 sequential
+    interior-point iterations however few satellites the call carries, so the groups run concurrently, each host
+    thread on its own context and stream (include/mpcx.h)."""
+    if len(jobs) == 1:
+        return [fn(*jobs[0], device=device, **kw)]
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as pool:
+        futs = [pool.submit(fn, *job, device=device, slot=1 + i % 8, **kw) for i, job in enumerate(jobs)]
+        return [f.result() for f in futs]
+
+
+def _rollouts(jobs, device):
+    return _concurrently(propagate_batch, jobs, device)
 
 
 class ConstellationMPC:
@@ -73,18 +90,28 @@ class ConstellationMPC:
         opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": self.horizon}     # control.py:192-197
         for it in range(self.scp_iterations):
             nxt_groups, nxt_x, nxt_u = {}, {}, {}
-            for Kg, idx in groups.items():
-                res = mpc_step_batch(xs[Kg], us[Kg], tf_u[idx], self.consts[idx], self.r_des[idx], options=opts, device=self.device)
+            keys = list(groups)
+            jobs = [(xs[Kg], us[Kg], tf_u[groups[Kg]], self.consts[groups[Kg]], self.r_des[groups[Kg]]) for Kg in keys]
+            if S <= 256:      # small groups: the solves are latency bound and overlap (measured: -12 % at 64 satellites)
+                solved = _concurrently(mpc_step_batch, jobs, self.device, options=opts)
+            else:             # large ones fill the device on their own; separate contexts would only regrow workspaces
+                solved = [mpc_step_batch(*job, options=opts, device=self.device) for job in jobs]
+            for Kg, res in zip(keys, solved):
+                idx = groups[Kg]
                 self.last_status[it, idx] = res.status
                 tf_u[idx] = res.tf
                 for j, s in enumerate(idx):
                     plan_u[s] = res.U[j]; plan_x[s] = res.X[j]
+                if it == self.scp_iterations - 1:
+                    continue          # (the reference re-rolls once more, control.py:227, and drops the result)
                 # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
                 Kn = (self.base_res * res.tf).astype(int)
-                for kn in np.unique(Kn):
-                    sel = np.nonzero(Kn == kn)[0]; gi = idx[sel]
-                    xr, st, _ = propagate_batch(y0[gi], tf_u[gi], self.consts[gi], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0), int(kn),
-                                                False, False, 0.001, self.device)
+                kns = np.unique(Kn)
+                sels = [np.nonzero(Kn == kn)[0] for kn in kns]
+                outs = _rollouts([(y0[idx[sel]], tf_u[idx[sel]], self.consts[idx[sel]], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0),
+                                   int(kn), False, False, 0.001) for kn, sel in zip(kns, sels)], self.device)
+                for kn, sel, (xr, st, _) in zip(kns, sels, outs):
+                    gi = idx[sel]
                     self._check(st)
                     ur = foh_resample(res.U[sel], int(kn))              # extract_uk of SequenceController(tf_sim = tf_u)
                     if int(kn) in nxt_groups:
@@ -105,12 +132,13 @@ class ConstellationMPC:
         y0 = self._y0()
         Ku = np.array([u.shape[1] for u in self.plan_u])
         y = np.empty((S, 7, n_eval))
-        for ku in np.unique(Ku):
-            gi = np.nonzero(Ku == ku)[0]
-            useq = np.stack([self.plan_u[s] for s in gi])
-            end_tau = self.plan_tf[gi] / self.interval                     # SequenceController(tf_u, tf_sim = interval)
-            yy, st, _ = propagate_batch(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, useq, int(ku), end_tau), n_eval,
-                                        self.include_drag, self.include_J2, 0.001, self.device)
+        kus = np.unique(Ku)
+        gis = [np.nonzero(Ku == ku)[0] for ku in kus]
+        # SequenceController(tf_u, tf_sim = interval): end_tau = tf_u / interval
+        outs = _rollouts([(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, np.stack([self.plan_u[s] for s in gi]), int(ku),
+                                                         self.plan_tf[gi] / self.interval), n_eval, self.include_drag, self.include_J2,
+                           0.001) for ku, gi in zip(kus, gis)], self.device)
+        for gi, (yy, st, _) in zip(gis, outs):
             self._check(st)
             y[gi] = yy
         t = np.linspace(0, 1, n_eval)

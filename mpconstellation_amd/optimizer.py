@@ -16,7 +16,7 @@ class SolveResult:
         self.X, self.U, self.NU, self.tf, self.status, self.iters, self.kkt = X, U, NU, tf, status, iters, kkt
 
 
-def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0,
+def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
                    **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays."""
@@ -30,7 +30,7 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     opts = _ffi.make_solve_opts(options, **solver)
     X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); tfo = np.empty(S); kkt = np.empty(S)
     status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
-    lib = _ffi.load(); ctx = _ffi.context(device)
+    lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
     rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
                                  _ffi.dptr(r_des), _ffi.FLAG_J2 if include_J2 else 0, float(max_step), C.byref(opts),

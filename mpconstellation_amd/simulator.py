@@ -19,7 +19,7 @@ class OdeResult:
         self.success = (status == 0)
 
 
-def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0):
+def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0, slot=0):
     """y0 (S,7) normalised, tf (S,), consts (S,8); law = (kind, vec, Ku, end_tau) with per-satellite or
     broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,)."""
     y0 = _ffi.as_f64(y0); S = y0.shape[0]
@@ -37,7 +37,7 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
         end_tau = _ffi.as_f64(np.broadcast_to(np.asarray(end_tau, dtype=np.float64), (S,))); et_p = _ffi.dptr(end_tau)
     y = np.empty((S, 7, n_eval)); status = np.zeros(S, dtype=np.int32); nsteps = np.zeros(S, dtype=np.int32)
     flags = (_ffi.FLAG_DRAG if include_drag else 0) | (_ffi.FLAG_J2 if include_J2 else 0)
-    lib = _ffi.load(); ctx = _ffi.context(device)
+    lib = _ffi.load(); ctx = _ffi.context(device, slot)
     rc = lib.mpcx_propagate_batch(ctx, S, int(n_eval), _ffi.dptr(y0), _ffi.dptr(tf), _ffi.dptr(consts), flags, kind,
                                   vec_p, int(Ku), et_p, float(max_step), _ffi.dptr(y), _ffi.iptr(status),
                                   _ffi.iptr(nsteps))
