@@ -82,7 +82,7 @@ struct SatData {
     double WxK[49];          // terminal Hessian used inside the recursion (soft + capped + AL)
     double WxKsoft[49], gxKsoft[7];
     double ta[NTERM][7], tw[NTERM], tgh[NTERM], twin[NTERM];
-    double avt[7], Hv[36], cv, gam, Wtf, gtf;
+    double avt[7], Hv[36], cv, gam, Wtf, gtf, sigmax;
     double Mb[NBD][NBD];     // border matrix, then its L D L^T factors (unit lower part, 1/d on the diagonal)
     double Sb[NBD][NBD];     // the border matrix itself (for the residual of the refinement step in border_solve)
     double siglam[NCH], xK[NCH][7];
@@ -513,6 +513,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
     const double tf = s.itg[G_TF];
     const int half = HALF_OF(lane);
     const bool h0 = (half == 0);
+    double sigmax = 0.0;                                   // largest barrier weight z/s of the stage constraints
     for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
@@ -544,6 +545,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             {
                 const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
                 const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
+                sigmax = fmax(sigmax, sig);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zh;
@@ -557,12 +559,14 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double g = r2 - b_rmax;
                 const double isr = rcp_pos(srmax);
                 sig_rmax = zrmax * isr; zh_rmax = mu * isr + sig_rmax * (g + srmax);
+                sigmax = fmax(sigmax, sig_rmax);
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) Wx3[i] = ((i & 3) == 0) ? 2.0 * w_tr + delta_w : 0.0;
             if (inner) {
                 const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
                 const double isr = rcp_pos(srmin), sig = zrmin * isr, zh = mu * isr + sig * (g + srmin);
+                sigmax = fmax(sigmax, sig);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     gx[i] += 2.0 * x[i] * zh_rmax - rbv[i] * zh;
@@ -668,6 +672,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             sd.gam = (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
         }
     }
+    sigmax = wave_max(sigmax);
     __syncthreads();
     // terminal Hessians, one lane per element: soft part (objective, radius balls, lam_vt * Hessian of the vt row) for
     // the residuals; + capped rank-1 terms + AL term for the recursion, which reads it from the terminal node's slot
@@ -690,8 +695,9 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             const double sj = s.itg[G_STF + j], zj = s.itg[G_ZTF + j];
             const double sig = zj / sj, zh = mu / sj + sig * (gv[j] + sj);
             W += sig; g += (j == 0 ? -zh : zh);
+            sigmax = fmax(sigmax, sig);
         }
-        sd.Wtf = W; sd.gtf = g;
+        sd.Wtf = W; sd.gtf = g; sd.sigmax = sigmax;
     }
     __syncthreads();
 }
@@ -1717,7 +1723,7 @@ __device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, dou
     const int K = s.K;
 #define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
                              const double c_ = mu * rcp_pos(s_); \
-                             z_ = fmax(fmin(z_, kKappaSigma * c_), c_ * (1.0 / kKappaSigma)); (sv) = s_; (zv) = z_; }
+                             z_ = fmin(z_, kKappaSigma * c_); (sv) = s_; (zv) = z_; }
     const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     const int half = HALF_OF(lane);
     const bool h0 = (half == 0);
@@ -1956,8 +1962,9 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             PT_BEGIN
             initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);      // right-hand side of the first solve = the Newton blocks
             PT_END(5)
-            // iterative refinement only once a terminal barrier weight is stiff enough to cost digits
-            double twmax = 0.0;
+            // iterative refinement only once a barrier weight (terminal rank-1 terms, stage balls and planes, the tf
+            // bounds) is stiff enough to cost digits
+            double twmax = sd.sigmax;
             for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
             const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
             PT_BEGIN
@@ -2045,6 +2052,10 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             PT_END(10)
             const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
             const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
+#ifdef MPCX_ITER_LOG
+            // diagnostic build only: the first trial's margins into this satellite's U block
+            if (ls == 0 && lane == 0 && 3 * iter + 2 < 3 * K) { double *lg = a.U + (size_t)sat * 3 * K + 3 * iter; lg[0] = alpha; lg[1] = sqrt(rt.sq) / rn0; lg[2] = rt.prod_min / (kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc)); }
+#endif
             if (dec && cen) break;
             alpha *= 0.5;
         }
@@ -2068,7 +2079,9 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
 #endif
         }
+#ifndef MPCX_ITER_LOG
         for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * K + (size_t)i * K + k] = p[I_U + i];
+#endif
     }
     if (lane == 0) {
         a.tf_out[sat] = s.itg[G_TF];

@@ -19,7 +19,7 @@ What is restated
   (z = w_nu/2, s = t = mu/z): mean iterations 42 -> 32,
   fraction-to-the-boundary rule tau = max(0.99, 1-mu), monotone barrier update
   mu <- max(tol/10, min(0.2 mu, mu^1.5)) once E_mu <= 10 mu, the scaled optimality error E_0 with
-  s_max = 100 and tol = 1e-8, multiplier safeguard z in [mu/(kappa s), kappa mu/s].
+  s_max = 100 and tol = 1e-8, multiplier safeguard z <= kappa mu/s (upper side only, see below).
 
 PARITY UNPINNED at this boundary: the reference's own tests hold no numbers for solve_OPT and
 ipopt cannot be run here, so nothing below is checked against ipopt output.  It is checked by
@@ -39,9 +39,12 @@ Deliberate differences from ipopt's path (none changes the NLP or its KKT points
   satellites of the benchmark constellation the floor and the loose neighbourhood cut the mean iteration count
   32.7 -> 21.6 and the maximum 48 -> 30 with every problem still converging; with no line search at all the
   K = 60, tf = 2 fixture breaks down).
-* kappa_Sigma = 100 instead of ipopt's 1e10: with one step length for primal and dual variables a loose
-  safeguard lets (s_i, z_i) pairs jam against the boundary (1 of the 64 benchmark satellites stalled at mu = 0.1);
-  re-centring the multipliers after every step removed every stall and cut the mean iteration count 46 -> 41.
+* kappa_Sigma = 100 instead of ipopt's 1e10, and only its upper side z <= kappa mu / s: with one step length for
+  primal and dual variables a loose safeguard lets (s_i, z_i) pairs jam against the boundary (1 of the 64 benchmark
+  satellites stalled at mu = 0.1); pulling oversized multipliers back after every step removed every stall.  The
+  lower side (z >= mu / (kappa s)) is dropped: raising the multipliers of inactive constraints after every step only
+  adds dual infeasibility (measured: 39 -> 32 iterations on long-arc K = 60 references, 51 -> 46 with the MPC loop's
+  option set, 21.7 -> 21.2 on the benchmark constellation; the saturated-thrust scenarios pay 26 -> 28).
 * x_0 is eliminated (it is fixed by an equality), nu_{K-1}, t_{K-1} (which enter no dynamics row) are
   reported as 0.
 * linear algebra: stage-wise Riccati recursion (see riccati_factor_solve) instead of MUMPS.
@@ -61,7 +64,7 @@ ALPHA_FLOOR = 0.25    # backtracking never takes the step below this (unless the
 MU_INIT = 1.0
 KAPPA_EPS, KAPPA_MU, THETA_MU = 10.0, 0.2, 1.5     # ipopt barrier_tol_factor, mu_linear_decrease_factor, mu_superlinear_decrease_power
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
-REFINE_TW = 1e9       # iterative refinement only once a terminal barrier weight exceeds this
+REFINE_TW = 1e9       # iterative refinement only once a barrier weight z/s (terminal terms, stage balls/planes, tf) exceeds this
 N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
 
 
@@ -466,7 +469,9 @@ def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
     zero = dict(X=np.zeros((7, K)), U=np.zeros((3, K)), NU=np.zeros((7, K - 1)), tf=0.0,
                 lam=-it.lam.copy(), lam_vt=-it.lam_vt)             # so that lam + dlam = 0: rhs has no multipliers
     d = zero
-    passes = 1 + (n_refine if max(w for (a, w, gh) in nb["term"]) > REFINE_TW else 0)
+    # refinement once a barrier weight z/s (terminal rank-1 terms, stage balls and planes, tf bounds) costs digits
+    stiff = max(max(w for (a, w, gh) in nb["term"]), max(nb["sig"][k].max() for k in ("u", "rmax", "rmin", "tf")))
+    passes = 1 + (n_refine if stiff > REFINE_TW else 0)
     for _ in range(passes):
         rhs = reduced_residual(P, nb, it, d)
         c = riccati_solve(P, nb, F, rhs)
@@ -597,7 +602,7 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
         for k in it.s:
             it.s[k] = np.maximum(it.s[k], -g[k])                                        # slack reset
-            it.z[k] = np.maximum(np.minimum(it.z[k], KAPPA_SIGMA * mu / it.s[k]), mu / (KAPPA_SIGMA * it.s[k]))
+            it.z[k] = np.minimum(it.z[k], KAPPA_SIGMA * mu / it.s[k])                  # upper side only, see the header
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
     T = np.zeros((7, K)); T[:, :K - 1] = it.T

@@ -42,26 +42,28 @@ def test_solve_vs_oracle(golden_dir, name):
                       [tf], cst[None], [r_des])
     assert ref["status"] == 0 and res.status[0] == 0
     assert res.kkt[0] <= 1e-8
-    # Same data, same algorithm: same iteration path, results equal to rounding.  Exception: a path that runs through
-    # factorisation breakdowns (indefinite reduced Hessian far from the solution, regularised by delta_w): whether a
-    # pivot of a nearly singular matrix comes out at +1e-17 or -1e-17 is decided by rounding, so the two paths may
-    # part there; both still end at the same KKT point, compared at the solver tolerance.
-    tol = TOL if ref["n_regularised"] == 0 else TOL_SOL
-    if ref["n_regularised"] == 0: assert res.iters[0] == ref["iters"]
+    # Same data, same algorithm: the same iteration path.  Two things are decided by rounding and may part the paths
+    # near their end: whether the last iterate already meets E_0 <= tol (one iteration more or less), and -- on a path
+    # that runs through factorisation breakdowns (indefinite reduced Hessian far from the solution, regularised by
+    # delta_w) -- whether a pivot of a nearly singular matrix comes out at +1e-17 or -1e-17.  Both sides still end at
+    # the same KKT point: the solutions are compared at rounding level when the paths coincide, at the solver
+    # tolerance otherwise ...
+    same_path = ref["n_regularised"] == 0 and res.iters[0] == ref["iters"]
+    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if ref["n_regularised"] == 0 else 10)
+    tol = 5 * TOL if same_path else TOL_SOL
     assert np.abs(res.X[0] - ref["X"]).max() < tol
     assert np.abs(res.U[0] - ref["U"]).max() < tol
     assert np.abs(res.NU[0] - ref["NU"]).max() < tol
     assert abs(res.tf[0] - ref["tf"]) < tol
-    if ref["n_regularised"] > 0:
-        # ... and well before the first breakdown (on either side: the device does not report its own, so half way to
-        # the oracle's) the two paths are the same: stop both there and compare the iterates
-        cap = ref["first_regularised"] // 2
-        _, refc = oracle_solve(x, u, tf, cst, r_des, stage, max_iter=cap)
-        resc = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
-                           [tf], cst[None], [r_des], max_iter=cap)
-        assert resc.iters[0] == refc["iters"] == cap
-        assert np.abs(resc.X[0] - refc["X"]).max() < TOL and np.abs(resc.U[0] - refc["U"]).max() < TOL
-        assert np.abs(resc.NU[0] - refc["NU"]).max() < TOL and abs(resc.tf[0] - refc["tf"]) < TOL
+    # ... and half way (to the end, or to the oracle's first breakdown: the device does not report its own) the two
+    # paths are the same: stop both there and compare the iterates at rounding level
+    cap = (ref["first_regularised"] if ref["n_regularised"] > 0 else ref["iters"]) // 2
+    _, refc = oracle_solve(x, u, tf, cst, r_des, stage, max_iter=cap)
+    resc = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
+                       [tf], cst[None], [r_des], max_iter=cap)
+    assert resc.iters[0] == refc["iters"] == cap
+    assert np.abs(resc.X[0] - refc["X"]).max() < TOL and np.abs(resc.U[0] - refc["U"]).max() < TOL
+    assert np.abs(resc.NU[0] - refc["NU"]).max() < TOL and abs(resc.tf[0] - refc["tf"]) < TOL
     # the result satisfies the reference NLP: dynamics with the reference's own A/B (from the golden file)
     e = P.dyn_residual(res.X[0], res.U[0], res.NU[0][:, :-1], res.tf[0])
     assert np.abs(e).max() < 1e-8
