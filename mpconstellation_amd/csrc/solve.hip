@@ -46,7 +46,7 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-2, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -1919,14 +1919,15 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     }
     __syncthreads();
 
-    double mu = kMuInit, dw_last = 0.0;
+    double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
+    const int nzc = n_ineq(K);
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
     for (int iter = 0;; ++iter) {
         it_count = iter;
         ResAcc r0;
         PT_BEGIN
-        eval_residual(s, sd, 0.0, mu, lane, r0);          // one evaluation serves E_0, E_mu (any mu) and the line search
+        eval_residual(s, sd, 0.0, 0.0, lane, r0);         // one evaluation serves E_0 and (any mu) the line search's ||F_mu||
         PT_END(0)
         E0 = scaled_error(r0, K, 0.0);
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
@@ -1934,17 +1935,9 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
         if (n_acc >= o.acc_iter) { status = MPCX_ST_ACCEPTABLE; break; }
         if (iter >= o.max_iter) { status = (E0 <= o.acc_tol) ? MPCX_ST_ACCEPTABLE : MPCX_ST_MAXITER; break; }
-        // monotone barrier update (ipopt: kappa_eps 10, kappa_mu 0.2, theta_mu 1.5)
-        const double mu_in = mu;
-        for (int guard = 0; guard < 64; ++guard) {
-            if (scaled_error(r0, K, mu) <= 10.0 * mu && mu > o.tol / 10.0) mu = fmax(o.tol / 10.0, fmin(0.2 * mu, pow(mu, 1.5)));
-            else break;
-        }
-        if (mu != mu_in) {                                   // the 2-norm of F_mu needs the new mu
-            PT_BEGIN
-            eval_residual(s, sd, 0.0, mu, lane, r0);
-            PT_END(0)
-        }
+        // adaptive barrier parameter: a fixed fraction of the iterate's mean complementarity ("Solver algorithm")
+        const double mu_cur = r0.prod_sum / (double)nzc;
+        mu = fmax(kSigma * mu_cur, o.tol / 10.0);
         // Newton direction, with Hessian regularisation retries on breakdown
         bool have_dir = false;
         double delta_w = 0.0, alpha = 1.0;
@@ -2042,8 +2035,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             status = MPCX_ST_NUMERIC; break;
         }
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
-        const double rn0 = sqrt(r0.sq);
-        const int nzc = n_ineq(K);
+        // ||F_mu||^2 of the iterate from the mu = 0 evaluation: sum (s z - mu)^2 = sum (s z)^2 - 2 mu sum s z + n mu^2
+        const double rn0 = sqrt(fmax(0.0, r0.sq - 2.0 * mu * r0.prod_sum + (double)nzc * mu * mu));
         for (int ls = 0; ls < 30; ++ls) {
             if (0.5 * alpha < kAlphaFloor) break;      // a rejection could not shorten the step any more: take it
             ResAcc rt;
@@ -2064,7 +2057,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
 #endif
         PT_BEGIN
-        apply_step(s, sd, alpha, mu, lane);
+        apply_step(s, sd, alpha, fmax(mu, mu_cur), lane);    // multiplier safeguard against the larger of mu, mean(s z)
         PT_END(9)
     }
 

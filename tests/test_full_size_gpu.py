@@ -114,7 +114,8 @@ def test_satellites_are_independent_units():
 
 def test_minimum_horizon_and_single_satellite():
     """K = 3 is the shortest horizon the solver accepts (one interior node); one satellite per call is the reference's
-    own use of Optimizer.  Same path as the oracle (no factorisation breaks down on these), compared at 1e-9."""
+    own use of Optimizer.  Same KKT point as the oracle, compared at the stated tolerance (these tiny problems run through
+    factorisation breakdowns, where device and oracle may regularise differently: tests/test_solve_gpu.py)."""
     from mpconstellation_amd import mpc_step_batch
     for K, sat in ((3, 0), (3, 5), (4, 0)):
         xbar, ubar, consts, r_des = workload(64, K, sat, 1)
@@ -123,7 +124,7 @@ def test_minimum_horizon_and_single_satellite():
         P = N.MpcProblem(xbar[0], ubar[0], 1.0, consts[0][0], od, O.constraint_terms(xbar[0], ubar[0], consts[0][0]),
                          {"r_des": float(r_des[0])})
         ref = N.solve(P)
-        assert ref["status"] == 0 and res.status[0] == 0 and ref["n_regularised"] == 0
+        assert ref["status"] == 0 and res.status[0] == 0
         assert res.X.shape == (1, 7, K) and res.U.shape == (1, 3, K) and res.NU.shape == (1, 7, K)
         assert np.abs(res.X[0] - ref["X"]).max() < 5e-6 and np.abs(res.U[0] - ref["U"]).max() < 5e-6
         assert abs(res.tf[0] - ref["tf"]) < 5e-6

@@ -14,6 +14,7 @@ import nlp_ipm as N
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9        # same stage data in -> same iteration path: agreement to rounding
+TOL_PATH = 1e-6   # iterates half way along the same path (unrefined directions, see test_solve_vs_oracle)
 TOL_SOL = 5e-6    # stated fp64 tolerance of a converged solution (tol 1e-8 on the scaled KKT error leaves the
                   # minimiser determined to ~1e-6 because the objective is flat: w_tr = 0.002); used wherever GPU and
                   # oracle discretise independently, where a 1e-16 difference can flip one line-search decision
@@ -56,14 +57,16 @@ def test_solve_vs_oracle(golden_dir, name):
     assert np.abs(res.NU[0] - ref["NU"]).max() < tol
     assert abs(res.tf[0] - ref["tf"]) < tol
     # ... and half way (to the end, or to the oracle's first breakdown: the device does not report its own) the two
-    # paths are the same: stop both there and compare the iterates at rounding level
+    # paths are the same: stop both there and compare the iterates.  Tolerance: a direction solved without refinement
+    # carries a relative error of 1e-9 .. 1e-6 depending on the barrier weights ("Linear solve"), which the
+    # following iterations contract again -- observed up to 2e-8 half way, 1e-14 at the end
     cap = (ref["first_regularised"] if ref["n_regularised"] > 0 else ref["iters"]) // 2
     _, refc = oracle_solve(x, u, tf, cst, r_des, stage, max_iter=cap)
     resc = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
                        [tf], cst[None], [r_des], max_iter=cap)
     assert resc.iters[0] == refc["iters"] == cap
-    assert np.abs(resc.X[0] - refc["X"]).max() < TOL and np.abs(resc.U[0] - refc["U"]).max() < TOL
-    assert np.abs(resc.NU[0] - refc["NU"]).max() < TOL and abs(resc.tf[0] - refc["tf"]) < TOL
+    assert np.abs(resc.X[0] - refc["X"]).max() < TOL_PATH and np.abs(resc.U[0] - refc["U"]).max() < TOL_PATH
+    assert np.abs(resc.NU[0] - refc["NU"]).max() < TOL_PATH and abs(resc.tf[0] - refc["tf"]) < TOL_PATH
     # the result satisfies the reference NLP: dynamics with the reference's own A/B (from the golden file)
     e = P.dyn_residual(res.X[0], res.U[0], res.NU[0][:, :-1], res.tf[0])
     assert np.abs(e).max() < 1e-8
