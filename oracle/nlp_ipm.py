@@ -13,7 +13,9 @@ What is restated
 * The solver it hands that NLP to is ipopt (third-party, unpinned, not installed here).  What is
   restated of ipopt is its published primal-dual interior-point scheme (Waechter & Biegler, Math.
   Prog. 106, 2006): slack form of the inequalities, relaxation of every bound by 1e-8*max(1,|b|)
-  (bound_relax_factor), slack initialisation (bound_push 1e-2), multipliers z = mu_init/s (ipopt's
+  (bound_relax_factor), slack initialisation s = max(-g, bound_push max(1,|b|)) with bound_push 1e-4 (ipopt: 1e-2; the
+  reference trajectory is nearly feasible and a smaller push keeps the start on it: 12.5 -> 10.9 iterations on the
+  benchmark constellation, nothing lost on the scenario sweeps), multipliers z = mu_init/s (ipopt's
   bound_mult_init_method = mu-based; its default 'constant 1' left 7 of 4096 benchmark satellites crawling
   along one boundary for 90-165 iterations), mu_init = 1 and the L1 slack pairs started dual feasible
   (z = w_nu/2, s = t = mu/z): mean iterations 42 -> 32,
@@ -67,7 +69,7 @@ DEFAULT_OPTIONS = dict(min_mass=0.1, u_lim=[0, 5], r_lim=[0.99, 5], r_des=1, eps
 
 ST_OK, ST_MAXITER, ST_NUMERIC, ST_ACCEPTABLE = 0, 5, 6, 7
 BOUND_RELAX = 1e-8
-BOUND_PUSH = 1e-2
+BOUND_PUSH = 1e-4
 KAPPA_SIGMA = 100.0
 GAMMA_NBHD = 1e-8
 DW_FIRST, DW_MIN, DW_MAX = 1e-4, 1e-20, 1e40     # ipopt first_hessian_perturbation, min_/max_hessian_perturbation
