@@ -70,7 +70,7 @@ __host__ __device__ inline int padded_nodes(int K) { return (K + 15) & ~15; }
 __host__ __device__ inline size_t ws_doubles(int K)
 {
     const size_t KP = (size_t)padded_nodes(K);
-    const size_t n = KP * (2 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 2 * GL_N;
+    const size_t n = KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 3 * GL_N;
     return (n + 15) & ~(size_t)15;
 }
 
@@ -258,7 +258,9 @@ struct Sat {
     cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
     gf64 *it, *dr, *nbs, *stT, *rbh;            // field-major [field][KP]: iterate, direction, Newton scalars, stage copy, r-hat
     gf64 *itg, *drg, *nb, *fac, *ch, *traj;     // globals; record-per-node arrays read by the recursion (one wave, one record)
+    gf64 *itB, *itgB;                           // the candidate iterate of the line search (swapped with it, itg on acceptance)
     __device__ Col<gf64> itn(int k) const { return Col<gf64>{wave_uniform(it), k, KP}; }
+    __device__ Col<gf64> itBn(int k) const { return Col<gf64>{wave_uniform(itB), k, KP}; }
     __device__ Col<gf64> drn(int k) const { return Col<gf64>{wave_uniform(dr), k, KP}; }
     __device__ Col<gf64> nsn(int k) const { return Col<gf64>{wave_uniform(nbs), k, KP}; }
     __device__ Col<gf64> rbn(int k) const { return Col<gf64>{wave_uniform(rbh), k, KP}; }
@@ -324,8 +326,14 @@ struct ResAcc {   // accumulators of one residual evaluation
 
 // Perturbed KKT residual F_mu at (iterate + a*direction): ipopt's scaled error pieces and the
 // 2-norm used by the line search.  Results are wave-uniform.
-__device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, int lane, ResAcc &out)
+// WRITE: the trial point is a candidate iterate -- slack reset s >= -g and multiplier safeguard z <= kappa mu_clip / s
+// are applied to it first, the residual is that of the corrected point, and the point is stored in the second
+// iterate buffer (s.itB, s.itgB): accepting the trial is a swap of the two buffers, and its residual is the next
+// iteration's.
+template <bool WRITE>
+__device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, double mu_clip, int lane, ResAcc &out)
 {
+#define POST(sv, zv, gval) { sv = fmax(sv, -(gval)); zv = fmin(zv, kKappaSigma * (mu_clip * rcp_pos(sv))); }
     const int K = s.K;
     double dual = 0.0, prim = 0.0, comp = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, pmax = -1e300, psum = 0.0;
     double gtf_part = 0.0;
@@ -341,7 +349,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
 #define TRIAL(P, D, off) trial_value(P, D, off, a, z)
     for (int k = NODE_OF(lane); k < K; k += 32) {
-        const auto p = s.itn(k), d = s.drn(k);
+        const auto p = s.itn(k), d = s.drn(k), w = s.itBn(k);
         const bool has_prev = (k >= 1), dyn = (k <= K - 2);
         // ---- chunk 0 (both halves, accounted by half 0): states, thrust, ball slacks, objective gradient ----
         double x[7], u[3], gx[7], gu[3], un[3];
@@ -349,13 +357,21 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
         for (int i = 0; i < 7; ++i) x[i] = TRIAL(p, d, I_X + i);
 #pragma unroll
         for (int i = 0; i < 3; ++i) u[i] = TRIAL(p, d, I_U + i);
-        const double su = TRIAL(p, d, I_SU), zu = TRIAL(p, d, I_ZU), srmax = TRIAL(p, d, I_SRMAX), zrmax = TRIAL(p, d, I_ZRMAX);
-        const double srmin = TRIAL(p, d, I_SRMIN), zrmin = TRIAL(p, d, I_ZRMIN);
+        double su = TRIAL(p, d, I_SU), zu = TRIAL(p, d, I_ZU), srmax = TRIAL(p, d, I_SRMAX), zrmax = TRIAL(p, d, I_ZRMAX);
+        double srmin = TRIAL(p, d, I_SRMIN), zrmin = TRIAL(p, d, I_ZRMIN);
         const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
         const auto rb = s.rbn(k);
         const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+        const double g_u = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
+        const double g_rmax = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax;
+        const double g_rmin = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
+        if (WRITE) {
+            POST(su, zu, g_u);
+            if (has_prev) POST(srmax, zrmax, g_rmax);
+            if (has_prev && dyn) POST(srmin, zrmin, g_rmin);
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * K + k]);
 #pragma unroll
@@ -366,15 +382,22 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
             if (dyn) { gx[0] -= rb0 * zrmin; gx[1] -= rb1 * zrmin; gx[2] -= rb2 * zrmin; }
         }
         if (h0) {
-            ACC_P(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u + su);       // thrust ball, every node
+            ACC_P(g_u + su);                                                 // thrust ball, every node
             ACC_C(su, zu);
             if (has_prev) {
-                ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax + srmax);
+                ACC_P(g_rmax + srmax);
                 ACC_C(srmax, zrmax);
                 if (dyn) {
-                    ACC_P(-(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin + srmin);
+                    ACC_P(g_rmin + srmin);
                     ACC_C(srmin, zrmin);
                 }
+            }
+            if (WRITE) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) w[I_X + i] = x[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[I_U + i] = u[i];
+                w[I_SU] = su; w[I_ZU] = zu; w[I_SRMAX] = srmax; w[I_ZRMAX] = zrmax; w[I_SRMIN] = srmin; w[I_ZRMIN] = zrmin;
             }
         } else {
 #pragma unroll
@@ -402,8 +425,9 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                 for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; bm[j] = Bm[i * 3 + j]; }
                 const double sg = Sg[i], xv = xi[i];
                 const double nu = TRIAL(p, d, I_NU + i), tt = TRIAL(p, d, I_T + i), lam = TRIAL(p, d, I_LAM + i);
-                const double stp = TRIAL(p, d, I_STP + i), ztp = TRIAL(p, d, I_ZTP + i);
-                const double stn = TRIAL(p, d, I_STN + i), ztn = TRIAL(p, d, I_ZTN + i);
+                double stp = TRIAL(p, d, I_STP + i), ztp = TRIAL(p, d, I_ZTP + i);
+                double stn = TRIAL(p, d, I_STN + i), ztn = TRIAL(p, d, I_ZTN + i);
+                if (WRITE && dyn) { POST(stp, ztp, nu - tt); POST(stn, ztn, -nu - tt); }
                 const double xn = TRIAL(pn, dn, I_X + i);
                 const double lmv = TRIAL(pm, dm, I_LAM + i);
                 const double lm = (valid && has_prev) ? lmv : 0.0;
@@ -432,6 +456,10 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #pragma unroll
                     for (int j = 0; j < 3; ++j) gu[j] -= bn[j] * lam;
                 }
+                if (WRITE && valid) {
+                    w[I_NU + i] = nu; w[I_T + i] = tt; w[I_LAM + i] = lam;
+                    w[I_STP + i] = stp; w[I_ZTP + i] = ztp; w[I_STN + i] = stn; w[I_ZTN + i] = ztn;
+                }
                 CHUNK_END
             }
             gtf_part -= sl;
@@ -451,15 +479,19 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                 for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
                 lsum += fabs(lvt);
                 for (int j = 0; j < 6; ++j) {
-                    const double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
-                    const double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
+                    double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
+                    double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
                     double gj = -sd.bT[j];
-                    for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; gx[i] += sd.aT[j][i] * zj; }
+                    for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
+                    if (WRITE) { POST(sj, zj, gj); s.itgB[G_STERM + j] = sj; s.itgB[G_ZTERM + j] = zj; }
+                    for (int i = 0; i < 7; ++i) gx[i] += sd.aT[j][i] * zj;
                     ACC_P(gj + sj);
                     ACC_C(sj, zj);
                 }
-                const double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
-                ACC_P(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax + srf);
+                double srf = s.itg[G_SRF] + a * s.drg[G_SRF], zrf = s.itg[G_ZRF] + a * s.drg[G_ZRF];
+                const double g_rf = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
+                if (WRITE) { POST(srf, zrf, g_rf); s.itgB[G_SRF] = srf; s.itgB[G_ZRF] = zrf; s.itgB[G_LVT] = lvt; }
+                ACC_P(g_rf + srf);
                 ACC_C(srf, zrf);
                 for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrf;
             }
@@ -474,8 +506,12 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     // tf stationarity and range constraints (lane 0 adds them after the reduction of gtf_part)
     double gtf = wave_sum(gtf_part);
     if (lane == 0) {
-        const double s0 = s.itg[G_STF] + a * s.drg[G_STF], s1 = s.itg[G_STF + 1] + a * s.drg[G_STF + 1];
-        const double z0 = s.itg[G_ZTF] + a * s.drg[G_ZTF], z1 = s.itg[G_ZTF + 1] + a * s.drg[G_ZTF + 1];
+        double s0 = s.itg[G_STF] + a * s.drg[G_STF], s1 = s.itg[G_STF + 1] + a * s.drg[G_STF + 1];
+        double z0 = s.itg[G_ZTF] + a * s.drg[G_ZTF], z1 = s.itg[G_ZTF + 1] + a * s.drg[G_ZTF + 1];
+        if (WRITE) {
+            POST(s0, z0, -tf - sd.b_tf[0]); POST(s1, z1, tf - sd.b_tf[1]);
+            s.itgB[G_TF] = tf; s.itgB[G_STF] = s0; s.itgB[G_STF + 1] = s1; s.itgB[G_ZTF] = z0; s.itgB[G_ZTF + 1] = z1;
+        }
         gtf += 1.0 + 2.0 * sd.w_tr * (tf - sd.tfbar) - z0 + z1;
         ACC_D(gtf);
         ACC_P(-tf - sd.b_tf[0] + s0);
@@ -487,9 +523,11 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #undef ACC_P
 #undef ACC_C
 #undef TRIAL
+#undef POST
     out.dual_max = wave_max(dual); out.prim_max = wave_max(prim); out.comp_max = wave_max(comp);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
     out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
+    if (WRITE) __syncthreads();            // the candidate iterate is complete before anybody reads it
 }
 
 __device__ __forceinline__ int n_ineq(int K) { return K + (K - 1) + (K - 2) + 6 + 1 + 14 * (K - 1) + 2; }
@@ -1717,83 +1755,6 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
     return amax;
 }
 
-// iterate <- iterate + a * direction, slack reset and multiplier safeguard (stage-parallel)
-__device__ __noinline__ void apply_step(const Sat &s, SatData &sd, double a, double mu, int lane)
-{
-    const int K = s.K;
-#define SAFE(sv, zv, gval) { double s_ = (sv), z_ = (zv); s_ = fmax(s_, -(gval)); \
-                             const double c_ = mu * rcp_pos(s_); \
-                             z_ = fmin(z_, kKappaSigma * c_); (sv) = s_; (zv) = z_; }
-    const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
-    const int half = HALF_OF(lane);
-    const bool h0 = (half == 0);
-    for (int k = NODE_OF(lane); k < K; k += 32) {
-        const auto p = s.itn(k), d = s.drn(k);
-        const auto rb = s.rbn(k);
-        // chunk 0 (both halves compute, half 0 stores): x, u and the three ball pairs
-        {
-            double v[16], dv[16];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) { v[i] = p[I_X + i]; dv[i] = d[I_X + i]; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { v[10 + i] = p[I_SU + i]; dv[10 + i] = d[I_SU + i]; }
-            const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] += a * dv[i];
-            const double *x = v, *u = v + 7;
-            SAFE(v[10], v[11], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u);
-            if (k >= 1) SAFE(v[12], v[13], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax);
-            if (k >= 1 && k <= K - 2) SAFE(v[14], v[15], -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin);
-            if (h0) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) p[I_X + i] = v[i];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) p[I_SU + i] = v[10 + i];
-            }
-        }
-        CHUNK_END
-        // four rounds: component i = 4*half + r of nu, t, lam and of the two L1 slack pairs
-        const bool dyn = (k <= K - 2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int iv = 4 * half + r;
-            const bool valid = iv < 7;
-            const int i = valid ? iv : 6;
-            const int off[7] = {I_NU + i, I_T + i, I_LAM + i, I_STP + i, I_ZTP + i, I_STN + i, I_ZTN + i};
-            double v[7], dv[7];
-#pragma unroll
-            for (int q = 0; q < 7; ++q) { v[q] = p[off[q]]; dv[q] = d[off[q]]; }
-#pragma unroll
-            for (int q = 0; q < 7; ++q) v[q] += a * dv[q];
-            if (dyn) {
-                SAFE(v[3], v[4], v[0] - v[1]);
-                SAFE(v[5], v[6], -v[0] - v[1]);
-            }
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < 7; ++q) p[off[q]] = v[q];
-            }
-            CHUNK_END
-        }
-    }
-    __syncthreads();
-    if (lane == 0) {
-        for (int i = 0; i < GL_N; ++i) s.itg[i] += a * s.drg[i];
-        const auto x = s.itn(K - 1) + I_X;
-        for (int j = 0; j < 6; ++j) {
-            double gj = -sd.bT[j];
-            for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
-            SAFE(s.itg[G_STERM + j], s.itg[G_ZTERM + j], gj);
-        }
-        SAFE(s.itg[G_SRF], s.itg[G_ZRF], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax);
-        const double tf = s.itg[G_TF];
-        SAFE(s.itg[G_STF], s.itg[G_ZTF], -tf - sd.b_tf[0]);
-        SAFE(s.itg[G_STF + 1], s.itg[G_ZTF + 1], tf - sd.b_tf[1]);
-    }
-#undef SAFE
-    __syncthreads();
-}
-
 // Launch order: satellites sorted by the previous solve's iteration count, longest first (counting sort, one block).
 // The order inside one count is whatever the atomics give; the solver's results do not depend on the order.
 __global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t *prev_iters, int32_t *order)
@@ -1855,6 +1816,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
     s.it = ws; ws += (size_t)KP * IT_N;
     s.dr = ws; ws += (size_t)KP * IT_N;
+    s.itB = ws; ws += (size_t)KP * IT_N;
     s.nbs = ws; ws += (size_t)KP * NS_N;
     s.stT = ws; ws += (size_t)KP * MPCX_STAGE_DOUBLES;
     s.rbh = ws; ws += (size_t)KP * 3;
@@ -1863,7 +1825,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     s.ch = ws; ws += (size_t)K * CH_N;
     s.traj = ws; ws += (size_t)K * NCH * TR_N;
     s.itg = ws; ws += GL_N;
-    s.drg = ws;
+    s.drg = ws; ws += GL_N;
+    s.itgB = ws;
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
@@ -1923,12 +1886,14 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     const int nzc = n_ineq(K);
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
+    // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
+    // (sq in its mu = 0 form: it serves E_0 and, for any mu, the line search's ||F_mu||)
+    ResAcc r0;
+    PT_BEGIN
+    eval_residual<false>(s, sd, 0.0, 0.0, 0.0, lane, r0);
+    PT_END(0)
     for (int iter = 0;; ++iter) {
         it_count = iter;
-        ResAcc r0;
-        PT_BEGIN
-        eval_residual(s, sd, 0.0, 0.0, lane, r0);         // one evaluation serves E_0 and (any mu) the line search's ||F_mu||
-        PT_END(0)
         E0 = scaled_error(r0, K, 0.0);
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
@@ -2037,11 +2002,15 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
         // ||F_mu||^2 of the iterate from the mu = 0 evaluation: sum (s z - mu)^2 = sum (s z)^2 - 2 mu sum s z + n mu^2
         const double rn0 = sqrt(fmax(0.0, r0.sq - 2.0 * mu * r0.prod_sum + (double)nzc * mu * mu));
+        // every trial is evaluated as the iterate it would become (slack reset and multiplier safeguard applied) and
+        // left in the second iterate buffer
+        const double mu_clip = fmax(mu, mu_cur);
+        ResAcc rt;
+        bool have_trial = false;
         for (int ls = 0; ls < 30; ++ls) {
             if (0.5 * alpha < kAlphaFloor) break;      // a rejection could not shorten the step any more: take it
-            ResAcc rt;
             PT_BEGIN
-            eval_residual(s, sd, alpha, mu, lane, rt);
+            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
             PT_END(10)
             const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
             const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
@@ -2049,16 +2018,22 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             // diagnostic build only: the first trial's margins into this satellite's U block
             if (ls == 0 && lane == 0 && 3 * iter + 2 < 3 * K) { double *lg = a.U + (size_t)sat * 3 * K + 3 * iter; lg[0] = alpha; lg[1] = sqrt(rt.sq) / rn0; lg[2] = rt.prod_min / (kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc)); }
 #endif
-            if (dec && cen) break;
+            if (dec && cen) { have_trial = true; break; }
             alpha *= 0.5;
+        }
+        if (!have_trial) {                              // the step taken untested
+            PT_BEGIN
+            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
+            PT_END(9)
         }
 #ifdef MPCX_ITER_LOG
         // diagnostic build only: iteration log (mu, E0, accepted step, regularisation) into this satellite's X block
         if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
 #endif
-        PT_BEGIN
-        apply_step(s, sd, alpha, fmax(mu, mu_cur), lane);    // multiplier safeguard against the larger of mu, mean(s z)
-        PT_END(9)
+        // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
+        { gf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
+        r0 = rt;
+        r0.sq = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;
     }
 
     // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----

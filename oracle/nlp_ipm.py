@@ -560,6 +560,17 @@ def step(it, d, a):
     return n
 
 
+def candidate(P, it, d, a, mu_clip):
+    """the iterate a step of length a would give: it + a d with the slacks reset to s >= -g and the multipliers
+    pulled back to z <= kappa mu / s (upper side only, see the header).  The line search tests this point."""
+    n = step(it, d, a)
+    g = P.ineq(n.X, n.U, n.NU, n.T, n.tf)
+    for k in n.s:
+        n.s[k] = np.maximum(n.s[k], -g[k])
+        n.z[k] = np.minimum(n.z[k], KAPPA_SIGMA * mu_clip / n.s[k])
+    return n
+
+
 def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_refine=1, dense=False,
           verbose=False):
     """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective, n_regularised = number of
@@ -602,19 +613,17 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
                 neg = dv[k] < 0
                 if neg.any(): a = min(a, (-tau * v[k][neg] / dv[k][neg]).min())
         r0 = residual_norm(P, it, mu)
+        mu_clip = max(mu, mu_cur)
+        n = None
         for ls in range(30):
-            if 0.5 * a < ALPHA_FLOOR: break            # a rejection could not shorten the step any more: take it
-            n = step(it, d, a)
+            if 0.5 * a < ALPHA_FLOOR: n = None; break   # a rejection could not shorten the step any more: take it
+            n = candidate(P, it, d, a, mu_clip)
             prod = np.concatenate([(n.s[k] * n.z[k]).ravel() for k in n.s])
             if residual_norm(P, n, mu) <= (1 - 1e-4 * a) * r0 and prod.min() >= GAMMA_NBHD * min(mu, prod.mean()):
                 break
             a *= 0.5
         if verbose: print(f"       mu {mu:.2e} step {a:.4f} delta_w {dw:.1e}")
-        it = step(it, d, a)
-        g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
-        for k in it.s:
-            it.s[k] = np.maximum(it.s[k], -g[k])                                        # slack reset
-            it.z[k] = np.minimum(it.z[k], KAPPA_SIGMA * max(mu, mu_cur) / it.s[k])     # upper side only, see the header
+        it = n if n is not None else candidate(P, it, d, a, mu_clip)
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
     T = np.zeros((7, K)); T[:, :K - 1] = it.T
