@@ -275,13 +275,6 @@ struct Sat {
     __device__ cgf64 *Sig(int k) const { return A(k) + 91; }
 };
 
-// Trial point (iterate + a * direction) of one node, everything a residual evaluation needs.
-struct NodeVals {
-    double x[7], u[3], nu[7], t[7], lam[7];
-    double stp[7], ztp[7], stn[7], ztn[7];
-    double su, zu, srmax, zrmax, srmin, zrmin;
-};
-
 // iterate + a * direction for one field, branch-free: both loads always issue (so they can all be in flight
 // together); at a == 0 the direction value, which may be stale, is replaced by 0.
 __device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64> &d, int off, double a, bool z)
@@ -290,25 +283,8 @@ __device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64
     return fma(a, z ? 0.0 : dv, pv);
 }
 
-__device__ __forceinline__ void load_node(const Sat &s, int k, double a, NodeVals &n)
-{
-    const auto p = s.itn(k), d = s.drn(k);
-    const bool z = (a == 0.0);
-#define LD(off) trial_value(p, d, off, a, z)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        n.x[i] = LD(I_X + i); n.nu[i] = LD(I_NU + i); n.t[i] = LD(I_T + i); n.lam[i] = LD(I_LAM + i);
-        n.stp[i] = LD(I_STP + i); n.ztp[i] = LD(I_ZTP + i); n.stn[i] = LD(I_STN + i); n.ztn[i] = LD(I_ZTN + i);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) n.u[i] = LD(I_U + i);
-    n.su = LD(I_SU); n.zu = LD(I_ZU); n.srmax = LD(I_SRMAX); n.zrmax = LD(I_ZRMAX);
-    n.srmin = LD(I_SRMIN); n.zrmin = LD(I_ZRMIN);
-#undef LD
-}
-
 struct ResAcc {   // accumulators of one residual evaluation
-    double dual_max, prim_max, comp_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
+    double dual_max, prim_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
 };
 
 // The node-parallel phases are written as chunks "loads -> arithmetic (-> stores)" separated by scheduling
@@ -335,7 +311,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 {
 #define POST(sv, zv, gval) { sv = fmax(sv, -(gval)); zv = fmin(zv, kKappaSigma * (mu_clip * rcp_pos(sv))); }
     const int K = s.K;
-    double dual = 0.0, prim = 0.0, comp = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, pmax = -1e300, psum = 0.0;
+    double dual = 0.0, prim = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, pmax = -1e300, psum = 0.0;
     double gtf_part = 0.0;
     const double tf = s.itg[G_TF] + a * s.drg[G_TF];
     const double lvt = s.itg[G_LVT] + a * s.drg[G_LVT];
@@ -345,7 +321,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     const bool h0 = (half == 0);
 #define ACC_D(v) { const double q_ = (v); dual = fmax(dual, fabs(q_)); sq += q_ * q_; }
 #define ACC_P(v) { const double q_ = (v); prim = fmax(prim, fabs(q_)); sq += q_ * q_; }
-#define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; comp = fmax(comp, fabs(q_)); sq += q_ * q_; \
+#define ACC_C(sv, zv) { const double s_ = (sv), z_ = (zv), q_ = s_ * z_ - mu; sq += q_ * q_; \
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
 #define TRIAL(P, D, off) trial_value(P, D, off, a, z)
     for (int k = NODE_OF(lane); k < K; k += 32) {
@@ -524,7 +500,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #undef ACC_C
 #undef TRIAL
 #undef POST
-    out.dual_max = wave_max(dual); out.prim_max = wave_max(prim); out.comp_max = wave_max(comp);
+    out.dual_max = wave_max(dual); out.prim_max = wave_max(prim);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
     out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
     if (WRITE) __syncthreads();            // the candidate iterate is complete before anybody reads it
