@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--workload", default="S64_K30", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra S4096_K30 measurement of the default run")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="satellites solved by the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="satellites solved by the CPU oracle")
     args = ap.parse_args()
 
     import torch
