@@ -105,7 +105,9 @@ typedef struct {
 /* By default the solver launches its per-satellite workgroups longest-first, ordered by the iteration counts of
  * the previous solve of the same batch size on this context (consecutive MPC steps pose similar problems; with a
  * few satellites per wave slot the launch ends when the slowest slot does).  Results never depend on the launch
- * order.  This flag keeps the plain index order. */
+ * order.  The counts are the library's own copy, written and read on the stream of the calls: consecutive solves on
+ * one context must be enqueued on the same stream (or be ordered by the caller).  This flag keeps the plain index
+ * order. */
 #define MPCX_SOLVE_INDEX_ORDER 1
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);

@@ -123,6 +123,15 @@ def iptr(a):
     return a.ctypes.data_as(_ip)
 
 
+SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
+
+
+def check_solver_keywords(solver):
+    bad = sorted(set(solver) - set(SOLVER_KEYWORDS))
+    if bad:
+        raise TypeError(f"unknown solver option(s) {bad}; known: {list(SOLVER_KEYWORDS)}")
+
+
 # reference option keys (optimizer.py:178-188) -> mpcx_solve_opts
 def make_solve_opts(options=None, **solver):
     """options: dict with the reference's keys (min_mass, u_lim, r_lim, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr;
@@ -135,6 +144,7 @@ def make_solve_opts(options=None, **solver):
     if "r_lim" in options: o.r_min, o.r_max = options["r_lim"][0], options["r_lim"][1]
     for k in ("eps_r", "eps_vr", "eps_vn", "tf_max", "w_nu", "w_tr"):
         if k in options: setattr(o, k, options[k])
+    check_solver_keywords(solver)
     for k, v in solver.items():
         setattr(o, k, v)
     return o

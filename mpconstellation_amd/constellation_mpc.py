@@ -10,6 +10,8 @@ is one batched device call over all satellites, each with its own SatelliteScale
 The number of nodes of the second SCP iteration is int(base_res * tf_u) and differs between satellites, as does the
 length of the thrust table played back during the segment; satellites are grouped by node count and every group is
 one batch, so each satellite gets exactly the result of the single-satellite path (tests/test_mpc_loop_gpu.py)."""
+import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -39,15 +41,31 @@ def foh_resample(u, n):
     return out
 
 
+MAX_SLOTS = 8      # contexts (streams) used side by side by one ConstellationMPC step
+
+
 def _concurrently(fn, jobs, device, **kw):
     """Several batched calls at once.  A rollout is ~1000 sequential RK45 steps and a solve ~25-50 sequential
-    interior-point iterations however few satellites the call carries, so the groups run concurrently, each host
-    thread on its own context and stream (include/mpcx.h)."""
+    interior-point iterations however few satellites the call carries, so the groups run concurrently.  A context is
+    not thread-safe (include/mpcx.h: one context per host thread): every worker thread of the pool owns one context
+    slot for its whole life (taken from a queue by the pool initialiser), so however many jobs there are no two calls
+    in flight ever share a context."""
     if len(jobs) == 1:
         return [fn(*jobs[0], device=device, **kw)]
-    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as pool:
-        futs = [pool.submit(fn, *job, device=device, slot=1 + i % 8, **kw) for i, job in enumerate(jobs)]
-        return [f.result() for f in futs]
+    n = min(MAX_SLOTS, len(jobs))
+    free = queue.SimpleQueue()
+    for slot in range(1, n + 1):
+        free.put(slot)
+    own = threading.local()
+
+    def take_slot():
+        own.slot = free.get_nowait()           # n workers, n slots: never empty
+
+    def run(job):
+        return fn(*job, device=device, slot=own.slot, **kw)
+
+    with ThreadPoolExecutor(max_workers=n, initializer=take_slot) as pool:
+        return list(pool.map(run, jobs))
 
 
 def _rollouts(jobs, device):

@@ -13,9 +13,15 @@ class Controller:
         self.sats = sats
         self.sat_ids = set(s.id for s in sats)
 
+    def _own(self, f):
+        """marks a thrust function as this controller's, so that Simulator.get_trajectory_ODE can tell it from a foreign
+        callable (which the device cannot integrate)"""
+        f._mpcx_controller = self
+        return f
+
     def get_u_func(self, sat_id=None):
         zero = np.array([0., 0., 0.])
-        return lambda x, tau: zero
+        return self._own(lambda x, tau: zero)
 
     def update(self):
         pass
@@ -32,7 +38,7 @@ class ConstantThrustController(Controller):
         self.thrust = thrust
 
     def get_u_func(self, sat_id=None):
-        return lambda x, tau: self.thrust
+        return self._own(lambda x, tau: self.thrust)
 
     def device_law(self):
         return _ffi.CTRL_CONSTANT, np.asarray(self.thrust, dtype=np.float64), 0, None
@@ -52,7 +58,7 @@ class ConstantTangentialThrustController(Controller):
         return np.column_stack([r_hat, np.cross(h_hat, r_hat), h_hat])
 
     def get_u_func(self, sat_id=None):
-        return lambda x, tau: self.compute_rotation(x) @ np.array([0, self.tangential_thrust, 0])
+        return self._own(lambda x, tau: self.compute_rotation(x) @ np.array([0, self.tangential_thrust, 0]))
 
     def device_law(self):
         return _ffi.CTRL_TANGENTIAL, np.array([float(self.tangential_thrust)]), 0, None
@@ -82,7 +88,7 @@ class SequenceController(Controller):
             if tau <= self.end_tau:
                 return self.u_FOH(tau / self.end_tau)
             return np.array([0., 0., 0.])
-        return u
+        return self._own(u)
 
     def device_law(self):
         return _ffi.CTRL_SEQUENCE, np.ascontiguousarray(self.u, dtype=np.float64), self.u.shape[1], float(self.end_tau)

@@ -34,7 +34,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return MPCX_E_HIP;
     mpcx_ctx *c = new mpcx_ctx();
     c->device = device; c->err[0] = 0; c->ws = nullptr; c->ws_bytes = 0;
-    c->prev_iters = nullptr; c->order = nullptr; c->order_S = 0; c->order_valid = 0;
+    c->prev_iters = nullptr; c->order = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         snprintf(g_create_err, sizeof g_create_err, "hipStreamCreate failed");

@@ -17,7 +17,7 @@ struct mpcx_ctx {
     // launch order of the solver's workgroups: the previous solve's iteration counts (library-owned copy) sorted
     // longest first; valid only for a following solve of the same batch size
     int32_t *prev_iters, *order;
-    int order_S, order_valid;
+    int order_S, order_valid, order_cap;
 };
 
 inline int ctx_fail(mpcx_ctx *ctx, int code, const char *msg)

@@ -126,7 +126,7 @@ __device__ __forceinline__ void wsync()
 
 // 1/d for d > 0 well inside the normal range: hardware seed + two Newton steps (the full IEEE division sequence
 // with its scaling / fix-up is not needed for pivots, slacks and determinants).  Measured on gfx950 over 1e-40..1e40
-// (tools/rcp_accuracy.hip): seed 4.5e-8 relative, one step 2.1e-15, two steps 1.1e-16 = half an ulp.
+// (profiles/tools/rcp_accuracy.hip): seed 4.5e-8 relative, one step 2.1e-15, two steps 1.1e-16 = half an ulp.
 __device__ __forceinline__ double rcp_pos(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -1746,7 +1746,9 @@ __global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t
         for (int key = 255; key >= 0; --key) { base[key] = acc; acc += hist[key]; }
     }
     __syncthreads();
-    for (int i = tid; i < S; i += 1024) order[atomicAdd(&base[min(max(prev_iters[i], 0), 255)], 1)] = i;
+    // (prev_iters is written by the previous solve on the SAME stream, include/mpcx.h; the clamp keeps a scatter past
+    // the table impossible even if a caller breaks that rule and the two passes see different counts)
+    for (int i = tid; i < S; i += 1024) order[min(atomicAdd(&base[min(max(prev_iters[i], 0), 255)], 1), S - 1)] = i;
 }
 
 // a satellite whose discretisation failed reports that code instead of the solver's
@@ -2087,14 +2089,18 @@ extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *s
     const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER);
     a.order = nullptr;
     if (adaptive) {
-        if (ctx->order_S != S) {
+        // grow-only buffers (a smaller batch reuses them: no free / allocation, hence no implicit device synchronisation,
+        // when ConstellationMPC alternates group sizes on one context); the stored counts are valid only for a following
+        // solve of the same batch size
+        if (ctx->order_cap < S) {
             if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
             if (ctx->order) (void)hipFree(ctx->order);
-            ctx->prev_iters = ctx->order = nullptr; ctx->order_S = 0; ctx->order_valid = 0;
+            ctx->prev_iters = ctx->order = nullptr; ctx->order_cap = 0; ctx->order_S = 0; ctx->order_valid = 0;
             MPCX_HIP(ctx, hipMalloc((void **)&ctx->prev_iters, (size_t)S * sizeof(int32_t)));
             MPCX_HIP(ctx, hipMalloc((void **)&ctx->order, (size_t)S * sizeof(int32_t)));
-            ctx->order_S = S;
+            ctx->order_cap = S;
         }
+        if (ctx->order_S != S) { ctx->order_S = S; ctx->order_valid = 0; }
         if (ctx->order_valid) {
             hipLaunchKernelGGL(launch_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, ctx->prev_iters, ctx->order);
             a.order = ctx->order;

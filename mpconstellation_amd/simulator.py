@@ -64,7 +64,7 @@ class Simulator:
     def _rollout(self, sats, tf):
         const = self.scale.get_normalized_constants().as_vector()
         y0 = np.stack([self.scale.normalize_state(s.get_state_vector()) for s in sats])
-        law = self.controller.device_law()
+        law = self._device_law()
         y, status, nsteps = propagate_batch(y0, tf, np.tile(const, (len(sats), 1)), law, self.eval_points,
                                             self.include_drag, self.include_J2, 0.001, self.device)
         if (status == 1).any():
@@ -73,6 +73,17 @@ class Simulator:
             raise RuntimeError(f"propagation failed: {[_ffi.STATUS_TEXT.get(int(c), c) for c in status if c]}")
         t = np.linspace(0, 1, self.eval_points)
         return [OdeResult(t.copy(), y[i], int(status[i]), int(nsteps[i])) for i in range(len(sats))]
+
+    def _device_law(self):
+        """The controller's thrust law in the form the device propagator takes.  A Controller subclass that overrides
+        get_u_func (the reference's extension point, control.py:20-29) without providing the matching device_law
+        would otherwise be flown with its base class's law."""
+        cls = type(self.controller)
+        owner = lambda name: next(k for k in cls.__mro__ if name in k.__dict__)
+        if not hasattr(cls, "device_law") or not issubclass(owner("device_law"), owner("get_u_func")):
+            raise NotImplementedError(f"{cls.__name__} overrides get_u_func without a device_law(): only the thrust laws "
+                                      "of control.py run on the device (there is no host integrator)")
+        return self.controller.device_law()
 
     def run(self, tf=10):
         """reference simulator.py:29-48"""
@@ -106,7 +117,14 @@ class Simulator:
             self.run_segment(tf=tf_step)
 
     def get_trajectory_ODE(self, sat, tf, u_func=None):
-        """reference simulator.py:164-189; the thrust law is taken from self.controller (device form)."""
+        """reference simulator.py:164-189; the thrust law is the controller's (device form).  The reference integrates
+        whatever callable it is handed; here only the controller's own law (what run/run_segment pass, :42,61) is
+        accepted, anything else raises instead of being ignored."""
+        mine = (self.controller, getattr(self.controller, "sequence_controller", None))
+        owner = getattr(u_func, "_mpcx_controller", None)
+        if u_func is not None and (owner is None or not any(owner is m for m in mine)):
+            raise NotImplementedError("get_trajectory_ODE integrates the controller's device thrust law; an arbitrary "
+                                      "u_func callable cannot run on the device (there is no host integrator)")
         return self._rollout([sat], tf)[0]
 
     @staticmethod

@@ -1,7 +1,7 @@
-"""diagnostic (not a test): A/B timing of two builds of libmpcx.so on the same box, alternating runs
-usage: python tools/dbg_ab.py libA.so libB.so [workload ...]"""
+"""profiling helper: A/B timing of two builds of libmpcx.so on the same box, alternating runs
+usage: python profiles/tools/ab_timing.py libA.so libB.so [workload ...]"""
 import os, sys, subprocess
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 libs = [os.path.abspath(a) for a in sys.argv[1:3]]
 wls = sys.argv[3:] or ["S64_K30", "S4096_K30"]
 code = '''

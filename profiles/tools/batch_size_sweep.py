@@ -1,6 +1,6 @@
-"""diagnostic (not a test): solve_kernel time against the number of satellites (1 .. 4 waves per SIMD's worth)"""
+"""profiling helper: solve_kernel time against the number of satellites (1 .. 4 waves per SIMD's worth)"""
 import os, sys
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import torch, bench
 for S in [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 2048, 3072, 4096, 8192]:

@@ -1,7 +1,7 @@
-"""diagnostic (not a test): per-iteration log of solve_kernel from a -DMPCX_ITER_LOG build"""
+"""profiling helper: per-iteration log of solve_kernel from a -DMPCX_ITER_LOG build"""
 import os, sys, subprocess
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from mpconstellation_amd import build as b
 lib = "/tmp/libmpcx_iterlog.so"

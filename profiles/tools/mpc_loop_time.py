@@ -1,6 +1,6 @@
-"""diagnostic (not a test): where a ConstellationMPC.run_segment spends its time"""
+"""profiling helper: where a ConstellationMPC.run_segment spends its time"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from mpconstellation_amd import Satellite, ConstellationMPC
 from mpconstellation_amd import constellation_mpc as cm

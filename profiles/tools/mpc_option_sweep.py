@@ -1,7 +1,7 @@
-"""diagnostic (not a test): convergence statistics with the options OptimalController passes (control.py:192-197):
+"""profiling helper: convergence statistics with the options OptimalController passes (control.py:192-197):
 orbit raising to r_des with eps_r 1e-6, eps_vr 1e-16, tf_max = horizon"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from mpconstellation_amd import mpc_step_batch, _ffi
 from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust

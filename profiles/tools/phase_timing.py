@@ -1,7 +1,7 @@
-"""diagnostic (not a test): per-phase cycle shares of solve_kernel from a -DMPCX_PHASE_TIMING build"""
+"""profiling helper: per-phase cycle shares of solve_kernel from a -DMPCX_PHASE_TIMING build"""
 import os, sys, subprocess, ctypes as C
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from mpconstellation_amd import build as b
 lib = "/tmp/libmpcx_timing.so"

@@ -1,6 +1,6 @@
-"""diagnostic (not a test): convergence statistics of the device solver over scenario variations"""
+"""profiling helper: convergence statistics of the device solver over scenario variations"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from mpconstellation_amd import mpc_step_batch, _ffi
 from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust

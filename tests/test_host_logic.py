@@ -102,6 +102,60 @@ def test_constellation_generator_and_sharding(golden_dir):
         assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
 
 
+def test_concurrent_jobs_never_share_a_context():
+    """ConstellationMPC runs its node-count groups concurrently on separate contexts; a context is not thread-safe
+    (include/mpcx.h), so with more jobs than slots (17 here, 8 slots) no two calls in flight may hold the same slot."""
+    import threading
+    import time
+    from mpconstellation_amd import constellation_mpc as cm
+    lock = threading.Lock(); busy = set(); seen = []; clashes = []
+
+    def fake_call(i, device=0, slot=0):
+        with lock:
+            if slot in busy: clashes.append((i, slot))
+            busy.add(slot); seen.append(slot)
+        time.sleep(0.01 * (1 + i % 3))
+        with lock:
+            busy.discard(slot)
+        return i
+
+    out = cm._concurrently(fake_call, [(i,) for i in range(17)], 0)
+    assert out == list(range(17))                            # results in job order
+    assert not clashes
+    assert set(seen) <= set(range(1, cm.MAX_SLOTS + 1)) and len(set(seen)) > 1
+    assert cm._concurrently(fake_call, [(5,)], 0) == [5]     # a single job runs on the caller's own context (slot 0)
+
+
+def test_foreign_thrust_laws_and_unknown_options_are_rejected():
+    """The device propagates the four thrust laws of control.py; a callable it cannot see must not be silently replaced
+    by one of them (reference extension points: get_trajectory_ODE's u_func argument, simulator.py:164-189, and
+    Controller.get_u_func overrides, control.py:20-29)."""
+    from mpconstellation_amd import Simulator, Controller, ConstantThrustController, _ffi
+    sim = Simulator(sats=[hubble()], controller=ConstantThrustController([], np.ones(3)))
+    with pytest.raises(NotImplementedError):
+        sim.get_trajectory_ODE(hubble(), 1.0, lambda x, tau: np.ones(3))
+    with pytest.raises(NotImplementedError):                 # another controller's law is foreign too
+        sim.get_trajectory_ODE(hubble(), 1.0, Controller().get_u_func())
+    assert sim.controller.get_u_func()._mpcx_controller is sim.controller     # its own law passes the check
+
+    class Mine(Controller):
+        def get_u_func(self, sat_id=None):
+            return lambda x, tau: np.array([1., 0., 0.])
+
+    with pytest.raises(NotImplementedError):
+        Simulator(sats=[hubble()], controller=Mine())._device_law()
+
+    class MineWithLaw(Mine):
+        def device_law(self):
+            return _ffi.CTRL_CONSTANT, np.array([1., 0., 0.]), 0, None
+
+    assert Simulator(sats=[hubble()], controller=MineWithLaw())._device_law()[0] == _ffi.CTRL_CONSTANT
+    assert Simulator(sats=[hubble()], controller=Controller())._device_law()[0] == _ffi.CTRL_ZERO
+    with pytest.raises(TypeError):
+        _ffi.check_solver_keywords({"max_iters": 10})        # misspelt: the field is max_iter
+    _ffi.check_solver_keywords({"max_iter": 10, "tol": 1e-9})
+
+
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
