@@ -26,8 +26,12 @@ What is restated
 
 PARITY UNPINNED at this boundary: the reference's own tests hold no numbers for solve_OPT and
 ipopt cannot be run here, so nothing below is checked against ipopt output.  It is checked by
-KKT residuals, by an independent dense Newton/KKT solve, and against scipy trust-constr on the
-full (un-eliminated, polynomial) NLP -- see tests/test_oracle_solver.py.
+KKT residuals, by an independent dense Newton/KKT solve, and against solutions of the full
+(un-eliminated, polynomial) NLP computed by scipy's trust-constr from a second, independent transcription
+of optimizer.py (tests/golden/make_nlp_xcheck.py -> xcheck_*.npz: the reference's own A/B matrices, default
+and OptimalController option sets, the constant-thrust reference whose optimum needs virtual control, the
+convex linearised-vt variant, ipopt's all-zero start) -- see tests/test_oracle_solver.py.  The same fixtures
+check the HIP kernel directly (tests/test_solve_xcheck_gpu.py).
 
 Deliberate differences from ipopt's path (none changes the NLP or its KKT points)
 * start: the reference trajectory (x_bar, u_bar, nu=0, tf_bar); ipopt starts from zeros because
@@ -60,7 +64,23 @@ Deliberate differences from ipopt's path (none changes the NLP or its KKT points
   0.2, LOQO's centrality rule or a sigma tied to the last step length are all worse than 0.1.
 * x_0 is eliminated (it is fixed by an equality), nu_{K-1}, t_{K-1} (which enter no dynamics row) are
   reported as 0.
-* linear algebra: stage-wise Riccati recursion (see riccati_factor_solve) instead of MUMPS.
+* linear algebra: stage-wise Riccati recursion (see riccati_factor / riccati_solve) instead of MUMPS.  Barrier
+  weights z/s reach 1e14..1e16 on active constraints at mu = 1e-9; three devices keep the structured solve as
+  accurate as a pivoted factorisation of the un-condensed system (with them the MPC option set of control.py:192-197
+  and optima with non-zero virtual control converge like the dense LAPACK path; without them they stalled):
+  - terminal rank-1 terms above TERM_CAP leave the recursion as border unknowns zeta (1/w form, no huge entry);
+  - the border unknowns (dtf, vt multiplier, zetas) are part of the direction that iterative refinement corrects:
+    the residual carries zeta explicitly, so a refinement pass solves for small corrections and removes the
+    cancellation error of the first pass's channel combination (reduced_residual);
+  - stage terms above STAGE_CAP (an active r_min plane, radius or thrust ball) enter the recursion through a
+    Sherman-Morrison update of (Q_uu^-1, gain, P_k) in which the weight appears only as its reciprocal.
+
+Variants and modes (tests only; the device implements variant exact/linvt in the FAST mode from the reference start)
+* MpcProblem(variant="linvt"): the linearised tangential pair of optimizer.py:471-489 instead of the quartic: convex.
+* solve(start=...): "ref" (default), "zero" (pyomo's unset Vars: ipopt's start; only where the reduced tangential
+  form is defined, i.e. variant linvt), or explicit arrays.
+* solve(mode="ipopt_default"): ipopt's documented defaults for the barrier strategy and initialisation (IPOPT_DEFAULT
+  below), frozen; the FAST parameters are the tuned ones.  Both must end at the same point (tested).
 """
 import numpy as np
 
@@ -78,6 +98,7 @@ MU_INIT = 1.0
 SIGMA = 0.1           # every iteration aims at mu = SIGMA * mean(s z)
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
 REFINE_TW = 1e9       # iterative refinement only once a barrier weight z/s (terminal terms, stage balls/planes, tf) exceeds this
+STAGE_CAP = 1e8       # share of a stage barrier weight kept inside the Hessian blocks of the recursion
 N_TERM = 5            # rank-1 terminal barrier directions: rf_min, vr, vn, mass, |r|^2
 
 
@@ -105,9 +126,12 @@ class MpcProblem:
     """One satellite's SCP subproblem.  stage = dict(A (K-1,7,7), Bp, Bn (K-1,7,3), Sigma, xi (7,K-1));
     terms = output of Optimizer.get_constraint_terms for this satellite (optimizer.py:80-170)."""
 
-    def __init__(self, xbar, ubar, tfbar, mu_grav, stage, terms, options=None):
+    def __init__(self, xbar, ubar, tfbar, mu_grav, stage, terms, options=None, variant="exact"):
+        """variant "exact": the quartic tangential-velocity equality the reference enables (optimizer.py:577);
+        "linvt": the linearised pair it keeps commented out (:471-489, :575-576) instead -- a convex problem."""
         o = {**DEFAULT_OPTIONS, **(options or {})}
-        self.o = o
+        self.o = o; self.variant = variant
+        assert variant in ("exact", "linvt")
         self.xbar = np.array(xbar, dtype=float); self.ubar = np.array(ubar, dtype=float)
         self.tfbar = float(tfbar)
         self.K = K = self.xbar.shape[1]
@@ -119,7 +143,8 @@ class MpcProblem:
         self.b_rmax = rl(o["r_lim"][1] ** 2)                          # :393-395
         self.b_rmin = rl(-o["r_lim"][0])                              # :384-391  (-rhat.r <= -r_min)
         self.rbar_hat = np.array(terms["rbar_hat"])                   # (3,K-1)
-        aT = np.zeros((6, 7)); bT = np.zeros(6)
+        nT = 8 if variant == "linvt" else 6
+        aT = np.zeros((nT, 7)); bT = np.zeros(nT)
         aT[0, :3] = -np.asarray(terms["rf_hat"]); bT[0] = rl(-(o["r_des"] - o["eps_r"]))      # :398-402
         for row, (V, D, Db, eps) in zip((1, 3), (("Vr", "DrVr_DvVr", "DrVr_DvVr_bar", "eps_vr"),
                                                  ("Vn", "DrVn_DvVn", "DrVn_DvVn_bar", "eps_vn"))):
@@ -127,6 +152,12 @@ class MpcProblem:
             aT[row, :6] = g; bT[row] = rl(o[eps] - c0)                # :406-410 / :436-440
             aT[row + 1, :6] = -g; bT[row + 1] = rl(o[eps] + c0)       # :412-416 / :442-446
         aT[5, 6] = -1.0; bT[5] = rl(-o["min_mass"])                   # :351-352
+        if variant == "linvt":
+            # |Vt_lin(x_K) - Vc_lin(r_K)| <= eps_vt: min_tan_vel_rule (:480-489) row 6, max_tan_vel_rule (:471-479) row 7
+            g = np.array(terms["DrVt_DvVt"], dtype=float).copy(); g[:3] -= np.asarray(terms["DrVc"])
+            c0 = terms["Vt"] - terms["DrVt_DvVt_bar"] - terms["Vc"] + terms["DrVc_rbar"]
+            aT[6, :6] = g; bT[6] = rl(o["eps_vt"] - c0)
+            aT[7, :6] = -g; bT[7] = rl(o["eps_vt"] + c0)
         self.aT, self.bT = aT, bT
         self.b_rfmax = rl((o["r_des"] + o["eps_r"]) ** 2)             # :403
         self.b_tf = np.array([rl(0.0), rl(o["tf_max"])])              # :588
@@ -164,21 +195,42 @@ class Iterate:
         n = Iterate(); n.__dict__.update(self.__dict__); return n
 
 
-def initial_iterate(P):
+FAST = dict(mu_strategy="adaptive", mu_init=MU_INIT, bound_push=BOUND_PUSH, kappa_sigma=KAPPA_SIGMA, kappa_two_sided=False,
+            z_init="mu", centred_l1=True)
+# ipopt's documented defaults for the same knobs: monotone Fiacco-McCormick barrier update, mu_init 0.1, bound_push 1e-2,
+# bound_mult_init_val 1, kappa_sigma 1e10 on both sides.  FROZEN: speed work changes FAST only; tests/test_oracle_solver.py
+# requires both modes to end at the same solution, so that tuning cannot move the answer.
+IPOPT_DEFAULT = dict(mu_strategy="monotone", mu_init=0.1, bound_push=1e-2, kappa_sigma=1e10, kappa_two_sided=True,
+                     z_init="one", centred_l1=False)
+
+
+def initial_iterate(P, start="ref", prm=FAST):
+    """start "ref": the reference trajectory (x_bar, u_bar, tf_bar); "zero": every variable 0 as pyomo hands the model
+    to ipopt (Vars without initial values, optimizer.py:267-270, 287; x_0 is eliminated and stays x_bar_0);
+    or a dict(X, U, tf[, NU]) of arrays."""
     K = P.K; it = Iterate()
-    it.X = P.xbar.copy(); it.U = P.ubar.copy(); it.tf = P.tfbar
+    if isinstance(start, dict):
+        it.X = np.array(start["X"], dtype=float); it.U = np.array(start["U"], dtype=float); it.tf = float(start["tf"])
+        it.X[:, 0] = P.xbar[:, 0]
+    elif start == "zero":
+        it.X = np.zeros_like(P.xbar); it.X[:, 0] = P.xbar[:, 0]; it.U = np.zeros_like(P.ubar); it.tf = 0.0
+    else:
+        it.X = P.xbar.copy(); it.U = P.ubar.copy(); it.tf = P.tfbar
     it.NU = np.zeros((7, K - 1)); it.T = np.zeros((7, K - 1))
+    if isinstance(start, dict) and "NU" in start: it.NU = np.array(start["NU"], dtype=float)[:, :K - 1].copy()
     it.lam = np.zeros((7, K - 1)); it.lam_vt = 0.0
     g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
     bnd = {"u": P.b_u, "rmax": P.b_rmax, "rmin": P.b_rmin, "term": P.bT, "rfmax": P.b_rfmax, "tp": 0.0,
            "tn": 0.0, "tf": P.b_tf}
-    it.s = {k: np.maximum(-v, BOUND_PUSH * np.maximum(1.0, np.abs(bnd[k]))) for k, v in g.items()}
-    it.z = {k: MU_INIT / it.s[k] for k in g}        # ipopt bound_mult_init_method = mu-based
-    # L1 slack pairs start dual feasible and centred: z+ = z- = w_nu/2 (stationarity in t), s = t = mu/z
-    zl = P.w_nu / 2.0
-    it.T = np.full_like(it.T, MU_INIT / zl)
-    for k in ("tp", "tn"):
-        it.s[k] = np.full_like(it.s[k], MU_INIT / zl); it.z[k] = np.full_like(it.z[k], zl)
+    it.s = {k: np.maximum(-v, prm["bound_push"] * np.maximum(1.0, np.abs(bnd[k]))) for k, v in g.items()}
+    if prm["z_init"] == "mu": it.z = {k: prm["mu_init"] / it.s[k] for k in g}        # ipopt bound_mult_init_method = mu-based
+    else: it.z = {k: np.ones_like(it.s[k]) for k in g}                                # ... = constant, bound_mult_init_val 1
+    if prm["centred_l1"]:
+        # L1 slack pairs start dual feasible and centred: z+ = z- = w_nu/2 (stationarity in t), t = |nu| + mu/z
+        zl = P.w_nu / 2.0
+        it.T = np.abs(it.NU) + prm["mu_init"] / zl
+        for k, sg in (("tp", 1.0), ("tn", -1.0)):
+            it.s[k] = it.T - sg * it.NU; it.z[k] = np.full_like(it.s[k], zl)
     return it
 
 
@@ -186,7 +238,8 @@ def lagrangian_gradient(P, it, zz, with_lambda=True):
     """gradient of f + lam^T c + zz^T g with respect to (x_k, u_k, tf, nu_k, t_k)"""
     K = P.K; X, U = it.X, it.U
     gx = 2 * P.w_tr * (X - P.xbar); gu = 2 * P.w_tr * (U - P.ubar); gtf = 1 + 2 * P.w_tr * (it.tf - P.tfbar)
-    cv, gv, Hv = vt_reduced(X[:3, K - 1], X[3:6, K - 1], P.vt_des)
+    if P.variant == "exact": cv, gv, Hv = vt_reduced(X[:3, K - 1], X[3:6, K - 1], P.vt_des)
+    else: cv, gv, Hv = 0.0, np.zeros(6), np.zeros((6, 6))       # no equality row: the tangential pair sits in aT
     if with_lambda:
         lam = it.lam
         for k in range(K - 1):
@@ -220,7 +273,7 @@ def optimality_error(P, it, mu, s_max=100.0):
     """ipopt's scaled E_mu (Waechter-Biegler eq. (5)-(6))"""
     dual, prim, comp = residual_vectors(P, it, mu)
     zsum = sum(np.abs(v).sum() for v in it.z.values()); nz = sum(v.size for v in it.z.values())
-    lsum = np.abs(it.lam).sum() + abs(it.lam_vt); nl = it.lam.size + 1
+    lsum = np.abs(it.lam).sum() + abs(it.lam_vt); nl = it.lam.size + (1 if P.variant == "exact" else 0)
     sd = max(s_max, (zsum + lsum) / (nz + nl)) / s_max
     sc = max(s_max, zsum / nz) / s_max
     d = max(np.abs(v).max() for v in dual); p = max(np.abs(v).max() for v in prim)
@@ -252,6 +305,23 @@ def newton_blocks(P, it, mu, delta_w=0.0):
         r = X[:3, k]; rh = P.rbar_hat[:, k]
         Wx[k][:3, :3] += (2 * z["rmax"][k - 1] * np.eye(3) + sig["rmax"][k - 1] * 4 * np.outer(r, r)
                           + sig["rmin"][k - 1] * np.outer(rh, rh))
+    # Stiff stage terms (an active r_min plane or radius / thrust ball: z/s reaches 1e14 at mu = 1e-9) would wipe out the
+    # trust-region curvature 2 w_tr of the other directions if they were summed into the 7x7 / 3x3 blocks (1e14 * 1e-16 >
+    # 0.004): the recursion keeps only min(sigma, STAGE_CAP) inside W and applies the excess as a rank-1 update of
+    # (Q_uu^-1, gain, P_k) in which it appears only as 1/sigma_ex (riccati_factor).  Wx, Wu keep the full weights for
+    # the residuals of the refinement.
+    Wx0 = Wx.copy(); Wu0 = Wu.copy(); stiff = [[] for _ in range(K)]
+    for k in range(K):
+        ex = sig["u"][k] - STAGE_CAP
+        if ex > 0:
+            cu = 2 * U[:, k]; Wu0[k] -= ex * np.outer(cu, cu); stiff[k].append((cu, np.zeros(7), ex))
+    for k in range(1, K - 1):
+        r = X[:3, k]; rh = P.rbar_hat[:, k]
+        for (vec, sg) in ((2 * r, sig["rmax"][k - 1]), (rh, sig["rmin"][k - 1])):
+            ex = sg - STAGE_CAP
+            if ex > 0:
+                cy = np.zeros(7); cy[:3] = vec
+                Wx0[k] -= ex * np.outer(cy, cy); stiff[k].append((None, cy, ex))
     r = X[:3, K - 1]
     WxK_soft = Wx[K - 1].copy()
     WxK_soft[:3, :3] += 2 * (z["rmax"][K - 2] + z["rfmax"][0]) * np.eye(3)
@@ -263,13 +333,15 @@ def newton_blocks(P, it, mu, delta_w=0.0):
             (P.aT[3], sig["term"][3] + sig["term"][4], zhat["term"][3] - zhat["term"][4]),
             (P.aT[5], sig["term"][5], zhat["term"][5]),
             (a2r, sig["rmax"][K - 2] + sig["rfmax"][0], zhat["rmax"][K - 2] + zhat["rfmax"][0])]
+    if P.variant == "linvt":
+        term.append((P.aT[6], sig["term"][6] + sig["term"][7], zhat["term"][6] - zhat["term"][7]))
     # gx so far contains the full gradient coefficient of every terminal barrier term; take it out
     gxK_soft = gx[:, K - 1].copy()
     for a, w, gh in term: gxK_soft -= gh * a
     a_ = sig["tp"] + sig["tn"]; b_ = sig["tn"] - sig["tp"]
     D = 4 * sig["tp"] * sig["tn"] / a_
     avt = np.zeros(7); avt[:6] = gv
-    return dict(Wx=Wx, Wu=Wu, WxK_soft=WxK_soft, gxK_soft=gxK_soft, term=term, Wtf=2 * P.w_tr + delta_w + sig["tf"].sum(),
+    return dict(Wx=Wx, Wu=Wu, Wx0=Wx0, Wu0=Wu0, stiff=stiff, WxK_soft=WxK_soft, gxK_soft=gxK_soft, term=term, Wtf=2 * P.w_tr + delta_w + sig["tf"].sum(),
                 D=D, rho=gnu - (b_ / a_) * gt, gx=gx, gu=gu, gtf=gtf, e=P.dyn_residual(it.X, it.U, it.NU, it.tf),
                 cv=cv, avt=avt, Hv=Hv, a_=a_, b_=b_, gt=gt, g=g, sig=sig, zhat=zhat)
 
@@ -298,14 +370,14 @@ def riccati_factor(P, nb):
     hold), nu_k eliminated per stage through M = D + P_{k+1} (LDL^T, explicit inverse so that the
     linear-term sweeps are pure matrix-vector products).  Terminal Hessian: soft part + capped share of
     the rank-1 barrier weights + augmented-Lagrangian term gamma a_vt a_vt^T (exact, see riccati_solve)."""
-    K = P.K; Wx, Wu, D = nb["Wx"], nb["Wu"], nb["D"]
+    K = P.K; Wx, Wu, D = nb["Wx0"], nb["Wu0"], nb["D"]
     WxK = nb["WxK_soft"].copy()
     win = []
     for a, w, gh in nb["term"]:
         wi = min(w, TERM_CAP); win.append(wi)
         WxK += wi * np.outer(a, a)
     avt = nb["avt"]
-    gam = (1.0 + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt)
+    gam = (1.0 + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt) if P.variant == "exact" else 0.0
     WxK += gam * np.outer(avt, avt)
     F = dict(P=np.zeros((K, 7, 7)), Minv=np.zeros((K, 7, 7)), G=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
              Qi=np.zeros((K, 3, 3)), Kg=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)), win=win, gam=gam, WxK=WxK)
@@ -329,6 +401,13 @@ def riccati_factor(P, nb):
         Qi = np.linalg.inv(Quu)
         Kg = Qi @ Quy
         Pk = Wxk + Ah.T @ Pt @ Ah - Quy.T @ Kg
+        for (cu, cy, ex) in nb["stiff"][k]:
+            # Q += ex c c^T with c = (c_u, c_y) in the (u_k, y_k) coordinates (x_k = y_k + Bpm u_k): Sherman-Morrison
+            if cu is None: cu = Bpm.T @ cy
+            t = Qi @ cu
+            om = 1.0 / (1.0 / ex + cu @ t)
+            v = cy - Kg.T @ cu
+            Pk = Pk + om * np.outer(v, v); Kg = Kg + om * np.outer(t, v); Qi = Qi - om * np.outer(t, t)
         F["P"][k] = 0.5 * (Pk + Pk.T); F["Pt"][k] = Pt; F["Qi"][k] = Qi; F["Kg"][k] = Kg; F["Bh"][k] = Bh
     return F
 
@@ -361,7 +440,7 @@ def riccati_channel(P, nb, F, gx, gu, rho, aff):
     return X, U, NU, LAM
 
 
-def border_ldl_solve(Mb, rb, wex, gex):
+def border_ldl_solve(Mb, rb, wex, gex, n_eq=1):
     """The bordered system in the order (vt, zeta_1..5, dtf) -- Mb, rb come in channel order (dtf, vt, zetas) --
     with the zeta rows in their 1/w_excess form (a zeta without excess weight is decoupled: pivot -1, value 0).
     In that order the matrix is symmetric, its constraint-type block is negative definite and dtf's Schur complement
@@ -373,11 +452,12 @@ def border_ldl_solve(Mb, rb, wex, gex):
     n = Mb.shape[0]
     order = list(range(1, n)) + [0]
     S = Mb[np.ix_(order, order)].copy(); r = rb[order].copy()
-    for t in range(N_TERM):
+    for t in range(len(wex)):
+        q = n_eq + t
         if wex[t] > 0.0:
-            S[1 + t, 1 + t] -= 1.0 / wex[t]; r[1 + t] -= gex[t] / wex[t]
+            S[q, q] -= 1.0 / wex[t]; r[q] -= gex[t] / wex[t]
         else:
-            S[1 + t, :] = 0.0; S[:, 1 + t] = 0.0; S[1 + t, 1 + t] = -1.0; r[1 + t] = 0.0
+            S[q, :] = 0.0; S[:, q] = 0.0; S[q, q] = -1.0; r[q] = 0.0
     L = np.eye(n); rd = np.zeros(n)
     for p in range(n):
         d = S[p, p]
@@ -389,9 +469,10 @@ def border_ldl_solve(Mb, rb, wex, gex):
             S[i, p + 1:] -= m * S[p, p + 1:]
             L[i, p] = m
     S0 = Mb[np.ix_(order, order)].copy()
-    for t in range(N_TERM):
-        if wex[t] > 0.0: S0[1 + t, 1 + t] -= 1.0 / wex[t]
-        else: S0[1 + t, :] = 0.0; S0[:, 1 + t] = 0.0; S0[1 + t, 1 + t] = -1.0
+    for t in range(len(wex)):
+        q = n_eq + t
+        if wex[t] > 0.0: S0[q, q] -= 1.0 / wex[t]
+        else: S0[q, :] = 0.0; S0[:, q] = 0.0; S0[q, q] = -1.0
 
     def ldl_solve(v):
         v = v.copy()
@@ -416,19 +497,18 @@ def riccati_solve(P, nb, F, rhs):
     Z7 = np.zeros((7, K)); Z3 = np.zeros((3, K)); Zn = np.zeros((7, K - 1))
     term = nb["term"]; win = F["win"]; avt = nb["avt"]
     gx0 = rhs["gx"].copy()
-    wex = []; gex = []
-    for j, (a, w, _) in enumerate(term):
-        share = win[j] / w if w > 0 else 1.0
-        gx0[:, K - 1] += rhs["gterm"][j] * share * a
-        wex.append(w - win[j]); gex.append(rhs["gterm"][j] * (1.0 - share))
+    wex = [w - win[j] for j, (a, w, _) in enumerate(term)]
+    # zeta rows in residual form: a.dx_K - dzeta / wex = -rz  (rz = residual of the row at the current direction)
+    gex = [rhs["rz"][j] * wex[j] for j in range(len(term))]
+    n_eq = 1 if P.variant == "exact" else 0
     gx0[:, K - 1] -= F["gam"] * rhs["rvt"] * avt                      # AL term: gamma (a.dx - rvt) a
     chans = [riccati_channel(P, nb, F, gx0, rhs["gu"], rhs["rho"], rhs["aff"]),
              riccati_channel(P, nb, F, Z7, Z3, Zn, P.Sig)]
-    vecs = [avt] + [a for (a, w, gh) in term]
+    vecs = ([avt] if n_eq else []) + [a for (a, w, gh) in term]
     for a in vecs:
         g1 = Z7.copy(); g1[:, K - 1] = a
         chans.append(riccati_channel(P, nb, F, g1, Z3, Zn, Zn))
-    nbd = 2 + N_TERM
+    nbd = 1 + len(vecs)
     Mb = np.zeros((nbd, nbd)); rb = np.zeros(nbd)
     Mb[0, 0] = nb["Wtf"]
     for c in range(1, 1 + nbd): Mb[0, c - 1] -= (P.Sig * chans[c][3]).sum()
@@ -436,13 +516,14 @@ def riccati_solve(P, nb, F, rhs):
     for i, a in enumerate(vecs):
         for c in range(1, 1 + nbd): Mb[1 + i, c - 1] += a @ chans[c][0][:, K - 1]
         rb[1 + i] = -(a @ chans[0][0][:, K - 1])
-    rb[1] += rhs["rvt"]
-    sol = border_ldl_solve(Mb, rb, wex, gex)
+    if n_eq: rb[1] += rhs["rvt"]
+    sol = border_ldl_solve(Mb, rb, wex, gex, n_eq)
     comb = lambda i: chans[0][i] + sum(sol[c - 1] * chans[c][i] for c in range(1, 1 + nbd))
-    return dict(X=comb(0), U=comb(1), NU=comb(2), lam=comb(3), tf=sol[0], lam_vt=sol[1])
+    return dict(X=comb(0), U=comb(1), NU=comb(2), lam=comb(3), tf=sol[0], lam_vt=sol[1] if n_eq else 0.0,
+                zeta=sol[1 + n_eq:].copy())
 
 
-def reduced_residual(P, nb, it, d):
+def reduced_residual(P, nb, it, d, win):
     """right-hand side minus reduced-KKT-matrix times d, in the layout riccati_solve takes"""
     K = P.K
     dX, dU, dtf, dNU, dl, dlv = d["X"], d["U"], d["tf"], d["NU"], d["lam"], d["lam_vt"]
@@ -457,7 +538,15 @@ def reduced_residual(P, nb, it, d):
         v = v + (it.lam[:, k - 1] + dl[:, k - 1])
         if k <= K - 2: v = v - P.A[k].T @ (it.lam[:, k] + dl[:, k])
         gx[:, k] = grad + v
-    gterm = np.array([gh + w * (a @ dX[:, K - 1]) for (a, w, gh) in nb["term"]])
+    # terminal rank-1 terms: the share win a a^T stays a Hessian term, the excess lives in zeta (kept as an unknown of the
+    # linear solve): x_K row  += (gh share + win a.dx + zeta) a ;  zeta row  a.dx - zeta / wex + gh / w  (all O(1) entries)
+    rz = np.zeros(len(nb["term"])); zeta = d["zeta"]
+    for j, (a, w, gh) in enumerate(nb["term"]):
+        adx = a @ dX[:, K - 1]
+        wex = w - win[j]
+        share = win[j] / w if w > 0 else 1.0
+        gx[:, K - 1] += (gh * share + win[j] * adx + (zeta[j] if wex > 0 else 0.0)) * a
+        rz[j] = adx - zeta[j] / wex + gh / w if wex > 0 else 0.0
     gtf = nb["gtf"] + nb["Wtf"] * dtf
     for k in range(K):
         v = Wu[k] @ dU[:, k]
@@ -471,7 +560,7 @@ def reduced_residual(P, nb, it, d):
         aff[:, k] = -nb["e"][:, k] - (dX[:, k + 1] - P.A[k] @ dX[:, k] - P.Bn[k] @ dU[:, k]
                                       - P.Bp[k] @ dU[:, k + 1] - P.Sig[:, k] * dtf - dNU[:, k])
     rvt = -nb["cv"] - nb["avt"] @ dX[:, K - 1]
-    return dict(gx=gx, gu=gu, rho=rho, aff=aff, gtf=gtf, rvt=rvt, gterm=gterm)
+    return dict(gx=gx, gu=gu, rho=rho, aff=aff, gtf=gtf, rvt=rvt, rz=rz)
 
 
 def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
@@ -480,16 +569,16 @@ def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
     K = P.K
     F = riccati_factor(P, nb)
     zero = dict(X=np.zeros((7, K)), U=np.zeros((3, K)), NU=np.zeros((7, K - 1)), tf=0.0,
-                lam=-it.lam.copy(), lam_vt=-it.lam_vt)             # so that lam + dlam = 0: rhs has no multipliers
+                lam=-it.lam.copy(), lam_vt=-it.lam_vt, zeta=np.zeros(len(nb["term"])))   # so that lam + dlam = 0: rhs has no multipliers
     d = zero
     # refinement once a barrier weight z/s (terminal rank-1 terms, stage balls and planes, tf bounds) costs digits
     stiff = max(max(w for (a, w, gh) in nb["term"]), max(nb["sig"][k].max() for k in ("u", "rmax", "rmin", "tf")))
     passes = 1 + (n_refine if stiff > REFINE_TW else 0)
     for _ in range(passes):
-        rhs = reduced_residual(P, nb, it, d)
+        rhs = reduced_residual(P, nb, it, d, F["win"])
         c = riccati_solve(P, nb, F, rhs)
         d = dict(X=d["X"] + c["X"], U=d["U"] + c["U"], NU=d["NU"] + c["NU"], tf=d["tf"] + c["tf"],
-                 lam=d["lam"] + c["lam"], lam_vt=d["lam_vt"] + c["lam_vt"])
+                 lam=d["lam"] + c["lam"], lam_vt=d["lam_vt"] + c["lam_vt"], zeta=d["zeta"] + c["zeta"])
     return finish_direction(P, it, nb, d)
 
 
@@ -535,7 +624,10 @@ def newton_direction_dense(P, it, mu, delta_w=0.0):
         M[il(k), :npr] = J; M[:npr, il(k)] = J.T
         M[il(k), il(k)] = -np.diag(1.0 / nb["D"][:, k])
         rhs[il(k)] = -nb["e"][:, k] - nb["rho"][:, k] / nb["D"][:, k]
-    M[ivt, ix(K - 1)] = nb["avt"]; M[ix(K - 1), ivt] = nb["avt"]; rhs[ivt] = -nb["cv"]
+    if P.variant == "exact":
+        M[ivt, ix(K - 1)] = nb["avt"]; M[ix(K - 1), ivt] = nb["avt"]; rhs[ivt] = -nb["cv"]
+    else:
+        M[ivt, ivt] = -1.0                                          # no equality row: decoupled placeholder (keeps the inertia count)
     sol = np.linalg.solve(M, rhs)
     d = dict(X=np.zeros((7, K)), U=sol[nx:nx + nu_].reshape(K, 3).T.copy(), tf=sol[itf])
     d["X"][:, 1:] = sol[:nx].reshape(K - 1, 7).T
@@ -560,22 +652,25 @@ def step(it, d, a):
     return n
 
 
-def candidate(P, it, d, a, mu_clip):
+def candidate(P, it, d, a, mu_clip, prm=FAST):
     """the iterate a step of length a would give: it + a d with the slacks reset to s >= -g and the multipliers
     pulled back to z <= kappa mu / s (upper side only, see the header).  The line search tests this point."""
     n = step(it, d, a)
     g = P.ineq(n.X, n.U, n.NU, n.T, n.tf)
     for k in n.s:
         n.s[k] = np.maximum(n.s[k], -g[k])
-        n.z[k] = np.minimum(n.z[k], KAPPA_SIGMA * mu_clip / n.s[k])
+        n.z[k] = np.minimum(n.z[k], prm["kappa_sigma"] * mu_clip / n.s[k])
+        if prm["kappa_two_sided"]: n.z[k] = np.maximum(n.z[k], mu_clip / (prm["kappa_sigma"] * n.s[k]))
     return n
 
 
 def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_refine=1, dense=False,
-          verbose=False):
+          verbose=False, start="ref", mode="fast"):
     """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective, n_regularised = number of
     iterations whose factorisation broke down and needed delta_w > 0, first_regularised = index of the first, -1 if none)."""
-    it = initial_iterate(P)
+    prm = FAST if mode == "fast" else IPOPT_DEFAULT
+    it = initial_iterate(P, start, prm)
+    mu = prm["mu_init"]
     n_acc = 0; status = ST_MAXITER; k_it = 0
     dw_last = 0.0; n_reg = 0; first_reg = -1
     for k_it in range(max_iter + 1):
@@ -587,7 +682,13 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         if n_acc >= acceptable_iter: status = ST_ACCEPTABLE; break
         if k_it == max_iter: status = ST_ACCEPTABLE if E0 <= acceptable_tol else ST_MAXITER; break
         mu_cur = sum((it.s[k] * it.z[k]).sum() for k in it.s) / sum(v.size for v in it.s.values())
-        mu = max(SIGMA * mu_cur, tol / 10)
+        if prm["mu_strategy"] == "adaptive":
+            mu = max(SIGMA * mu_cur, tol / 10)
+        else:
+            # Fiacco-McCormick: the barrier problem is solved to E_mu <= kappa_eps mu (kappa_eps = 10) before mu moves on
+            # to max(tol / 10, min(kappa_mu mu, mu^theta_mu)), kappa_mu = 0.2, theta_mu = 1.5 (Waechter & Biegler eq. (7))
+            while mu > tol / 10 and optimality_error(P, it, mu)[0] <= 10.0 * mu:
+                mu = max(tol / 10, min(0.2 * mu, mu ** 1.5))
         # Hessian regularisation on breakdown: ipopt's inertia-correction schedule (Waechter & Biegler 2006, Alg. IC):
         # delta_w = 0 first, then a third of the last successful value (1e-4 the first time), growing by 8
         # (by 100 until some value has worked), giving up above 1e40
@@ -617,13 +718,13 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         n = None
         for ls in range(30):
             if 0.5 * a < ALPHA_FLOOR: n = None; break   # a rejection could not shorten the step any more: take it
-            n = candidate(P, it, d, a, mu_clip)
+            n = candidate(P, it, d, a, mu_clip, prm)
             prod = np.concatenate([(n.s[k] * n.z[k]).ravel() for k in n.s])
             if residual_norm(P, n, mu) <= (1 - 1e-4 * a) * r0 and prod.min() >= GAMMA_NBHD * min(mu, prod.mean()):
                 break
             a *= 0.5
         if verbose: print(f"       mu {mu:.2e} step {a:.4f} delta_w {dw:.1e}")
-        it = n if n is not None else candidate(P, it, d, a, mu_clip)
+        it = n if n is not None else candidate(P, it, d, a, mu_clip, prm)
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
     T = np.zeros((7, K)); T[:, :K - 1] = it.T

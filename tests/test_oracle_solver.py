@@ -1,7 +1,10 @@
 """The solve-half oracle (oracle/nlp_ipm.py) checked without ipopt: the tangential-velocity reformulation is
 the same constraint, its solutions are KKT points of the restated NLP (independent dense assembly), its
 structured linear algebra equals a dense LAPACK solve, and it agrees with scipy's trust-constr run on the
-un-eliminated polynomial NLP (fixture tests/golden/solve_xcheck_K10.npz, made by make_solver_xcheck.py)."""
+un-eliminated polynomial NLP: fixtures tests/golden/xcheck_*.npz (make_nlp_xcheck.py: an independent transcription of
+optimizer.py on the reference's own A/B matrices; default and MPC option sets, the non-zero-virtual-control optimum, the
+convex linearised-vt variant, ipopt's zero start) and the older solve_xcheck_K10.npz (make_solver_xcheck.py).  Start
+points and the frozen ipopt-default parameter set are checked to give the same solution."""
 import os
 import sys
 
@@ -100,3 +103,92 @@ def test_status_codes(golden_dir):
     # a tolerance fp64 does not reach: three consecutive iterates at the acceptable level end the run
     r = N.solve(P, tol=1e-12, acceptable_tol=1e-6, acceptable_iter=3, max_iter=120)
     assert r["status"] == N.ST_ACCEPTABLE and r["kkt"] <= 1e-6
+
+
+# ---- independent fixtures: scipy trust-constr on a second transcription of optimizer.py (tests/golden/make_nlp_xcheck.py) ----
+XCHECK = ["tan_K20_tf2", "tan_K30_tf1", "tan_K30_tf1_zero", "const_K30_tf1", "tan_K20_tf2_linvt", "tan_K30_tf1_linvt",
+          "const_K30_tf1_linvt", "tan_K30_tf1_mpc105", "tan_K60_tf2_mpc12", "tan_K60_tf2_mpc15"]
+# two solvers, tol 1e-8 each, on an objective that is flat in u (only the trust-region weight 2 w_tr = 0.004 holds it):
+# x to 1e-5, tf to 1e-6; u to 5e-4; the convex variant (unique minimiser) much tighter
+TOL_X, TOL_U, TOL_TF = 1e-5, 5e-4, 1e-6
+
+
+def xcheck_problem(golden_dir, case):
+    f = np.load(os.path.join(golden_dir, f"xcheck_{case}.npz"))
+    d = np.load(os.path.join(golden_dir, f"disc_{str(f['fixture'])}.npz"))
+    x, u, tf, cst = d["x"], d["u"], float(d["tf"]), d["const"]
+    stage = {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")}
+    opts = {"r_des": float(f["r_des"]), **{str(k): float(v) for k, v in zip(f["option_keys"], f["option_vals"])}}
+    return N.MpcProblem(x, u, tf, cst[0], stage, O.constraint_terms(x, u, cst[0]), opts, variant=str(f["variant"])), f
+
+
+@pytest.mark.parametrize("case", XCHECK)
+def test_oracle_vs_independent_nlp_solution(golden_dir, case):
+    P, f = xcheck_problem(golden_dir, case)
+    assert f["status"] in (1, 2) and f["ceq_max"] < 1e-9 and f["gin_max"] < 1e-9 and f["optimality"] < 5e-8
+    r = N.solve(P)
+    assert r["status"] == N.ST_OK and r["n_regularised"] == 0
+    convex = P.variant == "linvt"
+    assert np.abs(r["X"] - f["X"]).max() < (1e-6 if convex else TOL_X)
+    assert np.abs(r["U"] - f["U"]).max() < (1e-5 if convex else TOL_U)
+    assert np.abs(r["NU"] - f["NU"]).max() < 1e-6
+    assert abs(r["tf"] - float(f["tf_opt"])) < (5e-8 if convex else TOL_TF)
+
+
+def test_virtual_control_optimum(golden_dir):
+    """The constant-thrust reference of test_discretizer.py:59 cannot meet the terminal window with thrust alone: the
+    optimum keeps a virtual control on one position component of the last interval.  Both solvers find it."""
+    P, f = xcheck_problem(golden_dir, "const_K30_tf1")
+    r = N.solve(P)
+    assert np.abs(f["NU"]).sum() > 0.07 and abs(np.abs(r["NU"]).sum() - np.abs(f["NU"]).sum()) < 1e-6
+    k, i = np.unravel_index(np.abs(r["NU"].T).argmax(), (P.K, 7))
+    assert k == P.K - 2 and np.abs(r["NU"]).sum() - abs(r["NU"][i, k]) < 1e-6          # a single entry carries it
+
+
+@pytest.mark.parametrize("case", ["tan_K20_tf2", "tan_K30_tf1", "const_K30_tf1", "tan_K30_tf1_linvt", "tan_K60_tf2_mpc12"])
+def test_frozen_ipopt_default_mode_ends_at_the_same_point(golden_dir, case):
+    """FAST (adaptive mu, push 1e-4, kappa_Sigma 100 one-sided, mu-based multipliers, centred L1 pairs) against ipopt's
+    defaults for the same knobs (monotone mu from 0.1, push 1e-2, kappa_Sigma 1e10, multipliers 1): the same KKT point."""
+    P, f = xcheck_problem(golden_dir, case)
+    a = N.solve(P); b = N.solve(P, mode="ipopt_default", max_iter=400)
+    assert a["status"] == b["status"] == N.ST_OK and b["iters"] > a["iters"]
+    assert np.abs(a["X"] - b["X"]).max() < 5e-6 and abs(a["tf"] - b["tf"]) < 1e-6
+    assert np.abs(b["X"] - f["X"]).max() < TOL_X and abs(b["tf"] - float(f["tf_opt"])) < TOL_TF
+
+
+@pytest.mark.parametrize("case", ["tan_K20_tf2", "tan_K30_tf1_linvt", "const_K30_tf1"])
+def test_start_point_does_not_change_the_solution(golden_dir, case):
+    """ipopt starts from zeros (pyomo Vars without values, optimizer.py:267-270, 287), oracle and device from the
+    reference trajectory.  Evidence that both land on the same local solution: (i) the independent solver does
+    (fixture tan_K30_tf1_zero against tan_K30_tf1, test above and here); (ii) the oracle reaches its own solution from
+    8 random starts (20 % noise on every state, unit noise on the thrust, tf scaled by 0.5 .. 1.5) and, in the convex
+    variant (where the reduced tangential form plays no role and x = 0 is admissible), from all-zeros."""
+    P, f = xcheck_problem(golden_dir, case)
+    base = N.solve(P)
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        st = dict(X=P.xbar * (1 + 0.2 * rng.standard_normal(P.xbar.shape)), U=P.ubar + rng.standard_normal(P.ubar.shape),
+                  tf=P.tfbar * rng.uniform(0.5, 1.5))
+        r = N.solve(P, start=st, max_iter=400)
+        assert r["status"] == N.ST_OK
+        assert np.abs(r["X"] - base["X"]).max() < 5e-6 and abs(r["tf"] - base["tf"]) < 1e-6
+    if P.variant == "linvt":
+        for mode in ("fast", "ipopt_default"):
+            r = N.solve(P, start="zero", mode=mode, max_iter=400)
+            assert r["status"] == N.ST_OK
+            assert np.abs(r["X"] - base["X"]).max() < 5e-6 and abs(r["tf"] - base["tf"]) < 1e-6
+
+
+def test_independent_solver_start_points(golden_dir):
+    a = np.load(os.path.join(golden_dir, "xcheck_tan_K30_tf1.npz")); b = np.load(os.path.join(golden_dir, "xcheck_tan_K30_tf1_zero.npz"))
+    assert str(b["start"]) == "zero" and np.abs(a["X"] - b["X"]).max() < 1e-6 and abs(float(a["tf_opt"]) - float(b["tf_opt"])) < 1e-7
+
+
+def test_zero_like_start_exact_variant(golden_dir):
+    """In the exact variant the device's reduced tangential form is undefined at r = 0 (the reference's polynomial has a
+    zero gradient there); from 1e-3 x_bar with zero thrust and tf = 0 the frozen ipopt-default mode still ends at the
+    reference-start solution."""
+    P, f = xcheck_problem(golden_dir, "tan_K30_tf1")
+    base = N.solve(P)
+    r = N.solve(P, start=dict(X=1e-3 * P.xbar, U=np.zeros_like(P.ubar), tf=0.0), mode="ipopt_default", max_iter=600)
+    assert r["status"] == N.ST_OK and np.abs(r["X"] - base["X"]).max() < 5e-6 and abs(r["tf"] - base["tf"]) < 1e-6
