@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 100
+#define MPCX_VERSION 200
 
 /* return codes */
 #define MPCX_OK 0
@@ -94,10 +94,11 @@ int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double
                                void *stream);
 
 /* Options of the per-satellite solve: the keys of Optimizer.init_options (optimizer.py:178-188;
- * u_lim[1] -> u_max, r_lim -> r_min/r_max; r_des is per satellite, eps_vt is unused by the reference
- * because the exact tangential constraint :577 is active) and the ipopt-level controls. */
+ * u_lim[1] -> u_max, r_lim -> r_min/r_max; r_des is per satellite; eps_vt is read only with
+ * MPCX_SOLVE_LINEAR_VT: the reference as shipped enables the exact tangential constraint :577, which has no
+ * tolerance) and the ipopt-level controls. */
 typedef struct {
-    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr;
+    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, eps_vt, tf_max, w_nu, w_tr;
     double tol, acceptable_tol;
     int32_t max_iter, acceptable_iter, n_refine, flags;   /* flags: MPCX_SOLVE_* */
 } mpcx_solve_opts;
@@ -109,6 +110,11 @@ typedef struct {
  * one context must be enqueued on the same stream (or be ordered by the caller).  This flag keeps the plain index
  * order. */
 #define MPCX_SOLVE_INDEX_ORDER 1
+/* Tangential velocity as the linearised pair max_tan_vel_rule / min_tan_vel_rule (optimizer.py:471-489,
+ * |Vt_lin(x_K) - Vc_lin(r_K)| <= eps_vt), which the reference keeps commented out at :575-576, instead of the quartic
+ * equality :492-517 it enables at :577.  Every constraint is then linear or convex quadratic and the objective strictly
+ * convex in (x, u, tf): the minimiser is unique -- the variant the parity tests use to compare solvers exactly. */
+#define MPCX_SOLVE_LINEAR_VT 2
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 size_t mpcx_solve_workspace_bytes(int S, int K);

@@ -34,7 +34,7 @@ _ctxs = {}
 
 class SolveOpts(C.Structure):
     """mpcx_solve_opts (include/mpcx.h)"""
-    _fields_ = [(n, C.c_double) for n in ("min_mass", "u_max", "r_min", "r_max", "eps_r", "eps_vr", "eps_vn",
+    _fields_ = [(n, C.c_double) for n in ("min_mass", "u_max", "r_min", "r_max", "eps_r", "eps_vr", "eps_vn", "eps_vt",
                                           "tf_max", "w_nu", "w_tr", "tol", "acceptable_tol")] + \
                [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "n_refine", "flags")]
 
@@ -124,6 +124,7 @@ def iptr(a):
 
 
 SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
+SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT = 1, 2          # mpcx_solve_opts.flags (include/mpcx.h)
 
 
 def check_solver_keywords(solver):
@@ -142,7 +143,7 @@ def make_solve_opts(options=None, **solver):
     if "min_mass" in options: o.min_mass = options["min_mass"]
     if "u_lim" in options: o.u_max = options["u_lim"][1]
     if "r_lim" in options: o.r_min, o.r_max = options["r_lim"][0], options["r_lim"][1]
-    for k in ("eps_r", "eps_vr", "eps_vn", "tf_max", "w_nu", "w_tr"):
+    for k in ("eps_r", "eps_vr", "eps_vn", "eps_vt", "tf_max", "w_nu", "w_tr"):
         if k in options: setattr(o, k, options[k])
     check_solver_keywords(solver)
     for k, v in solver.items():

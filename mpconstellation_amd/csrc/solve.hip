@@ -27,9 +27,16 @@ namespace mpcx {
 enum { I_X = 0, I_U = 7, I_NU = 10, I_T = 17, I_LAM = 24, I_STP = 31, I_ZTP = 38, I_STN = 45, I_ZTN = 52,
        I_SU = 59, I_ZU = 60, I_SRMAX = 61, I_ZRMAX = 62, I_SRMIN = 63, I_ZRMIN = 64, IT_N = 66 };
 // global part of iterate / direction
-enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16, G_TF = 18, G_LVT = 19, GL_N = 24 };
+enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16, G_TF = 18, G_LVT = 19, G_SVT = 20, G_ZVT = 22, GL_N = 24 };
+// slack / multiplier slot of terminal inequality row j: rows 0..5 always, rows 6, 7 (the linearised tangential pair) in the
+// convex variant only
+__host__ __device__ inline int gs_term(int j) { return j < 6 ? G_STERM + j : G_SVT + (j - 6); }
+__host__ __device__ inline int gz_term(int j) { return j < 6 ? G_ZTERM + j : G_ZVT + (j - 6); }
 // Newton blocks per node: the part the recursion reads as one contiguous record per node ...
-enum { N_WX = 0, N_WU = 49, N_D = 58, NB_N = 65 };
+// (N_SX: the stage's stiff barrier terms -- excess weight above kStageCap and direction of the position term (r_min
+//  plane or radius ball) and of the thrust ball; the blocks N_WX / N_WU carry only the capped share, see riccati_factor)
+enum { N_WX = 0, N_WU = 49, N_D = 58, N_SX = 65, NB_N = 73 };
+enum { SX_EX = 0, SX_A = 1, SX_EU = 4, SX_CU = 5, SX_N = 8 };
 // ... and the part only the node-parallel phases touch (field-major, see Col below)
 enum { NS_AA = 0, NS_BB = 7, NS_GT = 14, NS_RHO = 21, NS_GX = 28, NS_GU = 35, NS_E = 38, NS_D = 45, NS_N = 52 };
 // factorisation per node
@@ -46,11 +53,11 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1;
 
 struct SolveOpts {
-    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, tf_max, w_nu, w_tr, tol, acc_tol;
-    int max_iter, acc_iter, n_refine, pad;
+    double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, eps_vt, tf_max, w_nu, w_tr, tol, acc_tol;
+    int max_iter, acc_iter, n_refine, linvt;    // linvt: the linearised tangential pair (optimizer.py:471-489) instead of the quartic
 };
 
 struct SolveArgs {
@@ -76,7 +83,9 @@ __host__ __device__ inline size_t ws_doubles(int K)
 
 // ---- per-satellite constant data kept in LDS --------------------------------------------
 struct SatData {
-    double aT[6][7], bT[6];
+    double aT[8][7], bT[8];
+    int nT, linvt;           // terminal inequality rows (6, or 8 with the linearised tangential pair); convex variant flag
+    double w_vt, gh_vt, zeta_vt;   // convex variant: weight, gradient coefficient and border unknown of the tangential pair
     double b_u, b_rmax, b_rmin, b_rfmax, b_tf[2], vt_des, w_tr, w_nu, tfbar;
     // Newton-step globals
     double WxK[49];          // terminal Hessian used inside the recursion (soft + capped + AL)
@@ -87,6 +96,7 @@ struct SatData {
     double Sb[NBD][NBD];     // the border matrix itself (for the residual of the refinement step in border_solve)
     double siglam[NCH], xK[NCH][7];
     double sol[NBD];
+    double zeta[NTERM];      // border unknowns of the terminal terms accumulated over the passes of one linear solve
     double red[8];
     int flag;
 #ifdef MPCX_PHASE_TIMING
@@ -202,7 +212,9 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
     double gN[6] = {DrVn[0], DrVn[1], DrVn[2], DvVn[0], DvVn[1], DvVn[2]};
     double gRbar = 0.0, gNbar = 0.0;
     for (int i = 0; i < 6; ++i) { gRbar += gR[i] * xK[i]; gNbar += gN[i] * xK[i]; }
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 7; ++j) sd.aT[i][j] = 0.0;
+    for (int i = 0; i < 8; ++i) { sd.bT[i] = 0.0; for (int j = 0; j < 7; ++j) sd.aT[i][j] = 0.0; }
+    sd.linvt = o.linvt; sd.nT = o.linvt ? 8 : 6;
+    sd.w_vt = 0.0; sd.gh_vt = 0.0; sd.zeta_vt = 0.0;
     for (int j = 0; j < 3; ++j) sd.aT[0][j] = -rh[j];
     sd.bT[0] = relax(-(r_des - o.eps_r));
     for (int j = 0; j < 6; ++j) { sd.aT[1][j] = gR[j]; sd.aT[2][j] = -gR[j]; sd.aT[3][j] = gN[j]; sd.aT[4][j] = -gN[j]; }
@@ -210,6 +222,34 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
     sd.bT[1] = relax(o.eps_vr - c0r); sd.bT[2] = relax(o.eps_vr + c0r);
     sd.bT[3] = relax(o.eps_vn - c0n); sd.bT[4] = relax(o.eps_vn + c0n);
     sd.aT[5][6] = -1.0; sd.bT[5] = relax(-o.min_mass);
+    if (o.linvt) {
+        // optimizer.py:119,124-125,146-153: t_hat = h_hat x r_hat, Dr_t = -skew(r_hat) Dr_h + skew(h_hat) Dr_r,
+        // Dv_t = -skew(r_hat) Dv_h, Vt = v.t_hat, Vc = sqrt(mu/|r|), DrVc = -1/2 sqrt(mu) |r|^(-5/2) r;
+        // rows 6 / 7: min_tan_vel_rule / max_tan_vel_rule (:480-489 / :471-479)
+        double th[3] = {hh[1] * rh[2] - hh[2] * rh[1], hh[2] * rh[0] - hh[0] * rh[2], hh[0] * rh[1] - hh[1] * rh[0]};
+        double nSrh[9] = {0, rh[2], -rh[1], -rh[2], 0, rh[0], rh[1], -rh[0], 0};      // -skew(r_hat)
+        double Shh[9] = {0, -hh[2], hh[1], hh[2], 0, -hh[0], -hh[1], hh[0], 0};       // skew(h_hat)
+        double Dr_t[9], Dv_t[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0, b = 0.0, c = 0.0;
+                for (int l = 0; l < 3; ++l) { a += nSrh[i * 3 + l] * Dr_h[l * 3 + j]; b += Shh[i * 3 + l] * Dr_r[l * 3 + j]; c += nSrh[i * 3 + l] * Dv_h[l * 3 + j]; }
+                Dr_t[i * 3 + j] = a + b; Dv_t[i * 3 + j] = c;
+            }
+        const double Vt = v[0] * th[0] + v[1] * th[1] + v[2] * th[2];
+        const double Vc = sqrt(mu_grav / rn);
+        const double kc = -0.5 * sqrt(mu_grav) * pow(rn, -2.5);
+        double gT[6], gbar = 0.0, DrVc_r = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            gT[j] = v[0] * Dr_t[j] + v[1] * Dr_t[3 + j] + v[2] * Dr_t[6 + j];
+            gT[3 + j] = th[j] + (v[0] * Dv_t[j] + v[1] * Dv_t[3 + j] + v[2] * Dv_t[6 + j]);
+        }
+        for (int i = 0; i < 6; ++i) gbar += gT[i] * xK[i];
+        for (int j = 0; j < 3; ++j) { DrVc_r += kc * r[j] * r[j]; gT[j] -= kc * r[j]; }
+        const double c0t = Vt - gbar - Vc + DrVc_r;
+        for (int j = 0; j < 6; ++j) { sd.aT[6][j] = gT[j]; sd.aT[7][j] = -gT[j]; }
+        sd.bT[6] = relax(o.eps_vt - c0t); sd.bT[7] = relax(o.eps_vt + c0t);
+    }
     sd.b_u = relax(o.u_max * o.u_max);
     sd.b_rmax = relax(o.r_max * o.r_max);
     sd.b_rmin = relax(-o.r_min);
@@ -448,18 +488,22 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
         if (h0) {
             if (k == K - 1) {
                 // terminal inequalities, final-radius ball, vt equality
-                double cv, g6[6];
-                vt_reduced(x, sd.vt_des, cv, g6, nullptr);
-                ACC_P(cv);
+                if (!sd.linvt) {
+                    double cv, g6[6];
+                    vt_reduced(x, sd.vt_des, cv, g6, nullptr);
+                    ACC_P(cv);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
-                lsum += fabs(lvt);
-                for (int j = 0; j < 6; ++j) {
-                    double sj = s.itg[G_STERM + j] + a * s.drg[G_STERM + j];
-                    double zj = s.itg[G_ZTERM + j] + a * s.drg[G_ZTERM + j];
+                    for (int i = 0; i < 6; ++i) gx[i] += lvt * g6[i];
+                    lsum += fabs(lvt);
+                }
+                const int nT = sd.nT;
+                for (int j = 0; j < nT; ++j) {
+                    const int js = gs_term(j), jz = gz_term(j);
+                    double sj = s.itg[js] + a * s.drg[js];
+                    double zj = s.itg[jz] + a * s.drg[jz];
                     double gj = -sd.bT[j];
                     for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
-                    if (WRITE) { POST(sj, zj, gj); s.itgB[G_STERM + j] = sj; s.itgB[G_ZTERM + j] = zj; }
+                    if (WRITE) { POST(sj, zj, gj); s.itgB[js] = sj; s.itgB[jz] = zj; }
                     for (int i = 0; i < 7; ++i) gx[i] += sd.aT[j][i] * zj;
                     ACC_P(gj + sj);
                     ACC_C(sj, zj);
@@ -506,13 +550,13 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     if (WRITE) __syncthreads();            // the candidate iterate is complete before anybody reads it
 }
 
-__device__ __forceinline__ int n_ineq(int K) { return K + (K - 1) + (K - 2) + 6 + 1 + 14 * (K - 1) + 2; }
+__device__ __forceinline__ int n_ineq(int K, int nT) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + 2; }
 
 // ipopt's scaled optimality error E_mu from one residual evaluation: max_i |s_i z_i - mu| = max(pmax - mu, mu - pmin)
-__device__ double scaled_error(const ResAcc &r, int K, double mu)
+__device__ double scaled_error(const ResAcc &r, int K, int nT, double mu)
 {
     const double smax = 100.0;
-    const int nz = n_ineq(K), nl = 7 * (K - 1) + 1;
+    const int nz = n_ineq(K, nT), nl = 7 * (K - 1) + (nT == 6 ? 1 : 0);     // (the convex variant has no tangential equality)
     const double sdl = fmax(smax, (r.zsum + r.lsum) / (double)(nz + nl)) / smax;
     const double sc = fmax(smax, r.zsum / (double)nz) / smax;
     const double comp = fmax(r.prod_max - mu, mu - r.prod_min);
@@ -554,18 +598,25 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             zrmax = bs[3];
 #pragma unroll
             for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - xb[i]);
-            // thrust ball
-            double Wu[9];
+            // thrust ball.  Only min(sigma, kStageCap) of a stage barrier weight goes into the Hessian blocks: summed into
+            // a 3x3 / 7x7 block a weight of 1e14 (an active constraint at mu = 1e-9) would wipe out the trust-region
+            // curvature 2 w_tr of the other directions; the excess reaches the recursion as a rank-1 update (riccati_factor)
+            double Wu[9], sx[SX_N];
+#pragma unroll
+            for (int i = 0; i < SX_N; ++i) sx[i] = 0.0;
             {
                 const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
                 const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
                 sigmax = fmax(sigmax, sig);
+                const double sin_ = fmin(sig, kStageCap);
+                sx[SX_EU] = sig - sin_;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
+                    sx[SX_CU + i] = 2.0 * u[i];
                     gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zh;
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        Wu[i * 3 + j] = (i == j ? 2.0 * w_tr + delta_w + 2.0 * zu : 0.0) + sig * 4.0 * u[i] * u[j];
+                        Wu[i * 3 + j] = (i == j ? 2.0 * w_tr + delta_w + 2.0 * zu : 0.0) + sin_ * 4.0 * u[i] * u[j];
                 }
             }
             if (k >= 1) {
@@ -581,17 +632,26 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
                 const double isr = rcp_pos(srmin), sig = zrmin * isr, zh = mu * isr + sig * (g + srmin);
                 sigmax = fmax(sigmax, sig);
+                // at most one of the two position terms can be stiff (r_min < r_max): the one with the larger excess
+                // leaves the block, the other stays whole
+                const double ex_max = sig_rmax - kStageCap, ex_min = sig - kStageCap;
+                const bool st_max = ex_max > 0.0 && ex_max >= ex_min, st_min = ex_min > 0.0 && !st_max;
+                const double in_max = st_max ? kStageCap : sig_rmax, in_min = st_min ? kStageCap : sig;
+                sx[SX_EX] = st_max ? ex_max : (st_min ? ex_min : 0.0);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
+                    sx[SX_A + i] = st_max ? 2.0 * x[i] : rbv[i];
                     gx[i] += 2.0 * x[i] * zh_rmax - rbv[i] * zh;
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        Wx3[i * 3 + j] += (i == j ? 2.0 * zrmax : 0.0) + sig_rmax * 4.0 * x[i] * x[j] + sig * rbv[i] * rbv[j];
+                        Wx3[i * 3 + j] += (i == j ? 2.0 * zrmax : 0.0) + in_max * 4.0 * x[i] * x[j] + in_min * rbv[i] * rbv[j];
                 }
             }
             if (h0) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
+#pragma unroll
+                for (int i = 0; i < SX_N; ++i) nb[N_SX + i] = sx[i];
 #pragma unroll
                 for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
 #pragma unroll
@@ -650,18 +710,28 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         if (h0 && k == K - 1) {
             // terminal node: soft gradient, the five rank-1 barrier terms, the pieces of the terminal Hessians (the
             // 7x7 matrices themselves are assembled by 49 lanes after the loop)
-            double cv, g6[6];
-            vt_reduced(x, sd.vt_des, cv, g6, sd.Hv);
-            sd.cv = cv;
-            for (int i = 0; i < 7; ++i) sd.avt[i] = (i < 6) ? g6[i] : 0.0;
-            const double lvt = s.itg[G_LVT];
-            double sig[6], zh[6];
-            for (int j = 0; j < 6; ++j) {
+            double g6[6];
+            const double lvt = sd.linvt ? 0.0 : s.itg[G_LVT];
+            double sig[8], zh[8];
+            for (int j = 0; j < sd.nT; ++j) {
                 double gj = -sd.bT[j];
                 for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
-                const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
+                const double sj = s.itg[gs_term(j)], zj = s.itg[gz_term(j)];
                 sig[j] = zj / sj; zh[j] = mu / sj + sig[j] * (gj + sj);
             }
+            if (!sd.linvt) {
+                double cv;
+                vt_reduced(x, sd.vt_des, cv, g6, sd.Hv);
+                sd.cv = cv;
+            } else {
+                // convex variant: the tangential pair is a rank-1 terminal term whose border unknown rides in the channel
+                // of the (absent) equality's multiplier: direction a_vt = row 6, no curvature, no constraint value
+                for (int i = 0; i < 6; ++i) g6[i] = sd.aT[6][i];
+                for (int i = 0; i < 36; ++i) sd.Hv[i] = 0.0;
+                sd.cv = 0.0;
+                sd.w_vt = sig[6] + sig[7]; sd.gh_vt = zh[6] - zh[7];
+            }
+            for (int i = 0; i < 7; ++i) sd.avt[i] = (i < 6) ? g6[i] : 0.0;
             const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
             const double grf = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
             const double sigrf = zrf / srf, zhrf = mu / srf + sigrf * (grf + srf);
@@ -683,7 +753,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             double hn = 0.0, an = 0.0;
             for (int i = 0; i < 36; ++i) hn += sd.Hv[i] * sd.Hv[i];
             for (int i = 0; i < 6; ++i) an += g6[i] * g6[i];
-            sd.gam = (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
+            // (convex variant: the capped share of the pair's weight takes the place of the AL weight)
+            sd.gam = sd.linvt ? fmin(sd.w_vt, kTermCap) : (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
         }
     }
     sigmax = wave_max(sigmax);
@@ -751,10 +822,10 @@ __device__ __forceinline__ bool inv3_spd(const double *Q, double *Qi)
 constexpr int FS = 10;
 struct StageOps {
     double F[7 * FS], G2[7 * FS];
-    double Bn[21], Bpm[21], Wu[9], D[7];                  // the rest of the prefetched inputs (fetch order A Bn Bpm Wx Wu D)
+    double Bn[21], Bpm[21], Wu[9], D[7], SX[SX_N];        // the rest of the prefetched inputs (fetch order A Bn Bpm Wx Wu D SX)
     double G[49], Pt[49], Minv[49], Kg[21];
 };
-constexpr int OPS_IN = 156;
+constexpr int OPS_IN = 91 + NB_N;
 
 struct Scratch {   // LDS working set of the recursion
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
@@ -897,14 +968,15 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         cgf64 *p2 = nb + (e2 < OPS_IN ? e2 - 91 : 0);
         pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
     };
-    // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7]
+    // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7 | SX 8]
     auto ops_slot = [](int e) -> int {
         if (e < 49) return (int)offsetof(StageOps, F) + 8 * ((e / 7) * FS + e % 7);
         if (e < 70) return (int)offsetof(StageOps, Bn) + 8 * (e - 49);
         if (e < 91) return (int)offsetof(StageOps, Bpm) + 8 * (e - 70);
         if (e < 140) return (int)offsetof(StageOps, G2) + 8 * (((e - 91) / 7) * FS + (e - 91) % 7);
         if (e < 149) return (int)offsetof(StageOps, Wu) + 8 * (e - 140);
-        return (int)offsetof(StageOps, D) + 8 * ((e < OPS_IN) ? e - 149 : 0);
+        if (e < 156) return (int)offsetof(StageOps, D) + 8 * (e - 149);
+        return (int)offsetof(StageOps, SX) + 8 * ((e < OPS_IN) ? e - 156 : 0);
     };
     const int slot0 = ops_slot(lane), slot1 = ops_slot(e1), slot2 = ops_slot(e2);
     auto stash = [&](StageOps &o, int k) {
@@ -912,7 +984,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         char *base = (char *)&o;
         *(double *)(base + slot0) = dynk ? pre[0] : 0.0;
         *(double *)(base + slot1) = ((e1 < 70) ? dynk : (e1 < 91) ? (k >= 1) : true) ? pre[1] : 0.0;
-        if (e2 < OPS_IN) *(double *)(base + slot2) = (e2 < 149 || dynk) ? pre[2] : 0.0;
+        if (e2 < OPS_IN) *(double *)(base + slot2) = (e2 < 149 || e2 >= 156 || dynk) ? pre[2] : 0.0;
     };
     fetch(K - 1);
     stash(w.ops[(K - 1) & 1], K - 1);
@@ -1057,9 +1129,46 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         wsync();
         FT_MARK(5)
         // P7-P9: every lane inverts the 3x3 itself; P_k = sym(Qyy - Quy^T Qi Quy) straight from its own two columns of
-        // Quy (no exchange of the gain on the way); the gain Kg = Qi Quy goes to LDS / the factor record for the sweeps
+        // Quy (no exchange of the gain on the way); the gain Kg = Qi Quy goes to LDS / the factor record for the sweeps.
+        // Stiff stage terms (excess weight ex above kStageCap of the position term, direction a, and of the thrust ball,
+        // direction c_u = 2u; newton_blocks left them out of Wx / Wu) come in here as Q += ex c c^T with c = (c_u, c_y)
+        // in the (u_k, y_k) coordinates (x_k = y_k + Bpm u_k, so the position term has c_u = Bpm^T a, c_y = a), by
+        // Sherman-Morrison on the already inverted Q_uu:  t = Qi c_u, om = 1 / (1/ex + c_u.t), v = c_y - Quy^T t,
+        // Qi -= om t t^T, Kg += om t v^T, P_k += om v v^T  -- the weight enters only through 1/ex, nothing of size ex
+        // is ever formed (condensed into the blocks, 1e14 r r^T would leave no digit of the curvature 2 w_tr).
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
+        const double ex_x = o.SX[SX_EX], ex_u = o.SX[SX_EU];
+        double om1 = 0.0, om2 = 0.0, t1[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, tc = 0.0;
+        const bool stiff = (ex_x > 0.0) || (ex_u > 0.0);            // wave-uniform (same LDS words in every lane)
+        if (stiff) {
+            double ax[3], cu[3], c1[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) { ax[l] = o.SX[SX_A + l]; cu[l] = o.SX[SX_CU + l]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c1[j] = o.Bpm[j] * ax[0] + o.Bpm[3 + j] * ax[1] + o.Bpm[6 + j] * ax[2];
+            if (ex_x > 0.0) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) t1[l] = Qi[l * 3] * c1[0] + Qi[l * 3 + 1] * c1[1] + Qi[l * 3 + 2] * c1[2];
+                om1 = 1.0 / (1.0 / ex_x + (c1[0] * t1[0] + c1[1] * t1[1] + c1[2] * t1[2]));
+            }
+            if (ex_u > 0.0) {
+                double q2[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) q2[l] = Qi[l * 3] * cu[0] + Qi[l * 3 + 1] * cu[1] + Qi[l * 3 + 2] * cu[2];
+                tc = t1[0] * cu[0] + t1[1] * cu[1] + t1[2] * cu[2];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) t2[l] = q2[l] - om1 * tc * t1[l];                  // Qi' c_u with Qi' = Qi - om1 t1 t1^T
+                om2 = 1.0 / (1.0 / ex_u + (cu[0] * t2[0] + cu[1] * t2[1] + cu[2] * t2[2]));
+            }
+        }
+        // component j of v1 = a - Quy^T t1 and of v2 = -Kg'^T c_u = -(Quy^T q2) - om1 (t1.c_u) v1, from column j of Quy
+        auto sm_v = [&](const double (&qc)[3], int j, double &v1, double &v2) {
+            const double cyj = (j < 3) ? o.SX[SX_A + j] : 0.0;
+            v1 = cyj - (qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2]);
+            // Quy^T q2 = Quy^T (t2 + om1 tc t1)
+            v2 = -(qc[0] * t2[0] + qc[1] * t2[1] + qc[2] * t2[2]) - om1 * tc * (qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2]) - om1 * tc * v1;
+        };
         if (lane < 49) {
             const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
             double qi[3], qj[3];
@@ -1074,14 +1183,28 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
                 const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, hi)
                 a1 -= qi[l] * kj;
             }
+            if (stiff) {
+                double v1l, v2l, v1h, v2h;
+                sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
+                a1 += om1 * (v1l * v1h) + om2 * (v2l * v2h);
+            }
             w.Pn[lane] = a1;
         }
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
-            const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
+            const double qc[3] = {w.Quy[c], w.Quy[7 + c], w.Quy[14 + c]};
+            double kg = Qi[r * 3] * qc[0] + Qi[r * 3 + 1] * qc[1] + Qi[r * 3 + 2] * qc[2];
+            if (stiff) {
+                double v1, v2;
+                sm_v(qc, c, v1, v2);
+                kg += om1 * t1[r] * v1 + om2 * t2[r] * v2;
+            }
             o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.F[(lane / 3) * FS + 7 + lane % 3];
         }
-        if (lane < 9) fac[F_QI + lane] = Qi[lane];
+        if (lane < 9) {
+            const int r = lane / 3, c = lane - 3 * r;
+            fac[F_QI + lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
+        }
         FT_MARK(6)
         FT_MARK(7)
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
@@ -1312,8 +1435,11 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int 
         for (int q = 0; q < 4; ++q) if (act[q]) dr[dst[q]] = base[q] + v[q];
     }
     if (lane == 0) {
-        if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = -s.itg[G_LVT] + sd.sol[1]; }
-        else { s.drg[G_TF] += sd.sol[0]; s.drg[G_LVT] += sd.sol[1]; }
+        if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = sd.linvt ? 0.0 : -s.itg[G_LVT] + sd.sol[1]; }
+        else { s.drg[G_TF] += sd.sol[0]; if (!sd.linvt) s.drg[G_LVT] += sd.sol[1]; }
+        if (sd.linvt) sd.zeta_vt = (first ? 0.0 : sd.zeta_vt) + sd.sol[1];
+        // the zetas of the stiff terminal terms are border unknowns like dtf: kept for the refinement's residual
+        for (int t = 0; t < NTERM; ++t) sd.zeta[t] = (first ? 0.0 : sd.zeta[t]) + sd.sol[2 + t];
     }
     __syncthreads();
 }
@@ -1328,6 +1454,14 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int 
 // without it the iteration can alternate between a descent and an ascent direction in tf on short-arc references --
 // and it runs redundantly in the registers of every lane.  A zeta without excess weight is decoupled (pivot -1).
 __device__ __forceinline__ int border_channel(int q) { return q == NBD - 1 ? 1 : 2 + q; }
+// Row p < NBD-1 of the border: 1/wex of a zeta row with excess weight, 0 for a zeta row without (decoupled), and `eq`
+// set for the tangential equality (row 0 of the exact variant; in the convex variant row 0 is the zeta row of the pair)
+__device__ __forceinline__ double border_iw(const SatData &sd, int p, bool &eq)
+{
+    eq = (p == 0) && !sd.linvt;
+    const double wex = (p == 0) ? (sd.linvt ? sd.w_vt - sd.gam : 0.0) : sd.tw[p - 1] - sd.twin[p - 1];
+    return (!eq && wex > 0.0) ? 1.0 / wex : 0.0;
+}
 
 __device__ __noinline__ bool border_factor(SatData &sd, int lane)
 {
@@ -1351,12 +1485,14 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
 #pragma unroll
         for (int q = 0; q < NBD; ++q) S[p][q] = sd.Mb[p][q];
 #pragma unroll
-    for (int t = 0; t < NTERM; ++t) {
-        const double wex = sd.tw[t] - sd.twin[t];
-        const bool on = wex > 0.0;
+    for (int p = 0; p < NBD - 1; ++p) {
+        bool eq;
+        const double iw = border_iw(sd, p, eq);
+        const bool on = iw > 0.0;
+        if (eq) continue;
 #pragma unroll
-        for (int q = 0; q < NBD; ++q) if (!on && q != 1 + t) { S[1 + t][q] = 0.0; S[q][1 + t] = 0.0; }
-        S[1 + t][1 + t] = on ? S[1 + t][1 + t] - 1.0 / wex : -1.0;
+        for (int q = 0; q < NBD; ++q) if (!on && q != p) { S[p][q] = 0.0; S[q][p] = 0.0; }
+        S[p][p] = on ? S[p][p] - iw : -1.0;
     }
     bool ok = true;
     double rd[NBD];
@@ -1401,12 +1537,13 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
         rb[p] = -acc;
     }
     rb[0] += rvt_rhs;
-    double iw[NTERM];
+    double iw[NBD - 1];
+    bool eqr[NBD - 1];
 #pragma unroll
-    for (int t = 0; t < NTERM; ++t) {
-        const double wex = sd.tw[t] - sd.twin[t];
-        iw[t] = (wex > 0.0) ? 1.0 / wex : 0.0;
-        rb[1 + t] = (wex > 0.0) ? rb[1 + t] - gex[t] * iw[t] : 0.0;
+    for (int p = 0; p < NBD - 1; ++p) {
+        iw[p] = border_iw(sd, p, eqr[p]);
+        if (p >= 1) rb[p] = (iw[p] > 0.0) ? rb[p] - gex[p - 1] * iw[p] : 0.0;
+        else if (!eqr[0] && !(iw[0] > 0.0)) rb[0] = 0.0;       // convex variant, pair without excess weight: decoupled
     }
     rb[NBD - 1] = -gtf_rhs + sd.siglam[0];
     auto ldl_solve = [&](double (&v)[NBD]) {
@@ -1431,10 +1568,10 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
 #pragma unroll
         for (int q = 0; q < NBD; ++q) {
             double s = sd.Sb[p][q];
-            const int tp = p - 1, tq = q - 1;
-            const bool offp = (tp >= 0 && tp < NTERM) && !(iw[tp < 0 ? 0 : (tp >= NTERM ? 0 : tp)] > 0.0);
-            const bool offq = (tq >= 0 && tq < NTERM) && !(iw[tq < 0 ? 0 : (tq >= NTERM ? 0 : tq)] > 0.0);
-            if (p == q && tp >= 0 && tp < NTERM) s = offp ? -1.0 : s - iw[tp];
+            const int pc = p < NBD - 1 ? p : 0, qc = q < NBD - 1 ? q : 0;
+            const bool zp = p < NBD - 1 && !eqr[pc], zq = q < NBD - 1 && !eqr[qc];      // zeta rows / columns
+            const bool offp = zp && !(iw[pc] > 0.0), offq = zq && !(iw[qc] > 0.0);
+            if (p == q && zp) s = offp ? -1.0 : s - iw[pc];
             else if (offp || offq) s = 0.0;
             acc -= s * x[q];
         }
@@ -1453,8 +1590,13 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
 }
 
 // Residual of the reduced KKT system at the current direction -> rhs record of channel 0
-// ("Linear solve").  Stage-parallel.  Returns gtf_rhs, rvt_rhs, gterm[] via sd.red / gterm.
-__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
+// ("Linear solve").  Stage-parallel.  Returns gtf_rhs, rvt_rhs and gex[] = wex * (residual of the zeta rows).
+// The border unknowns zeta_t of the stiff terminal terms are part of the direction being refined (sd.zeta): the x_K row
+// carries zeta_t a_t itself and the zeta row reads a_t.dx_K - zeta_t / wex_t + gh_t / w_t -- every entry O(1) -- so a
+// refinement pass solves for small corrections of all border unknowns and thereby removes the cancellation error the
+// first pass's combination of O(1) channel trajectories into an O(1e-8) direction leaves in dx_K (which a terminal
+// weight of 1e16 would turn into an O(1) error of the new multipliers).
+__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
 {
     const int K = s.K;
     double gtf_part = 0.0;
@@ -1494,6 +1636,16 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc += nb[N_WU + i * 3 + j] * d[I_U + j];
             gu[i] = acc;
+        }
+        {
+            // the stiff stage terms' excess weight, which the blocks N_WX / N_WU do not carry (newton_blocks)
+            const double ex_x = nb[N_SX + SX_EX], ex_u = nb[N_SX + SX_EU];
+            const double a0 = nb[N_SX + SX_A], a1 = nb[N_SX + SX_A + 1], a2 = nb[N_SX + SX_A + 2];
+            const double c0 = nb[N_SX + SX_CU], c1 = nb[N_SX + SX_CU + 1], c2 = nb[N_SX + SX_CU + 2];
+            const double px = ex_x * (a0 * d[I_X] + a1 * d[I_X + 1] + a2 * d[I_X + 2]);
+            const double pu = ex_u * (c0 * d[I_U] + c1 * d[I_U + 1] + c2 * d[I_U + 2]);
+            if (k >= 1 && k <= K - 2) { gx[0] += px * a0; gx[1] += px * a1; gx[2] += px * a2; }
+            gu[0] += pu * c0; gu[1] += pu * c1; gu[2] += pu * c2;
         }
         if (k >= 1) {
             const auto Bp = s.Bpt(k - 1);
@@ -1548,32 +1700,48 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
     double av = 0.0;
     for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
     rvt_rhs = -sd.cv - av;
+    double rvt_x = rvt_rhs;     // what the x_K row's shift -gam * rvt_x * a_vt uses (the same value for the equality)
+    if (sd.linvt) {
+        // the tangential pair as a terminal rank-1 term: gam is its capped share, zeta_vt its border unknown
+        const double wex = sd.w_vt - sd.gam;
+        const bool on = wex > 0.0;
+        rvt_x = -(sd.gh_vt * (sd.gam / sd.w_vt) + sd.gam * av + (on ? sd.zeta_vt : 0.0)) / sd.gam;
+        rvt_rhs = on ? -(av - sd.zeta_vt / wex + sd.gh_vt / sd.w_vt) : 0.0;
+    }
+    double gin[NTERM];          // coefficient of a_t in the x_K row: gh share + win a.dx + zeta
     for (int t = 0; t < NTERM; ++t) {
-        double acc = 0.0;
-        for (int i = 0; i < 7; ++i) acc += sd.ta[t][i] * dK[I_X + i];
-        gterm[t] = sd.tgh[t] + sd.tw[t] * acc;
+        double adx = 0.0;
+        for (int i = 0; i < 7; ++i) adx += sd.ta[t][i] * dK[I_X + i];
+        const double wex = sd.tw[t] - sd.twin[t];
+        const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+        const bool on = wex > 0.0;
+        gin[t] = sd.tgh[t] * share + sd.twin[t] * adx + (on ? sd.zeta[t] : 0.0);
+        gex[t] = on ? (adx - sd.zeta[t] / wex + sd.tgh[t] / sd.tw[t]) * wex : 0.0;
     }
     __syncthreads();
-    // terminal-node rhs completion: capped share of the rank-1 gradient terms and the AL shift
+    // terminal-node rhs completion: the rank-1 terms and the AL shift
     if (lane == 0) {
         gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
-        for (int t = 0; t < NTERM; ++t) {
-            const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gterm[t] * share * sd.ta[t][i];
-        }
-        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_rhs * sd.avt[i];
+        for (int t = 0; t < NTERM; ++t)
+            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gin[t] * sd.ta[t][i];
+        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_x * sd.avt[i];
     }
     __syncthreads();
 }
 
 // Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
 // themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).  Lane k writes node k's record.
-__device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gterm)
+__device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
 {
     const int K = s.K;
     gtf_rhs = sd.gtf;
-    rvt_rhs = -sd.cv;
-    for (int t = 0; t < NTERM; ++t) gterm[t] = sd.tgh[t];
+    rvt_rhs = sd.linvt ? -sd.gh_vt / sd.w_vt : -sd.cv;       // (convex variant: the pair's zeta row at the zero direction)
+    double gterm[NTERM];
+    for (int t = 0; t < NTERM; ++t) {
+        gterm[t] = sd.tgh[t];
+        const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+        gex[t] = gterm[t] * (1.0 - share);          // = wex * gh / w: the zeta row's residual at the zero direction, times wex
+    }
     for (int k = lane; k < K; k += 64) {
         const auto ns = s.nsn(k);
         gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
@@ -1696,13 +1864,14 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             }
         }
         if (h0 && k == K - 1) {
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < sd.nT; ++j) {
+                const int js = gs_term(j), jz = gz_term(j);
                 double gj = -sd.bT[j], dg = 0.0;
                 for (int i = 0; i < 7; ++i) { gj += sd.aT[j][i] * x[i]; dg += sd.aT[j][i] * dx[i]; }
-                const double sj = s.itg[G_STERM + j], zj = s.itg[G_ZTERM + j];
+                const double sj = s.itg[js], zj = s.itg[jz];
                 const double sig = zj / sj, zh = mu / sj + sig * (gj + sj);
-                s.drg[G_STERM + j] = -(gj + sj) - dg; s.drg[G_ZTERM + j] = zh + sig * dg - zj;
-                LIM(sj, s.drg[G_STERM + j]); LIM(zj, s.drg[G_ZTERM + j]);
+                s.drg[js] = -(gj + sj) - dg; s.drg[jz] = zh + sig * dg - zj;
+                LIM(sj, s.drg[js]); LIM(zj, s.drg[jz]);
             }
             const double srf = s.itg[G_SRF], zrf = s.itg[G_ZRF];
             const double g = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - sd.b_rfmax;
@@ -1846,10 +2015,10 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         for (int i = 0; i < GL_N; ++i) { s.itg[i] = 0.0; s.drg[i] = 0.0; }
         double xK[7];
         for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < sd.nT; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * xK[i];
-            s.itg[G_STERM + j] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[G_ZTERM + j] = kMuInit / s.itg[G_STERM + j];
+            s.itg[gs_term(j)] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[gz_term(j)] = kMuInit / s.itg[gs_term(j)];
         }
         const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
         s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = kMuInit / s.itg[G_SRF];
@@ -1861,7 +2030,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     __syncthreads();
 
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
-    const int nzc = n_ineq(K);
+    const int nzc = n_ineq(K, sd.nT);
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
@@ -1872,7 +2041,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     PT_END(0)
     for (int iter = 0;; ++iter) {
         it_count = iter;
-        E0 = scaled_error(r0, K, 0.0);
+        E0 = scaled_error(r0, K, sd.nT, 0.0);
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
         n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
@@ -1894,9 +2063,9 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             PT_BEGIN
             newton_blocks(s, sd, mu, delta_w, lane);
             PT_END(1)
-            double gtf_rhs, rvt_rhs, gterm[NTERM], gex[NTERM];
+            double gtf_rhs, rvt_rhs, gex[NTERM];
             PT_BEGIN
-            initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gterm);      // right-hand side of the first solve = the Newton blocks
+            initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gex);        // right-hand side of the first solve = the Newton blocks
             PT_END(5)
             // iterative refinement only once a barrier weight (terminal rank-1 terms, stage balls and planes, the tf
             // bounds) is stiff enough to cost digits
@@ -1915,12 +2084,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
                 for (int pass = 0; pass < passes && ok; ++pass) {
                     if (pass > 0) {
                         PT_BEGIN
-                        reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gterm);
+                        reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gex);
                         PT_END(5)
-                    }
-                    for (int t = 0; t < NTERM; ++t) {
-                        const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-                        gex[t] = gterm[t] * (1.0 - share);
                     }
                     // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only
                     const int c1 = (pass == 0) ? NCH : 1;
@@ -1949,7 +2114,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
                         for (int j = 0; j < NCH; ++j) lg[n++] = sd.siglam[j];
                         for (int c = 0; c < NCH; ++c) for (int j = 0; j < 7; ++j) lg[n++] = sd.xK[c][j];
                         lg[n++] = gtf_rhs; lg[n++] = rvt_rhs;
-                        for (int j = 0; j < NTERM; ++j) lg[n++] = gterm[j];
+                        for (int j = 0; j < NTERM; ++j) lg[n++] = gex[j];
                         lg[n++] = sd.Wtf; lg[n++] = sd.gam; lg[n++] = delta_w;
                     }
 #endif
@@ -2051,9 +2216,9 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
 {
     SolveOpts d;
     d.min_mass = o->min_mass; d.u_max = o->u_max; d.r_min = o->r_min; d.r_max = o->r_max; d.eps_r = o->eps_r;
-    d.eps_vr = o->eps_vr; d.eps_vn = o->eps_vn; d.tf_max = o->tf_max; d.w_nu = o->w_nu; d.w_tr = o->w_tr;
+    d.eps_vr = o->eps_vr; d.eps_vn = o->eps_vn; d.eps_vt = o->eps_vt; d.tf_max = o->tf_max; d.w_nu = o->w_nu; d.w_tr = o->w_tr;
     d.tol = o->tol; d.acc_tol = o->acceptable_tol; d.max_iter = o->max_iter; d.acc_iter = o->acceptable_iter;
-    d.n_refine = o->n_refine; d.pad = 0;
+    d.n_refine = o->n_refine; d.linvt = (o->flags & MPCX_SOLVE_LINEAR_VT) ? 1 : 0;
     return d;
 }
 
@@ -2061,7 +2226,7 @@ extern "C" void mpcx_default_solve_opts(mpcx_solve_opts *o)
 {
     // reference defaults: optimizer.py:178-188; ipopt defaults: tol 1e-8, acceptable_tol 1e-6
     o->min_mass = 0.1; o->u_max = 5.0; o->r_min = 0.99; o->r_max = 5.0; o->eps_r = 0.01;
-    o->eps_vr = 1e-5; o->eps_vn = 1e-5; o->tf_max = 5.0; o->w_nu = 1000.0; o->w_tr = 0.002;
+    o->eps_vr = 1e-5; o->eps_vn = 1e-5; o->eps_vt = 1e-5; o->tf_max = 5.0; o->w_nu = 1000.0; o->w_tr = 0.002;
     o->tol = 1e-8; o->acceptable_tol = 1e-6; o->max_iter = 200; o->acceptable_iter = 15; o->n_refine = 1; o->flags = 0;
 }
 

@@ -16,10 +16,20 @@ class SolveResult:
         self.X, self.U, self.NU, self.tf, self.status, self.iters, self.kkt = X, U, NU, tf, status, iters, kkt
 
 
+def _solver_flags(solver, linear_vt):
+    """linear_vt: the linearised tangential pair the reference keeps commented out (optimizer.py:471-489, 575-576;
+    tolerance options['eps_vt']) instead of the exact equality it enables (:577) -- MPCX_SOLVE_LINEAR_VT."""
+    solver = dict(solver)
+    if linear_vt:
+        solver["flags"] = int(solver.get("flags", 0)) | _ffi.SOLVE_LINEAR_VT
+    return solver
+
+
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   **solver):
+                   linear_vt=False, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays."""
+    solver = _solver_flags(solver, linear_vt)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     if xbar.shape[1] != 7 or ubar.shape != (S, 3, K):
@@ -40,8 +50,9 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     return SolveResult(X, U, NU, tfo, status, iters, kkt)
 
 
-def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, **solver):
+def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, **solver):
     """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""
+    solver = _solver_flags(solver, linear_vt)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     arrs = [_ffi.as_f64(a) for a in (A, Bp, Bn, Sigma, xi)]

@@ -311,17 +311,19 @@ def newton_blocks(P, it, mu, delta_w=0.0):
     # (Q_uu^-1, gain, P_k) in which it appears only as 1/sigma_ex (riccati_factor).  Wx, Wu keep the full weights for
     # the residuals of the refinement.
     Wx0 = Wx.copy(); Wu0 = Wu.copy(); stiff = [[] for _ in range(K)]
+    for k in range(1, K - 1):
+        # at most one of the two position terms can be stiff (r_min < r_max): the one with the larger excess leaves the
+        # block, the other stays whole
+        ex_max = sig["rmax"][k - 1] - STAGE_CAP; ex_min = sig["rmin"][k - 1] - STAGE_CAP
+        cy = np.zeros(7)
+        if ex_max > 0 and ex_max >= ex_min: cy[:3] = 2 * X[:3, k]; ex = ex_max
+        elif ex_min > 0: cy[:3] = P.rbar_hat[:, k]; ex = ex_min
+        else: continue
+        Wx0[k] -= ex * np.outer(cy, cy); stiff[k].append((None, cy, ex))
     for k in range(K):
         ex = sig["u"][k] - STAGE_CAP
         if ex > 0:
             cu = 2 * U[:, k]; Wu0[k] -= ex * np.outer(cu, cu); stiff[k].append((cu, np.zeros(7), ex))
-    for k in range(1, K - 1):
-        r = X[:3, k]; rh = P.rbar_hat[:, k]
-        for (vec, sg) in ((2 * r, sig["rmax"][k - 1]), (rh, sig["rmin"][k - 1])):
-            ex = sg - STAGE_CAP
-            if ex > 0:
-                cy = np.zeros(7); cy[:3] = vec
-                Wx0[k] -= ex * np.outer(cy, cy); stiff[k].append((None, cy, ex))
     r = X[:3, K - 1]
     WxK_soft = Wx[K - 1].copy()
     WxK_soft[:3, :3] += 2 * (z["rmax"][K - 2] + z["rfmax"][0]) * np.eye(3)

@@ -25,15 +25,15 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
     assert set(_ffi.exported_symbols()) == set(names)     # the Python binding binds exactly the header
-    assert _ffi.load().mpcx_version() == 100
+    assert _ffi.load().mpcx_version() == 200
 
 
 def test_struct_layout_and_defaults():
     from mpconstellation_amd import _ffi
     o = _ffi.make_solve_opts({"u_lim": [0, 3.0], "r_lim": [0.95, 4.0], "eps_r": 1e-3, "tf_max": 2.0}, max_iter=50)
-    assert C.sizeof(_ffi.SolveOpts) == 12 * 8 + 4 * 4
+    assert C.sizeof(_ffi.SolveOpts) == 13 * 8 + 4 * 4
     assert (o.u_max, o.r_min, o.r_max, o.eps_r, o.tf_max, o.max_iter) == (3.0, 0.95, 4.0, 1e-3, 2.0, 50)
-    assert (o.min_mass, o.eps_vr, o.eps_vn, o.w_nu, o.w_tr, o.tol) == (0.1, 1e-5, 1e-5, 1000.0, 0.002, 1e-8)   # optimizer.py:178-188
+    assert (o.min_mass, o.eps_vr, o.eps_vn, o.eps_vt, o.w_nu, o.w_tr, o.tol) == (0.1, 1e-5, 1e-5, 1e-5, 1000.0, 0.002, 1e-8)   # optimizer.py:178-188
     lib = _ffi.load()
     assert lib.mpcx_mpc_step_workspace_bytes(64, 30) > lib.mpcx_solve_workspace_bytes(64, 30) > 0
 

@@ -18,7 +18,7 @@ TOL_PATH = 1e-6   # iterates half way along the same path (unrefined directions,
 TOL_SOL = 5e-6    # stated fp64 tolerance of a converged solution (tol 1e-8 on the scaled KKT error leaves the
                   # minimiser determined to ~1e-6 because the objective is flat: w_tr = 0.002); used wherever GPU and
                   # oracle discretise independently, where a 1e-16 difference can flip one line-search decision
-CASES = ["tan_K20_tf2", "tan_K30_tf1", "tan_K60_tf2", "tan_K100_tf1", "zero_K20_tf1", "tanJ2_K30_tf1"]
+CASES = ["tan_K20_tf2", "tan_K30_tf1", "tan_K60_tf2", "tan_K100_tf1", "zero_K20_tf1", "tanJ2_K30_tf1", "const_K30_tf1"]
 
 
 def oracle_solve(x, u, tf, cst, r_des, stage=None, **kw):

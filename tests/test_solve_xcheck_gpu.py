@@ -1,0 +1,85 @@
+"""The HIP solver (through the C ABI) against INDEPENDENT solutions of the reference's NLP: tests/golden/xcheck_*.npz,
+computed by scipy's trust-constr from a second transcription of optimizer.py on the reference's own A/B matrices
+(tests/golden/make_nlp_xcheck.py) -- not by this repo's oracle, which is only compared alongside.  Covers
+BASELINE configs[0]'s workload (Hubble, tangential 0.5, tf 2, K = 20), the N = 30 horizon, ipopt's zero start,
+an optimum that needs virtual control, OptimalController's option set and the convex linearised-vt variant."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import oracle_lib as O
+import nlp_ipm as N
+
+pytestmark = pytest.mark.gpu
+XCHECK = ["tan_K20_tf2", "tan_K30_tf1", "tan_K30_tf1_zero", "const_K30_tf1", "tan_K20_tf2_linvt", "tan_K30_tf1_linvt",
+          "const_K30_tf1_linvt", "tan_K30_tf1_mpc105", "tan_K60_tf2_mpc12", "tan_K60_tf2_mpc15"]
+# two solvers at tol 1e-8 on an objective that is flat in u (held by 2 w_tr = 0.004 only): x 1e-5, tf 1e-6, u 5e-4;
+# the convex variant has a unique minimiser: x 1e-6, tf 5e-8, u 1e-5
+TOL = {"exact": (1e-5, 5e-4, 1e-6), "linvt": (1e-6, 1e-5, 5e-8)}
+
+
+def load(golden_dir, case):
+    f = np.load(os.path.join(golden_dir, f"xcheck_{case}.npz"))
+    d = np.load(os.path.join(golden_dir, f"disc_{str(f['fixture'])}.npz"))
+    opts = {str(k): float(v) for k, v in zip(f["option_keys"], f["option_vals"])}
+    return f, d, opts
+
+
+def device_solve(d, opts, r_des, variant, **kw):
+    from mpconstellation_amd import solve_batch
+    x, u = d["x"], d["u"]
+    return solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
+                       [float(d["tf"])], d["const"][None], [r_des], options=opts, linear_vt=(variant == "linvt"), **kw)
+
+
+@pytest.mark.parametrize("case", XCHECK)
+def test_device_vs_independent_nlp_solution(golden_dir, case):
+    f, d, opts = load(golden_dir, case)
+    variant = str(f["variant"])
+    res = device_solve(d, opts, float(f["r_des"]), variant)
+    assert res.status[0] == 0 and res.kkt[0] <= 1e-8
+    tx, tu, ttf = TOL[variant]
+    assert np.abs(res.X[0] - f["X"]).max() < tx
+    assert np.abs(res.U[0] - f["U"]).max() < tu
+    assert np.abs(res.NU[0] - f["NU"]).max() < 1e-6
+    assert abs(res.tf[0] - float(f["tf_opt"])) < ttf
+    # ... and against the CPU oracle (same algorithm): solver-tolerance agreement, same iteration count give or take
+    # the decisions rounding can flip
+    x, u, cst = d["x"], d["u"], d["const"]
+    P = N.MpcProblem(x, u, float(d["tf"]), cst[0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
+                     O.constraint_terms(x, u, cst[0]), {"r_des": float(f["r_des"]), **opts}, variant=variant)
+    ref = N.solve(P)
+    assert ref["status"] == 0
+    assert np.abs(res.X[0] - ref["X"]).max() < 5e-6 and abs(res.tf[0] - ref["tf"]) < 5e-6
+    assert abs(int(res.iters[0]) - ref["iters"]) <= 10
+
+
+def test_virtual_control_optimum_on_device(golden_dir):
+    """test_discretizer.py:59's constant-thrust reference: the optimum keeps |nu|_1 = 0.074 on one position component of
+    the last interval (round 1's solver stalled on it)."""
+    f, d, opts = load(golden_dir, "const_K30_tf1")
+    res = device_solve(d, opts, float(f["r_des"]), "exact")
+    assert res.status[0] == 0
+    assert abs(np.abs(res.NU[0]).sum() - np.abs(f["NU"]).sum()) < 1e-6 and np.abs(f["NU"]).sum() > 0.07
+    assert res.iters[0] <= 60
+
+
+def test_convex_variant_batch_is_order_independent(golden_dir):
+    """linear-vt flag on a batch: every satellite converges, results do not depend on the batch composition."""
+    from mpconstellation_amd import solve_batch
+    c64 = np.load(os.path.join(golden_dir, "constellation64.npz"))
+    idx = list(c64["idx"])
+    pack = lambda key: np.stack([c64[f"{key}_{i}"] for i in idx])
+    x, u, cs = pack("x"), pack("u"), pack("const")
+    r_des = np.linalg.norm(x[:, :3, -1], axis=1)
+    args = [pack(k) for k in ("A", "Bp", "Bn", "Sigma", "xi")]
+    a = solve_batch(*args, x, u, np.ones(len(idx)), cs, r_des, linear_vt=True)
+    assert (a.status == 0).all() and a.kkt.max() <= 1e-8
+    rev = slice(None, None, -1)
+    b = solve_batch(*[v[rev] for v in args], x[rev], u[rev], np.ones(len(idx)), cs[rev], r_des[rev], linear_vt=True)
+    assert np.array_equal(a.X, b.X[rev]) and np.array_equal(a.tf, b.tf[rev])
+    e = solve_batch(*args, x, u, np.ones(len(idx)), cs, r_des)                   # the exact variant differs (another constraint)
+    assert (e.status == 0).all() and np.abs(e.tf - a.tf).max() > 1e-6
