@@ -3,12 +3,16 @@
 
 One "step" = one pass of the hot path (Discretizer.discretize + get_constraint_terms + solve_OPT of
 the reference, one SCP iteration) over every satellite of the batch, inputs resident in HBM.
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement"."""
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
+
+`python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one process per GPU, before this process has
+touched a GPU); under an outer launcher (WORLD_SIZE set) it is one of the ranks."""
 import argparse
 import ctypes as C
 import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,19 +23,21 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {            # BASELINE.json configs: name -> (satellites per GPU, nodes K, SCP iterations per MPC step)
     "S64_K30": (64, 30, 1),            # configs[1]
-    "S4096_K30": (4096, 30, 1),        # configs[2]
+    "S4096_K30": (4096, 30, 1),        # configs[2]: the N = 30 single-GPU configuration the target is stated for
     "S4096_K100_scp2": (4096, 100, 2), # configs[3]: 2 SCP iterations with nonlinear re-rollout (control.py:166,183-227)
     "S8192_K30": (8192, 30, 1),        # configs[4] per GPU (65,536 over 8)
 }
+DEFAULT_SINGLE, DEFAULT_MULTI = "S4096_K30", "S8192_K30"
 F64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak
 FLOP_PER_NODE_ITER = 18e3       # factorisation 8.7k + 8-channel sweeps 7k + node-parallel phases 2.4k
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table
 
 
 def algorithmic_bytes(K):
-    """compulsory traffic of one fused satellite-MPC-step (one SCP iteration): read xbar(7K) ubar(3K)
-    tf consts(5), write x(7K) u(3K) nu(7K) tf status  =  8(27K+7)+8 bytes."""
-    return 8 * (27 * K + 7) + 8
+    """compulsory traffic of one satellite-MPC-step (one SCP iteration): read xbar(7K) ubar(3K) tf
+    consts(5), write x(7K) u(3K) nu(7K) tf status = 8(27K+7)+8 bytes, plus -- discretize and solve being two kernels --
+    the stage records A, B+-, Sigma, xi written by one and read by the other: 2 x 840 (K-1) bytes."""
+    return 8 * (27 * K + 7) + 8 + 1680 * (K - 1)
 
 
 class Runner:
@@ -74,6 +80,7 @@ class Runner:
         self.opts = _ffi.make_solve_opts({})
         self.stream = torch.cuda.current_stream().cuda_stream
         self.solve_events = []
+        self.first_status = None     # per SCP iteration: status / iterations of the last step (SCP workloads)
 
     def step(self, record=False):
         torch, lib, ctx, ffi = self.torch, self.lib, self.ctx, self.ffi
@@ -95,7 +102,9 @@ class Runner:
                 e1.record(); self.solve_events.append((e0, e1))
             if self.n_scp > 1:
                 # SCP re-linearisation point (control.py:221,227): nonlinear rollout under the optimised FOH sequence over
-                # tf_u; the new reference thrust is the sequence itself (FOH at its own nodes)
+                # tf_u; the new reference thrust is the sequence itself (FOH at its own nodes).  The reference samples this
+                # rollout at int(base_res * tf_u) nodes, a different count per satellite (ConstellationMPC groups by it);
+                # the benchmark keeps K nodes so that the batch stays one rectangular launch
                 ffi.check(lib.mpcx_propagate_batch_dev(ctx, S, K, p(self.d_y0), p(self.d_tfo), p(self.d_c), 0, ffi.CTRL_SEQUENCE,
                                                        p(self.d_U), K, p(self.d_one), 1e-3, p(self.d_x), p(self.d_pst), p(self.d_pns),
                                                        st), ctx, "propagate")
@@ -138,21 +147,68 @@ def measured_traffic(workload, kernel="solve_kernel"):
     return None
 
 
+def roofline(workload, S, K, solve_ms, iters):
+    B = algorithmic_bytes(K)
+    achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
+    flops = FLOP_PER_NODE_ITER * K * float(iters.sum())   # of the last solve_kernel launch on this rank
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": measured_traffic(workload), "kernel": "mpcx::solve_kernel", "kernel_ms": solve_ms,
+            "algorithmic_bytes_per_satellite": B,
+            "note": "algorithmic bytes = 8(27K+7)+8 + 1680(K-1) per satellite-MPC-step (SURVEY 8d, two-kernel form) x satellites per "
+                    "launch; duration = HIP events around solve_kernel on its launch stream; traffic = FETCH_SIZE+WRITE_SIZE of "
+                    "profiles/ (workspace traffic: the kernel is bound by the latency / issue rate of one wave per satellite, not by "
+                    "its algorithmic HBM bytes)",
+            # what actually limits the kernel: fp64 vector arithmetic of ~18 kflop per node and interior-point
+            # iteration against the 78.6 TFLOP/s fp64 vector peak
+            "valu_f64": {"achieved": flops / (solve_ms * 1e-3) / 1e12, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (solve_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}}
+
+
+def host_pointer_rate(h, S, local_rank, reps=3):
+    """the same step through the host-pointer entry point (numpy in / numpy out): H2D of the inputs and D2H of the results
+    through the context's pinned staging inside the timed region -- the PCIe-inclusive figure of SURVEY 8(d), reported
+    beside `value`, never as `value`"""
+    from mpconstellation_amd import mpc_step_batch
+    mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
+    t0 = time.perf_counter()
+    for _ in range(reps): mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": S / dt, "unit": "satellite-MPC-steps/s", "ms_per_call": dt * 1e3,
+            "note": "mpcx_mpc_step_batch: one SCP iteration per call; PCIe transfers through pinned staging and the copies "
+                    "between the caller's arrays and the staging included"}
+
+
+def spawn_ranks(args):
+    """--gpus N without an outer launcher: start the N ranks as child processes (this parent never touches a GPU) and
+    pass their output and exit code through."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="S64_K30", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help=f"default: {DEFAULT_SINGLE} on one GPU, {DEFAULT_MULTI} per GPU on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra S4096_K30 measurement of the default run")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="satellites solved by the CPU oracle")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra S64_K30 measurement of the default run")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="satellites solved by the CPU oracle")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     single_dev = os.environ.get("MPCX_BENCH_SINGLE_DEVICE") == "1"   # rehearsal of the N>1 path on a 1-GPU box (gloo)
     if single_dev:
         local_rank = 0
@@ -162,8 +218,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmpcx has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    workload = args.workload or (DEFAULT_SINGLE if world == 1 else DEFAULT_MULTI)
 
-    run = Runner(args.workload, rank, world, local_rank)
+    run = Runner(workload, rank, world, local_rank)
     S, K, n_scp = run.S, run.K, run.n_scp
     elapsed, solve_ms = measure(run, args.steps, args.warmup, world)
     status, iters, kkt = run.solver_stats()
@@ -174,27 +231,14 @@ def main():
     if rank == 0:
         S_total = S * world
         value = S_total * args.steps / elapsed
-        B = algorithmic_bytes(K)
-        achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
-        flops = FLOP_PER_NODE_ITER * K * float(iters.sum())   # of the last solve_kernel launch on this rank
-        traffic = measured_traffic(args.workload)
         out = {
             "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve per SCP iteration)",
             "value": value, "unit": "satellite-MPC-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "satellites_per_gpu": S, "satellites_total": S_total, "nodes_K": K,
+            "config": {"workload": workload, "satellites_per_gpu": S, "satellites_total": S_total, "nodes_K": K,
                        "scp_iterations_per_step": n_scp, "parallelism": f"satellite-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "mpcx::solve_kernel",
-                         "kernel_ms": solve_ms,
-                         "note": "algorithmic bytes = 8(27K+7)+8 per satellite per launch; duration = HIP events around solve_kernel on its "
-                                 "launch stream; traffic = FETCH_SIZE+WRITE_SIZE of profiles/ (workspace re-reads: the kernel is "
-                                 "bound by the latency / issue rate of one wave per satellite, not by algorithmic HBM bytes)",
-                         # what actually limits the kernel: fp64 vector arithmetic of ~18 kflop per node and interior-point
-                         # iteration against the 78.6 TFLOP/s fp64 vector peak
-                         "valu_f64": {"achieved": flops / (solve_ms * 1e-3) / 1e12, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": flops / (solve_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}},
+            "roofline": roofline(workload, S, K, solve_ms, iters),
             "solver": {"converged": int(stats[0].item()), "of": int(stats[1].item()),
                        "ipm_iterations_mean": float(iters.mean()), "ipm_iterations_max": int(iters.max()),
                        "kkt_max": float(kkt.max())},
@@ -205,33 +249,29 @@ def main():
         # device results of the timed steps (first SCP iteration's inputs are the host arrays only when n_scp == 1)
         dev_res = (run.d_X.cpu().numpy(), run.d_U.cpu().numpy(), run.d_tfo.cpu().numpy(), status) if n_scp == 1 else None
         if world == 1 and not args.no_also:
-            # the same step through the host-pointer entry point (numpy in / numpy out): staging allocation, H2D of the
-            # inputs and D2H of the results inside the timed region -- reported beside `value`, never as `value`
-            from mpconstellation_amd import mpc_step_batch
-            mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
-            t0 = time.perf_counter()
-            for _ in range(3): mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank)
-            dt = (time.perf_counter() - t0) / 3
-            out["host_pointer_entry"] = {"value": S / dt * (1 if n_scp == 1 else 1.0 / n_scp), "unit": "satellite-MPC-steps/s",
-                                         "ms_per_call": dt * 1e3,
-                                         "note": "mpcx_mpc_step_batch: one SCP iteration per call, PCIe transfers and staging included"}
-        if world == 1 and not args.no_also and args.workload == "S64_K30":
+            out["host_pointer_entry"] = host_pointer_rate(h, S if n_scp == 1 else S / n_scp, local_rank)
+            # the same launch order question for every workload: the default order is longest-first by the previous
+            # solve's iteration counts -- an exact predictor here (every step solves the same problems); a closed loop
+            # gets whatever correlation its consecutive steps have, the plain index order is the lower bound
+            run.opts.flags = 1; run.solve_events = []
+            ei, si = measure(run, max(2, args.steps // 2), 1, 1)
+            run.opts.flags = 0
+            out["index_launch_order"] = {"value": S * max(2, args.steps // 2) / ei, "ms_per_step": ei / max(2, args.steps // 2) * 1e3,
+                                         "solve_kernel_ms": si}
+        if world == 1 and not args.no_also and workload == DEFAULT_SINGLE:
             del run
             torch.cuda.empty_cache()
-            r2 = Runner("S4096_K30", 0, 1, local_rank)
-            r2.opts.flags = 1                                   # MPCX_SOLVE_INDEX_ORDER: plain index launch order
-            e2i, s2i = measure(r2, 3, 1, 1)
-            r2.opts.flags = 0; r2.solve_events = []
-            e2, s2 = measure(r2, 3, 1, 1)
-            st2, it2, _ = r2.solver_stats()
-            out["also"] = {"S4096_K30": {"value": 4096 * 3 / e2, "unit": "satellite-MPC-steps/s", "ms_per_step": e2 / 3 * 1e3,
-                                         "solve_kernel_ms": s2, "converged": int(((st2 == 0) | (st2 == 7)).sum()), "of": 4096,
-                                         "ipm_iterations_mean": float(it2.mean()),
-                                         "traffic": measured_traffic("S4096_K30"),
-                                         "index_launch_order": {"ms_per_step": e2i / 3 * 1e3, "solve_kernel_ms": s2i},
-                                         "note": "BASELINE configs[2], same run, 3 steps after 1 warm-up; default launch order = "
-                                                 "longest first by the previous solve's iteration counts (an exact predictor here: "
-                                                 "every step solves the same problems); index_launch_order = without it"}}
+            r2 = Runner("S64_K30", 0, 1, local_rank)
+            e2, s2 = measure(r2, args.steps, args.warmup, 1)
+            st2, it2, k2 = r2.solver_stats()
+            out["also"] = {"S64_K30": {"value": 64 * args.steps / e2, "unit": "satellite-MPC-steps/s", "steps": args.steps,
+                                       "warmup": args.warmup, "ms_per_step": e2 / args.steps * 1e3,
+                                       "roofline": roofline("S64_K30", 64, 30, s2, it2),
+                                       "solver": {"converged": int(((st2 == 0) | (st2 == 7)).sum()), "of": 64,
+                                                  "ipm_iterations_mean": float(it2.mean()), "ipm_iterations_max": int(it2.max()),
+                                                  "kkt_max": float(k2.max())},
+                                       "host_pointer_entry": host_pointer_rate(r2.host, 64, local_rank),
+                                       "note": "BASELINE configs[1] (64 satellites: 64 of the chip's 1024 SIMDs busy), same run"}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)
             if err: out["trajectory_error_vs_cpu_oracle"] = err
@@ -240,35 +280,52 @@ def main():
         dist.barrier(); dist.destroy_process_group()
 
 
-def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n, dev_res=None):
-    """The CPU oracle (oracle/: C discretize + numpy interior point) timed on one host core on the first n
-    satellites of the same workload.  Reported baseline only; pyomo+ipopt are not installed on this image.
-    With the device results of the same satellites it also returns BASELINE.json's 'trajectory error' against the
-    stand-in for ipopt (the oracle): max and 99th percentile over the sample of max_k |x_gpu - x_cpu|_inf etc."""
+def _cpu_worker(job):
+    """one satellite-MPC-step on the CPU oracle (C discretize + numpy interior point); runs in a spawned worker"""
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib as O
     import nlp_ipm as N
+    x, u, tf, cst, rd = job
+    d = O.discretize(x, u, tf, cst)
+    P = N.MpcProblem(x, u, tf, cst[0], d, O.constraint_terms(x, u, cst[0]), {"r_des": rd})
+    r = N.solve(P)
+    return r["status"], r["X"], r["U"], r["tf"]
+
+
+def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n, dev_res=None):
+    """The CPU oracle (oracle/: C discretize + numpy interior point) timed on ALL host cores (one worker process per core,
+    satellites dealt out evenly) on the first n satellites of the same workload.  Reported baseline only; pyomo+ipopt are
+    not installed on this image.  With the device results of the same satellites it also returns BASELINE.json's
+    'trajectory error' against the stand-in for ipopt (the oracle): max and 99th percentile over the sample."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.build()                                             # the C half, once, before the workers load it
     n = min(n, xbar.shape[0])
-    t0 = time.perf_counter(); ok = 0
+    cores = len(os.sched_getaffinity(0))
+    jobs = [(xbar[i], ubar[i], float(tfbar[i]), consts[i], float(r_des[i])) for i in range(n)]
+    with mp.get_context("spawn").Pool(cores) as pool:
+        pool.map(_cpu_worker, jobs[:cores])               # workers import numpy / load the library outside the timed region
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, jobs, chunksize=max(1, n // (4 * cores)))
+        dt = time.perf_counter() - t0
+    ok = sum(int(r[0] in (0, 7)) for r in res)
     ex, eu, et = [], [], []
-    for i in range(n):
-        d = O.discretize(xbar[i], ubar[i], float(tfbar[i]), consts[i])
-        terms = O.constraint_terms(xbar[i], ubar[i], consts[i][0])
-        P = N.MpcProblem(xbar[i], ubar[i], float(tfbar[i]), consts[i][0], d, terms, {"r_des": float(r_des[i])})
-        r = N.solve(P)
-        ok += int(r["status"] in (0, 7))
-        if dev_res is not None and r["status"] == 0 and dev_res[3][i] == 0:
-            ex.append(np.abs(dev_res[0][i] - r["X"]).max()); eu.append(np.abs(dev_res[1][i] - r["U"]).max())
-            et.append(abs(dev_res[2][i] - r["tf"]))
-    dt = time.perf_counter() - t0
-    base = {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} satellites of the workload, oracle/ (C discretize + numpy IPM), {ok}/{n} converged, {dt:.1f} s"}
+    if dev_res is not None:
+        for i, r in enumerate(res):
+            if r[0] == 0 and dev_res[3][i] == 0:
+                ex.append(np.abs(dev_res[0][i] - r[1]).max()); eu.append(np.abs(dev_res[1][i] - r[2]).max())
+                et.append(abs(dev_res[2][i] - r[3]))
+    base = {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} satellites of the workload, oracle/ (C discretize + numpy IPM), one worker process per host core "
+                      f"({cores}, nproc), {ok}/{n} converged, {dt:.1f} s wall = {dt * cores:.0f} core-seconds"}
     err = None
     if ex:
         q = lambda v: {"max": float(np.max(v)), "p99": float(np.percentile(v, 99))}
         err = {"x": q(ex), "u": q(eu), "tf": q(et), "satellites": len(ex), "stated_tolerance": 5e-6,
                "note": "normalised units; both sides converged to ipopt's scaled error 1e-8 on a flat objective (w_tr = 0.002); "
-                       "the reference's ipopt itself is not available on this image (parity unpinned, DESIGN.md section 2)"}
+                       "the reference's ipopt itself is not available on this image (parity unpinned, DESIGN.md section 2); "
+                       "tests/test_solve_xcheck_gpu.py compares the device with independent scipy solutions of the same NLP"}
     return base, err
 
 

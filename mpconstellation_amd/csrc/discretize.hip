@@ -498,6 +498,5 @@ extern "C" int mpcx_discretize_batch(mpcx_ctx *ctx, int S, int K, int Ku, const 
     if (rc) return rc;
     ar.download(A, dA, n * 49); ar.download(Bp, dBp, n * 21); ar.download(Bn, dBn, n * 21);
     ar.download(Sigma, dS, n * 7); ar.download(xi, dX, n * 7); ar.download(status, dst, S);
-    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ar.failed() ? ar.code() : MPCX_OK;
+    return ar.finish();
 }

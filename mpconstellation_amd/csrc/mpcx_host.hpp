@@ -7,6 +7,44 @@
 #include <vector>
 #include "../../include/mpcx.h"
 
+// Staging for the host-pointer entry points.  The buffers belong to the context and only grow: a device pool and a
+// pinned host pool, each a list of chunks that a call bump-allocates from and the next call reuses from the start --
+// in steady state a call allocates nothing (the first version paid a hipMalloc / hipFree pair per array and moved
+// pageable memory: +12 ms on a 4096-satellite step).  Uploads go caller -> pinned -> HBM, downloads HBM -> pinned and,
+// once the stream has drained (finish()), pinned -> caller.
+struct StagePool {
+    struct Chunk { char *p; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t cur, off;          // chunk in use and bump offset inside it
+    bool pinned;
+};
+
+inline void *pool_take(StagePool &pl, size_t bytes)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    while (pl.cur < pl.chunks.size()) {
+        if (pl.off + bytes <= pl.chunks[pl.cur].cap) { void *r = pl.chunks[pl.cur].p + pl.off; pl.off += bytes; return r; }
+        ++pl.cur; pl.off = 0;
+    }
+    size_t cap = bytes;
+    for (const auto &c : pl.chunks) cap = cap > c.cap ? cap : c.cap;
+    cap = cap > bytes ? cap * 2 : bytes;                    // new chunks at least double the largest so far
+    void *p = nullptr;
+    hipError_t e = pl.pinned ? hipHostMalloc(&p, cap, hipHostMallocDefault) : hipMalloc(&p, cap);
+    if (e != hipSuccess) return nullptr;
+    pl.chunks.push_back({(char *)p, cap});
+    pl.cur = pl.chunks.size() - 1; pl.off = bytes;
+    return p;
+}
+
+inline void pool_reset(StagePool &pl) { pl.cur = 0; pl.off = 0; }
+
+inline void pool_free(StagePool &pl)
+{
+    for (auto &c : pl.chunks) { if (pl.pinned) (void)hipHostFree(c.p); else (void)hipFree(c.p); }
+    pl.chunks.clear(); pl.cur = pl.off = 0;
+}
+
 struct mpcx_ctx {
     int device;
     hipStream_t stream;       // stream used by the host-pointer entry points
@@ -18,6 +56,7 @@ struct mpcx_ctx {
     // longest first; valid only for a following solve of the same batch size
     int32_t *prev_iters, *order;
     int order_S, order_valid, order_cap;
+    StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
 };
 
 inline int ctx_fail(mpcx_ctx *ctx, int code, const char *msg)
@@ -47,39 +86,52 @@ inline void *ctx_workspace(mpcx_ctx *ctx, size_t bytes)
     return p;
 }
 
-// RAII staging buffers for the host-pointer entry points.
+// Bump allocator over the two pools for the duration of one host-pointer call.
 class DeviceArena {
   public:
-    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0) {}
-    ~DeviceArena() { for (void *p : ptrs_) (void)hipFree(p); }
+    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0) { pool_reset(c->pool_dev); pool_reset(c->pool_host); }
     template <typename T> T *alloc(size_t n)
     {
-        void *p = nullptr;
         if (code_) return nullptr;
-        hipError_t e = hipMalloc(&p, n * sizeof(T) + 16);
-        if (e != hipSuccess) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, hipGetErrorString(e)); return nullptr; }
-        ptrs_.push_back(p);
+        void *p = pool_take(ctx_->pool_dev, n * sizeof(T) + 16);
+        if (!p) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "device staging allocation failed"); return nullptr; }
         return (T *)p;
     }
     template <typename T> T *upload(const T *h, size_t n)
     {
         T *d = alloc<T>(n);
         if (!d) return nullptr;
-        hipError_t e = hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
+        void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
+        if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return nullptr; }
+        memcpy(pin, h, n * sizeof(T));
+        hipError_t e = hipMemcpyAsync(d, pin, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         return d;
     }
     template <typename T> void download(T *h, const T *d, size_t n)
     {
         if (code_ || !h) return;
-        hipError_t e = hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
-        if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+        void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
+        if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return; }
+        hipError_t e = hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e != hipSuccess) { code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e)); return; }
+        out_.push_back({h, pin, n * sizeof(T)});
+    }
+    // wait for the stream, then hand the downloads to the caller's buffers
+    int finish()
+    {
+        if (code_) return code_;
+        hipError_t e = hipStreamSynchronize(ctx_->stream);
+        if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+        for (const auto &o : out_) memcpy(o.dst, o.src, o.bytes);
+        return MPCX_OK;
     }
     bool failed() const { return code_ != 0; }
     int code() const { return code_; }
 
   private:
+    struct Out { void *dst; const void *src; size_t bytes; };
     mpcx_ctx *ctx_;
     int code_;
-    std::vector<void *> ptrs_;
+    std::vector<Out> out_;
 };

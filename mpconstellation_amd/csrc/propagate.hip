@@ -258,6 +258,5 @@ extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const doub
                                       dns, ctx->stream);
     if (rc) return rc;
     ar.download(y_out, dy, (size_t)S * 7 * n_eval); ar.download(status, dst, S); ar.download(nsteps, dns, S);
-    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ar.failed() ? ar.code() : MPCX_OK;
+    return ar.finish();
 }

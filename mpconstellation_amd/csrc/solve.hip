@@ -2331,8 +2331,7 @@ extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xb
     if (rc) return rc;
     ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
     ar.download(tf_out, dtfo, S); ar.download(status, dst, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
-    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ar.failed() ? ar.code() : MPCX_OK;
+    return ar.finish();
 }
 
 extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,
@@ -2373,6 +2372,5 @@ extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, co
     if (rc) return rc;
     ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
     ar.download(tf_out, dtfo, S); ar.download(status, dstat, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
-    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ar.failed() ? ar.code() : MPCX_OK;
+    return ar.finish();
 }
