@@ -601,18 +601,15 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             // thrust ball.  Only min(sigma, kStageCap) of a stage barrier weight goes into the Hessian blocks: summed into
             // a 3x3 / 7x7 block a weight of 1e14 (an active constraint at mu = 1e-9) would wipe out the trust-region
             // curvature 2 w_tr of the other directions; the excess reaches the recursion as a rank-1 update (riccati_factor)
-            double Wu[9], sx[SX_N];
-#pragma unroll
-            for (int i = 0; i < SX_N; ++i) sx[i] = 0.0;
+            double Wu[9];
             {
                 const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
                 const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
                 sigmax = fmax(sigmax, sig);
                 const double sin_ = fmin(sig, kStageCap);
-                sx[SX_EU] = sig - sin_;
+                if (h0) { nb[N_SX + SX_EU] = sig - sin_; nb[N_SX + SX_CU] = 2.0 * u[0]; nb[N_SX + SX_CU + 1] = 2.0 * u[1]; nb[N_SX + SX_CU + 2] = 2.0 * u[2]; }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    sx[SX_CU + i] = 2.0 * u[i];
                     gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zh;
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
@@ -637,10 +634,13 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double ex_max = sig_rmax - kStageCap, ex_min = sig - kStageCap;
                 const bool st_max = ex_max > 0.0 && ex_max >= ex_min, st_min = ex_min > 0.0 && !st_max;
                 const double in_max = st_max ? kStageCap : sig_rmax, in_min = st_min ? kStageCap : sig;
-                sx[SX_EX] = st_max ? ex_max : (st_min ? ex_min : 0.0);
+                if (h0) {
+                    nb[N_SX + SX_EX] = st_max ? ex_max : (st_min ? ex_min : 0.0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) nb[N_SX + SX_A + i] = st_max ? 2.0 * x[i] : rbv[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    sx[SX_A + i] = st_max ? 2.0 * x[i] : rbv[i];
                     gx[i] += 2.0 * x[i] * zh_rmax - rbv[i] * zh;
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
@@ -650,8 +650,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             if (h0) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
-#pragma unroll
-                for (int i = 0; i < SX_N; ++i) nb[N_SX + i] = sx[i];
+                if (!inner) { nb[N_SX + SX_EX] = 0.0; nb[N_SX + SX_A] = 0.0; nb[N_SX + SX_A + 1] = 0.0; nb[N_SX + SX_A + 2] = 0.0; }
 #pragma unroll
                 for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
 #pragma unroll
@@ -713,7 +712,10 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             double g6[6];
             const double lvt = sd.linvt ? 0.0 : s.itg[G_LVT];
             double sig[8], zh[8];
-            for (int j = 0; j < sd.nT; ++j) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {               // (static indices: the arrays stay in registers)
+                sig[j] = 0.0; zh[j] = 0.0;
+                if (j >= sd.nT) continue;
                 double gj = -sd.bT[j];
                 for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * x[i];
                 const double sj = s.itg[gs_term(j)], zj = s.itg[gz_term(j)];
@@ -901,6 +903,71 @@ __device__ __forceinline__ ChanIn chan_mask(const ChanRaw &cr, int c, int r, boo
     ci.gx = c0 ? cr.gx : 0.0; ci.gu = (c0 && r < 3) ? cr.gu : 0.0; ci.rho = c0 ? cr.rho : 0.0;
     ci.aff = (act && c <= 1) ? cr.aff : 0.0;
     return ci;
+}
+
+// Stiff stage terms (excess weight ex above kStageCap of the position term, direction a, and of the thrust ball, direction
+// c_u = 2u; newton_blocks left them out of Wx / Wu) enter the recursion as Q += ex c c^T with c = (c_u, c_y) in the
+// (u_k, y_k) coordinates (x_k = y_k + Bpm u_k, so the position term has c_u = Bpm^T a, c_y = a), by Sherman-Morrison on
+// the already inverted Q_uu:  t = Qi c_u, om = 1 / (1/ex + c_u.t), v = c_y - Quy^T t,  Qi -= om t t^T, Kg += om t v^T,
+// P_k += om v v^T  -- the weight enters only through 1/ex, nothing of size ex is ever formed (condensed into the
+// blocks, 1e14 r r^T would leave no digit of the trust-region curvature 2 w_tr in the other directions).  Position term
+// first, thrust ball second (on the once-updated quantities).  Same arithmetic as the oracle's riccati_factor.
+__device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, gf64 *fac, int lane)
+{
+    double Qi[9];
+    (void)inv3_spd(w.Quu, Qi);
+    const double ex_x = o.SX[SX_EX], ex_u = o.SX[SX_EU];
+    double om1 = 0.0, om2 = 0.0, t1[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, tc = 0.0;
+    double ax[3], cu[3], c1[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { ax[l] = o.SX[SX_A + l]; cu[l] = o.SX[SX_CU + l]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c1[j] = o.Bpm[j] * ax[0] + o.Bpm[3 + j] * ax[1] + o.Bpm[6 + j] * ax[2];
+    if (ex_x > 0.0) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t1[l] = Qi[l * 3] * c1[0] + Qi[l * 3 + 1] * c1[1] + Qi[l * 3 + 2] * c1[2];
+        om1 = 1.0 / (1.0 / ex_x + (c1[0] * t1[0] + c1[1] * t1[1] + c1[2] * t1[2]));
+    }
+    if (ex_u > 0.0) {
+        double q2[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) q2[l] = Qi[l * 3] * cu[0] + Qi[l * 3 + 1] * cu[1] + Qi[l * 3 + 2] * cu[2];
+        tc = t1[0] * cu[0] + t1[1] * cu[1] + t1[2] * cu[2];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t2[l] = q2[l] - om1 * tc * t1[l];                  // Qi' c_u with Qi' = Qi - om1 t1 t1^T
+        om2 = 1.0 / (1.0 / ex_u + (cu[0] * t2[0] + cu[1] * t2[1] + cu[2] * t2[2]));
+    }
+    // component j of v1 = a - Quy^T t1 and of v2 = -Kg'^T c_u = -(Quy^T q2) - om1 (t1.c_u) v1, from column j of Quy
+    // (Quy^T q2 = Quy^T (t2 + om1 tc t1))
+    auto sm_v = [&](const double (&qc)[3], int j, double &v1, double &v2) {
+        const double cyj = (j < 3) ? o.SX[SX_A + j] : 0.0;
+        const double qt1 = qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2];
+        v1 = (ex_x > 0.0) ? cyj - qt1 : 0.0;
+        v2 = -(qc[0] * t2[0] + qc[1] * t2[1] + qc[2] * t2[2]) - om1 * tc * qt1 - om1 * tc * v1;
+    };
+    wsync();                                       // every lane has read what it needs of the un-updated values
+    if (lane < 49) {
+        const int mi = lane / 7, mj = lane - 7 * mi;
+        const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
+        double qi[3], qj[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
+        double v1l, v2l, v1h, v2h;
+        sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
+        w.Pn[lane] += om1 * (v1l * v1h) + om2 * (v2l * v2h);
+    }
+    if (lane < 21) {
+        const int r = lane / 7, c = lane - 7 * r;
+        const double qc[3] = {w.Quy[c], w.Quy[7 + c], w.Quy[14 + c]};
+        double v1, v2;
+        sm_v(qc, c, v1, v2);
+        const double kg = o.Kg[lane] + om1 * t1[r] * v1 + om2 * t2[r] * v2;
+        o.Kg[lane] = kg; fac[F_KG + lane] = kg;
+    }
+    if (lane < 9) {
+        const int r = lane / 3, c = lane - 3 * r;
+        fac[F_QI + lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
+    }
 }
 
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
@@ -1129,46 +1196,9 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         wsync();
         FT_MARK(5)
         // P7-P9: every lane inverts the 3x3 itself; P_k = sym(Qyy - Quy^T Qi Quy) straight from its own two columns of
-        // Quy (no exchange of the gain on the way); the gain Kg = Qi Quy goes to LDS / the factor record for the sweeps.
-        // Stiff stage terms (excess weight ex above kStageCap of the position term, direction a, and of the thrust ball,
-        // direction c_u = 2u; newton_blocks left them out of Wx / Wu) come in here as Q += ex c c^T with c = (c_u, c_y)
-        // in the (u_k, y_k) coordinates (x_k = y_k + Bpm u_k, so the position term has c_u = Bpm^T a, c_y = a), by
-        // Sherman-Morrison on the already inverted Q_uu:  t = Qi c_u, om = 1 / (1/ex + c_u.t), v = c_y - Quy^T t,
-        // Qi -= om t t^T, Kg += om t v^T, P_k += om v v^T  -- the weight enters only through 1/ex, nothing of size ex
-        // is ever formed (condensed into the blocks, 1e14 r r^T would leave no digit of the curvature 2 w_tr).
+        // Quy (no exchange of the gain on the way); the gain Kg = Qi Quy goes to LDS / the factor record for the sweeps
         double Qi[9];
         if (!inv3_spd(w.Quu, Qi)) good = false;
-        const double ex_x = o.SX[SX_EX], ex_u = o.SX[SX_EU];
-        double om1 = 0.0, om2 = 0.0, t1[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, tc = 0.0;
-        const bool stiff = (ex_x > 0.0) || (ex_u > 0.0);            // wave-uniform (same LDS words in every lane)
-        if (stiff) {
-            double ax[3], cu[3], c1[3];
-#pragma unroll
-            for (int l = 0; l < 3; ++l) { ax[l] = o.SX[SX_A + l]; cu[l] = o.SX[SX_CU + l]; }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c1[j] = o.Bpm[j] * ax[0] + o.Bpm[3 + j] * ax[1] + o.Bpm[6 + j] * ax[2];
-            if (ex_x > 0.0) {
-#pragma unroll
-                for (int l = 0; l < 3; ++l) t1[l] = Qi[l * 3] * c1[0] + Qi[l * 3 + 1] * c1[1] + Qi[l * 3 + 2] * c1[2];
-                om1 = 1.0 / (1.0 / ex_x + (c1[0] * t1[0] + c1[1] * t1[1] + c1[2] * t1[2]));
-            }
-            if (ex_u > 0.0) {
-                double q2[3];
-#pragma unroll
-                for (int l = 0; l < 3; ++l) q2[l] = Qi[l * 3] * cu[0] + Qi[l * 3 + 1] * cu[1] + Qi[l * 3 + 2] * cu[2];
-                tc = t1[0] * cu[0] + t1[1] * cu[1] + t1[2] * cu[2];
-#pragma unroll
-                for (int l = 0; l < 3; ++l) t2[l] = q2[l] - om1 * tc * t1[l];                  // Qi' c_u with Qi' = Qi - om1 t1 t1^T
-                om2 = 1.0 / (1.0 / ex_u + (cu[0] * t2[0] + cu[1] * t2[1] + cu[2] * t2[2]));
-            }
-        }
-        // component j of v1 = a - Quy^T t1 and of v2 = -Kg'^T c_u = -(Quy^T q2) - om1 (t1.c_u) v1, from column j of Quy
-        auto sm_v = [&](const double (&qc)[3], int j, double &v1, double &v2) {
-            const double cyj = (j < 3) ? o.SX[SX_A + j] : 0.0;
-            v1 = cyj - (qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2]);
-            // Quy^T q2 = Quy^T (t2 + om1 tc t1)
-            v2 = -(qc[0] * t2[0] + qc[1] * t2[1] + qc[2] * t2[2]) - om1 * tc * (qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2]) - om1 * tc * v1;
-        };
         if (lane < 49) {
             const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
             double qi[3], qj[3];
@@ -1183,28 +1213,17 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
                 const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];     // Kg(l, hi)
                 a1 -= qi[l] * kj;
             }
-            if (stiff) {
-                double v1l, v2l, v1h, v2h;
-                sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
-                a1 += om1 * (v1l * v1h) + om2 * (v2l * v2h);
-            }
             w.Pn[lane] = a1;
         }
         if (lane < 21) {
             const int r = lane / 7, c = lane - 7 * r;
-            const double qc[3] = {w.Quy[c], w.Quy[7 + c], w.Quy[14 + c]};
-            double kg = Qi[r * 3] * qc[0] + Qi[r * 3 + 1] * qc[1] + Qi[r * 3 + 2] * qc[2];
-            if (stiff) {
-                double v1, v2;
-                sm_v(qc, c, v1, v2);
-                kg += om1 * t1[r] * v1 + om2 * t2[r] * v2;
-            }
+            const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
             o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.F[(lane / 3) * FS + 7 + lane % 3];
         }
-        if (lane < 9) {
-            const int r = lane / 3, c = lane - 3 * r;
-            fac[F_QI + lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
-        }
+        if (lane < 9) fac[F_QI + lane] = Qi[lane];
+        // stiff stage terms (rare: an active r_min plane / radius or thrust ball late in the iteration): rank-1 update of
+        // what was just written; out of line so that the common path keeps its register allocation
+        if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) stiff_stage_update(o, w, fac, lane);
         FT_MARK(6)
         FT_MARK(7)
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
