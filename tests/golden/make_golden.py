@@ -269,9 +269,37 @@ def gen_propagation_cases():
     save("propagate.npz", **out)
 
 
+def gen_csv_case():
+    """The trajectory CSV the reference writes (Simulator.save_to_csv, simulator.py:192-201, read by visualizer.m:23-28):
+    file name pattern, the file's text and the run that produced it."""
+    import glob
+    import tempfile
+    sat = Satellite(R_HUBBLE, V_HUBBLE, M_HUBBLE)
+    scale = SatelliteScale(sat=sat)
+    ctrl = ConstantThrustController([sat], np.array([0.1, 0.0, 0.05]))
+    sim = Simulator(sats=[sat], controller=ctrl, scale=scale, base_res=12)      # truth model: drag and J2 on (defaults)
+    sim.run(tf=1)
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd(); os.chdir(tmp)
+        try:
+            sim.save_to_csv(suffix="_ref")
+            files = glob.glob("trajectory_*_ref.csv")
+            assert len(files) == 1
+            text = open(files[0], "rb").read()
+            name = files[0].replace(str(sat.id), "<id>")
+        finally:
+            os.chdir(cwd)
+    save("csv_reference.npz", text=np.frombuffer(text, dtype=np.uint8), file_pattern=np.array(name), x=sim.sim_data[sat.id],
+         thrust=np.array([0.1, 0.0, 0.05]), base_res=np.int64(12), tf=np.float64(1.0))
+
+
 if __name__ == "__main__":
     os.chdir("/tmp")  # reference code may write files into the CWD
+    if len(sys.argv) > 1 and sys.argv[1] == "csv":
+        gen_csv_case()
+        raise SystemExit(0)
     gen_constants_and_pointwise()
     gen_discretize_cases()
     gen_constellation_cases()
     gen_propagation_cases()
+    gen_csv_case()

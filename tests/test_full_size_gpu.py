@@ -142,3 +142,68 @@ def test_rejected_arguments(golden_dir):
         mpc_step_batch(np.zeros((1, 6, 5)), np.zeros((1, 3, 5)), [1.0], np.zeros((1, 8)), [1.0])
     with pytest.raises((MpcxError, ValueError)):         # empty batch
         mpc_step_batch(np.zeros((0, 7, 5)), np.zeros((0, 3, 5)), np.zeros(0), np.zeros((0, 8)), np.zeros(0))
+
+
+def test_config3_full_size_scp_loop():
+    """BASELINE configs[3] at full size through the bench harness's device-resident path: 4096 satellites, K = 100,
+    two SCP iterations with the nonlinear re-rollout under the optimised sequence between them (control.py:166,183-227;
+    the benchmark re-samples the rollout at K nodes, bench.py).  Properties over all satellites after the second
+    iteration, and three satellites against the same chain built from the CPU oracle."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import torch
+    import bench
+    run = bench.Runner("S4096_K100_scp2", 0, 1, 0)
+    run.step()
+    torch.cuda.synchronize()
+    status, iters, kkt = run.solver_stats()
+    S, K = run.S, run.K
+    assert (status == 0).all() and kkt.max() <= 1e-8 and iters.max() <= 40
+    X = run.d_X.cpu().numpy(); U = run.d_U.cpu().numpy(); NU = run.d_NU.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
+    assert (run.d_pst.cpu().numpy() == 0).all()                                              # the re-rollouts succeeded
+    h = run.host
+    assert np.abs(X[:, :, 0] - h["xbar"][:, :, 0]).max() == 0.0
+    assert np.linalg.norm(U, axis=1).max() <= 5 + 1e-6 and (np.abs(NU) <= 1e-6).all()
+    rn = np.linalg.norm(X[:, :3, :], axis=1)
+    assert np.abs(rn[:, -1] - h["r_des"]).max() <= 0.01 + 1e-6
+    assert (tfo > 0).all() and (tfo <= 5 + 1e-6).all()
+    hK = np.cross(X[:, :3, -1], X[:, 3:6, -1])
+    assert np.abs(np.linalg.norm(hK, axis=1) / rn[:, -1] - np.sqrt(h["consts"][:, 0] / h["r_des"])).max() < 1e-7
+    # the second iteration's reference is the rollout under the first one's plan: shorter flight time than the first guess
+    assert (tfo < 1.0).all()
+    for s in (0, 1777, 4095):
+        x, u, tf = h["xbar"][s], h["ubar"][s], 1.0
+        cst = h["consts"][s]
+        for it in range(2):
+            d = O.discretize(x, u, tf, cst)
+            P = N.MpcProblem(x, u, tf, cst[0], d, O.constraint_terms(x, u, cst[0]), {"r_des": float(h["r_des"][s])})
+            r = N.solve(P)
+            assert r["status"] == 0
+            if it == 0:
+                ctrl = O.make_ctrl(3, useq=np.ascontiguousarray(r["U"]), end_tau=1.0)
+                x = O.propagate(h["xbar"][s][:, 0], r["tf"], cst, ctrl, K)[0]; u = r["U"]; tf = r["tf"]
+        assert np.abs(X[s] - r["X"]).max() < 5e-6 and abs(tfo[s] - r["tf"]) < 5e-6
+
+
+def test_config4_per_gpu_share():
+    """BASELINE configs[4]: 65 536 satellites over 8 GPUs = 8192 per GPU.  Rank 3's block through the bench harness: every
+    problem converges, and a satellite's result is bit for bit what it is when its generator index is solved in another
+    batch (no cross-satellite state: the shards need no exchange)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import torch
+    import bench
+    from mpconstellation_amd import mpc_step_batch
+    from mpconstellation_amd.sharding import shard_block
+    rank, world = 3, 8
+    run = bench.Runner("S8192_K30", rank, world, 0)
+    run.step()
+    torch.cuda.synchronize()
+    status, iters, kkt = run.solver_stats()
+    assert run.S == 8192 and (status == 0).all() and kkt.max() <= 1e-8 and iters.mean() <= 13
+    first, count = shard_block(65536, world, rank)
+    assert (first, count) == (3 * 8192, 8192)
+    X = run.d_X.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
+    pick = np.array([0, 1, 4097, 8191])
+    xb, ub, cs, rd = workload(65536, 30, first=first, count=count)            # the same generator indices, rebuilt
+    assert np.array_equal(xb, run.host["xbar"])
+    res = mpc_step_batch(xb[pick], ub[pick], np.ones(len(pick)), cs[pick], rd[pick])
+    assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])

@@ -48,6 +48,89 @@ def test_run_batched_and_csv(tmp_path, monkeypatch):
     assert np.allclose(np.loadtxt(ids[0], delimiter=","), scale.redim_state(data[sats[1].id]).T)
 
 
+def test_csv_matches_the_reference_written_file(golden_dir, tmp_path, monkeypatch):
+    """tests/golden/csv_reference.npz holds the text of the file the reference's Simulator.save_to_csv wrote for a
+    12-node constant-thrust run under the truth model (drag + J2) and the run itself: same rollout, same file name
+    pattern, same text format (np.savetxt '%.18e', ',' separated, T rows x 7 columns, redimensionalised), same values."""
+    import glob, re, os
+    from mpconstellation_amd import Satellite, SatelliteScale, Simulator, ConstantThrustController
+    g = np.load(os.path.join(golden_dir, "csv_reference.npz"))
+    sat = Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+    scale = SatelliteScale(sat=sat)
+    sim = Simulator(sats=[sat], controller=ConstantThrustController([sat], g["thrust"]), scale=scale, base_res=int(g["base_res"]))
+    sim.run(tf=float(g["tf"]))
+    assert np.abs(sim.sim_data[sat.id] - g["x"]).max() < 1e-10          # device rollout = reference rollout (truth model)
+    monkeypatch.chdir(tmp_path)
+    sim.save_to_csv(suffix="_ref")
+    files = glob.glob("trajectory_*_ref.csv")
+    assert len(files) == 1
+    stamp = r"\d{4}-\d{2}-\d{2}-\d{2}-\d{2}-\d{2}"
+    ref_name = str(g["file_pattern"])                                   # trajectory_<date>_<id>_ref.csv
+    assert re.fullmatch("trajectory_" + stamp + "_<id>_ref\\.csv", ref_name)
+    assert re.fullmatch("trajectory_" + stamp + "_" + re.escape(str(sat.id)) + "_ref\\.csv", files[0])
+    ours = open(files[0], "rb").read().decode().splitlines(); ref = bytes(g["text"]).decode().splitlines()
+    assert len(ours) == len(ref) == 12
+    num = r"-?\d\.\d{18}e[+-]\d{2}"
+    for a, b in zip(ours, ref):
+        assert re.fullmatch(",".join([num] * 7), a) and re.fullmatch(",".join([num] * 7), b)
+        va = np.array(a.split(","), dtype=float); vb = np.array(b.split(","), dtype=float)
+        assert np.abs(va - vb).max() <= 1e-9 * np.abs(vb).max()
+    assert ours[0] == ref[0]                                            # the initial state: identical text
+
+
+def oracle_scp_chain(y0, cst, base_res, horizon, r_des, n_iter=2):
+    """OptimalController.update (control.py:166-235) assembled from the CPU oracle's pieces"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import oracle_lib as O, nlp_ipm as N
+    K = int(base_res * horizon)
+    ctrl = O.make_ctrl(2, thrust=(0.5, 0.0, 0.0))
+    x = O.propagate(y0, horizon, cst, ctrl, K)[0]; t = np.linspace(0, 1, K)
+    tf_u = horizon; r = None
+    for i in range(n_iter):
+        u_bar = O.extract_uk(x, t, ctrl)
+        d = O.discretize(x, u_bar, tf_u, cst)
+        P = N.MpcProblem(x, u_bar, tf_u, cst[0], d, O.constraint_terms(x, u_bar, cst[0]),
+                         {"r_des": r_des, "eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": horizon})
+        r = N.solve(P)
+        assert r["status"] == 0
+        tf_u = r["tf"]
+        ctrl = O.make_ctrl(3, useq=np.ascontiguousarray(r["U"]), end_tau=1.0)
+        Kn = int(base_res * tf_u)
+        x = O.propagate(y0, tf_u, cst, ctrl, Kn)[0]; t = np.linspace(0, 1, Kn)
+    return r
+
+
+def test_reference_test_mpc_configuration():
+    """The reference's own test_mpc (test_simulator.py:79-98) as written: base_res 30, tf_horizon 2, two segments, the
+    default r_des = 1.5 (control.py:147), eps_vr = 1e-16, truth model with drag and J2 at base_res 100.  Every solve of
+    both segments (K = 60, then int(30 tf_u), then K = 30 ...) ends with status 0, and the first plan equals the
+    oracle chain's."""
+    from mpconstellation_amd import Satellite, SatelliteScale, Simulator, OptimalController
+    sat = Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+    scale = SatelliteScale(sat=sat)
+    y0 = scale.normalize_state(sat.get_state_vector()); cst = scale.get_normalized_constants().as_vector()
+    tf, nseg = 2, 2
+    c = OptimalController(sats=[sat], base_res=30, tf_horizon=tf, tf_interval=tf / nseg, plot_inter=False, opt_verbose=False)
+    assert c.r_des == 1.5
+    c.update()
+    assert c.last_status == [0, 0]
+    r = oracle_scp_chain(y0, cst, 30, 2, 1.5)
+    assert c.opt_trajectory.shape == r["X"].shape and np.abs(c.opt_trajectory - r["X"]).max() < 5e-6
+    c.horizon = tf                                            # (update() shrank it; run_segments starts over like the test)
+    sim = Simulator(sats=[sat], controller=c, scale=scale, base_res=100, verbose=False)
+    statuses = []
+    orig = c.update
+    def update():
+        orig(); statuses.extend(c.last_status)
+    c.update = update
+    sim.run_segments(tf=tf, num_segments=nseg)
+    assert statuses == [0, 0, 0, 0]
+    x_act = sim.sim_data[sat.id]
+    assert x_act.shape == (7, 200) and np.isfinite(x_act).all() and c.horizon == 1.0
+    assert np.linalg.norm(x_act[:3, -1]) > 1.05              # the orbit was raised under the truth model
+
+
 def test_scp_update_vs_oracle_chain():
     """OptimalController.update (control.py:166-235: reference rollout, then 2 x (extract_uk, discretize, solve, nonlinear
     re-rollout under the optimised FOH sequence)) on the device against the same chain built from the CPU oracle's
@@ -117,3 +200,21 @@ def test_constellation_mpc_equals_single_satellite_loops():
         assert np.abs(mpc.plan_x[sats.index(sat)] - plan).max() < 5e-5
         assert np.abs(sat.get_state_vector() / state - 1).max() < 5e-5
     assert mpc.horizon == 1.0
+
+
+def test_constellation_mpc_plan_vs_oracle_chain():
+    """ConstellationMPC.update for satellites with different scales against the oracle chain of each (not against
+    this repo's own single-satellite loop): the plan after both SCP iterations."""
+    from mpconstellation_amd import Satellite, SatelliteScale, ConstellationMPC
+    from mpconstellation_amd.constellation import constellation_states
+    st = constellation_states(4096)[[5, 977, 3010]]
+    sats = [Satellite(s[:3], s[3:6], s[6]) for s in st]
+    mpc = ConstellationMPC(sats, base_res=15, tf_horizon=2, tf_interval=1, r_des=1.2, sim_base_res=40)
+    mpc.update()
+    assert (mpc.last_status == 0).all()
+    for i, sat in enumerate(sats):
+        sc = SatelliteScale(sat=sat)
+        r = oracle_scp_chain(sc.normalize_state(sat.get_state_vector()), sc.get_normalized_constants().as_vector(), 15, 2, 1.2)
+        assert mpc.plan_x[i].shape == r["X"].shape
+        assert np.abs(mpc.plan_x[i] - r["X"]).max() < 5e-6 and np.abs(mpc.plan_u[i] - r["U"]).max() < 5e-5
+        assert abs(mpc.plan_tf[i] - r["tf"]) < 5e-6
