@@ -115,6 +115,15 @@ typedef struct {
  * equality :492-517 it enables at :577.  Every constraint is then linear or convex quadratic and the objective strictly
  * convex in (x, u, tf): the minimiser is unique -- the variant the parity tests use to compare solvers exactly. */
 #define MPCX_SOLVE_LINEAR_VT 2
+/* The final time is not a variable: satellite s is solved with tf held at the value found in tf_out[s] ON ENTRY (its
+ * range constraint optimizer.py:588 and its stationarity row drop out; the trust-region term w_tr (tf - tf_bar)^2 stays in
+ * the objective as a constant).  ON EXIT tf_out[s] holds the satellite's term of the tf stationarity row,
+ * g_s = 2 w_tr (tf - tf_bar) - sum_k Sigma_k . lambda_k = dV_s/dtf of its optimal value.  This is the inner problem of the
+ * shared-tf mode: several satellites in one reference Optimizer share ONE tf (optimizer.py:287,311,322,336), and that NLP
+ * separates given tf -- its KKT conditions are every inner problem's plus 1 + sum_s g_s(tf) = 0 (or tf on its bound),
+ * a scalar equation the host solves (mpconstellation_amd/optimizer.py: Optimizer with shared tf).  Host-pointer entry
+ * points read tf_out as an input too in this mode. */
+#define MPCX_SOLVE_FIXED_TF 4
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 size_t mpcx_solve_workspace_bytes(int S, int K);

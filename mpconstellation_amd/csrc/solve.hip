@@ -58,6 +58,7 @@ constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGa
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, eps_vt, tf_max, w_nu, w_tr, tol, acc_tol;
     int max_iter, acc_iter, n_refine, linvt;    // linvt: the linearised tangential pair (optimizer.py:471-489) instead of the quartic
+    int fixed_tf, pad;                          // fixed_tf: tf is held at the value passed in tf_out (MPCX_SOLVE_FIXED_TF)
 };
 
 struct SolveArgs {
@@ -85,6 +86,7 @@ __host__ __device__ inline size_t ws_doubles(int K)
 struct SatData {
     double aT[8][7], bT[8];
     int nT, linvt;           // terminal inequality rows (6, or 8 with the linearised tangential pair); convex variant flag
+    int fixed_tf;            // tf is a constant of the problem: no range constraint, no stationarity row, dtf = 0
     double w_vt, gh_vt, zeta_vt;   // convex variant: weight, gradient coefficient and border unknown of the tangential pair
     double b_u, b_rmax, b_rmin, b_rfmax, b_tf[2], vt_des, w_tr, w_nu, tfbar;
     // Newton-step globals
@@ -213,7 +215,7 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
     double gRbar = 0.0, gNbar = 0.0;
     for (int i = 0; i < 6; ++i) { gRbar += gR[i] * xK[i]; gNbar += gN[i] * xK[i]; }
     for (int i = 0; i < 8; ++i) { sd.bT[i] = 0.0; for (int j = 0; j < 7; ++j) sd.aT[i][j] = 0.0; }
-    sd.linvt = o.linvt; sd.nT = o.linvt ? 8 : 6;
+    sd.linvt = o.linvt; sd.nT = o.linvt ? 8 : 6; sd.fixed_tf = o.fixed_tf;
     sd.w_vt = 0.0; sd.gh_vt = 0.0; sd.zeta_vt = 0.0;
     for (int j = 0; j < 3; ++j) sd.aT[0][j] = -rh[j];
     sd.bT[0] = relax(-(r_des - o.eps_r));
@@ -325,6 +327,7 @@ __device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64
 
 struct ResAcc {   // accumulators of one residual evaluation
     double dual_max, prim_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
+    double g_tf;      // the satellite's term of the tf stationarity row, 2 w_tr (tf - tf_bar) - sum_k Sigma_k . lam_k
 };
 
 // The node-parallel phases are written as chunks "loads -> arithmetic (-> stores)" separated by scheduling
@@ -525,7 +528,10 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     }
     // tf stationarity and range constraints (lane 0 adds them after the reduction of gtf_part)
     double gtf = wave_sum(gtf_part);
-    if (lane == 0) {
+    out.g_tf = gtf + 2.0 * sd.w_tr * (tf - sd.tfbar);
+    if (lane == 0 && sd.fixed_tf) {
+        if (WRITE) s.itgB[G_TF] = tf;
+    } else if (lane == 0) {
         double s0 = s.itg[G_STF] + a * s.drg[G_STF], s1 = s.itg[G_STF + 1] + a * s.drg[G_STF + 1];
         double z0 = s.itg[G_ZTF] + a * s.drg[G_ZTF], z1 = s.itg[G_ZTF + 1] + a * s.drg[G_ZTF + 1];
         if (WRITE) {
@@ -550,13 +556,13 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     if (WRITE) __syncthreads();            // the candidate iterate is complete before anybody reads it
 }
 
-__device__ __forceinline__ int n_ineq(int K, int nT) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + 2; }
+__device__ __forceinline__ int n_ineq(int K, int nT, int fixed_tf) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + (fixed_tf ? 0 : 2); }
 
 // ipopt's scaled optimality error E_mu from one residual evaluation: max_i |s_i z_i - mu| = max(pmax - mu, mu - pmin)
-__device__ double scaled_error(const ResAcc &r, int K, int nT, double mu)
+__device__ double scaled_error(const ResAcc &r, int K, int nT, int fixed_tf, double mu)
 {
     const double smax = 100.0;
-    const int nz = n_ineq(K, nT), nl = 7 * (K - 1) + (nT == 6 ? 1 : 0);     // (the convex variant has no tangential equality)
+    const int nz = n_ineq(K, nT, fixed_tf), nl = 7 * (K - 1) + (nT == 6 ? 1 : 0);     // (the convex variant has no tangential equality)
     const double sdl = fmax(smax, (r.zsum + r.lsum) / (double)(nz + nl)) / smax;
     const double sc = fmax(smax, r.zsum / (double)nz) / smax;
     const double comp = fmax(r.prod_max - mu, mu - r.prod_min);
@@ -774,7 +780,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         sd.WxKsoft[lane] = soft; sd.WxK[lane] = full;
         s.nb[(size_t)(K - 1) * NB_N + N_WX + lane] = full;
     }
-    if (lane == 0) {
+    if (lane == 0 && sd.fixed_tf) { sd.Wtf = 1.0; sd.gtf = 0.0; sd.sigmax = sigmax; }
+    else if (lane == 0) {
         const double tf = s.itg[G_TF];
         double W = 2.0 * sd.w_tr + delta_w, g = 1.0 + 2.0 * sd.w_tr * (tf - sd.tfbar);
         const double gv[2] = {-tf - sd.b_tf[0], tf - sd.b_tf[1]};
@@ -1495,6 +1502,7 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
 #pragma unroll
             for (int l = 0; l < 7; ++l) v += a[l] * sd.xK[c][l];
         } else v = (q == NBD - 1 ? sd.Wtf : 0.0) - sd.siglam[c];
+        if (sd.fixed_tf && (p == NBD - 1 || q == NBD - 1)) v = (p == q) ? 1.0 : 0.0;      // dtf = 0: out of the border
         sd.Mb[p][q] = v; sd.Sb[p][q] = v;    // Sb keeps the matrix for the refinement step of border_solve
     }
     __syncthreads();
@@ -1564,7 +1572,7 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
         if (p >= 1) rb[p] = (iw[p] > 0.0) ? rb[p] - gex[p - 1] * iw[p] : 0.0;
         else if (!eqr[0] && !(iw[0] > 0.0)) rb[0] = 0.0;       // convex variant, pair without excess weight: decoupled
     }
-    rb[NBD - 1] = -gtf_rhs + sd.siglam[0];
+    rb[NBD - 1] = sd.fixed_tf ? 0.0 : -gtf_rhs + sd.siglam[0];
     auto ldl_solve = [&](double (&v)[NBD]) {
 #pragma unroll
         for (int p = 0; p < NBD; ++p)
@@ -1900,7 +1908,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
             LIM(srf, s.drg[G_SRF]); LIM(zrf, s.drg[G_ZRF]);
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && !sd.fixed_tf) {
         const double tf = s.itg[G_TF], dtf = s.drg[G_TF];
         const double gv[2] = {-tf - sd.b_tf[0], tf - sd.b_tf[1]}, dgv[2] = {-dtf, dtf};
         for (int j = 0; j < 2; ++j) {
@@ -2041,7 +2049,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         }
         const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
         s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = kMuInit / s.itg[G_SRF];
-        const double tf = sd.tfbar;
+        const double tf = sd.fixed_tf ? a.tf_out[sat] : sd.tfbar;      // (fixed: the value to hold comes in through tf_out)
         s.itg[G_TF] = tf;
         s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = kMuInit / s.itg[G_STF];
         s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = kMuInit / s.itg[G_STF + 1];
@@ -2049,7 +2057,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     __syncthreads();
 
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
-    const int nzc = n_ineq(K, sd.nT);
+    const int nzc = n_ineq(K, sd.nT, sd.fixed_tf);
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
     double E0 = 0.0;
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
@@ -2060,7 +2068,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     PT_END(0)
     for (int iter = 0;; ++iter) {
         it_count = iter;
-        E0 = scaled_error(r0, K, sd.nT, 0.0);
+        E0 = scaled_error(r0, K, sd.nT, sd.fixed_tf, 0.0);
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
         n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
@@ -2214,7 +2222,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
 #endif
     }
     if (lane == 0) {
-        a.tf_out[sat] = s.itg[G_TF];
+        a.tf_out[sat] = sd.fixed_tf ? r0.g_tf : s.itg[G_TF];
         a.status[sat] = status;
         a.iters[sat] = it_count;
         a.kkt[sat] = E0;
@@ -2238,6 +2246,7 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
     d.eps_vr = o->eps_vr; d.eps_vn = o->eps_vn; d.eps_vt = o->eps_vt; d.tf_max = o->tf_max; d.w_nu = o->w_nu; d.w_tr = o->w_tr;
     d.tol = o->tol; d.acc_tol = o->acceptable_tol; d.max_iter = o->max_iter; d.acc_iter = o->acceptable_iter;
     d.n_refine = o->n_refine; d.linvt = (o->flags & MPCX_SOLVE_LINEAR_VT) ? 1 : 0;
+    d.fixed_tf = (o->flags & MPCX_SOLVE_FIXED_TF) ? 1 : 0; d.pad = 0;
     return d;
 }
 
@@ -2342,7 +2351,8 @@ extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xb
     double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
     double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
     double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K);
-    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = ar.alloc<double>(S), *dk = ar.alloc<double>(S);
+    const bool fixed_tf = (opts->flags & MPCX_SOLVE_FIXED_TF) != 0;          // tf_out is an input too (include/mpcx.h)
+    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = fixed_tf ? ar.upload(tf_out, S) : ar.alloc<double>(S), *dk = ar.alloc<double>(S);
     int32_t *dst = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S);
     if (ar.failed()) return ar.code();
     int rc = mpcx_mpc_step_batch_dev(ctx, S, K, dx, du, dtf, dc, drd, flags, max_step, opts, dX, dU, dNU, dtfo, dst,
@@ -2383,7 +2393,8 @@ extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, co
     double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
     double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
     double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K);
-    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = ar.alloc<double>(S), *dk = ar.alloc<double>(S);
+    const bool fixed_tf = (opts->flags & MPCX_SOLVE_FIXED_TF) != 0;          // tf_out is an input too (include/mpcx.h)
+    double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = fixed_tf ? ar.upload(tf_out, S) : ar.alloc<double>(S), *dk = ar.alloc<double>(S);
     int32_t *dstat = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S);
     if (ar.failed()) return ar.code();
     int rc = mpcx_solve_batch_dev(ctx, S, K, dst_, dx, du, dtf, dc, drd, opts, dX, dU, dNU, dtfo, dstat, dit, dk, ws,

@@ -12,24 +12,36 @@ DEFAULT_OPTIONS = {'min_mass': 0.1, 'u_lim': [0, 5], 'r_lim': [0.99, 5], 'r_des'
 class SolveResult:
     """What the reference keeps in self.model (a pyomo object) reduced to what its callers read."""
 
-    def __init__(self, X, U, NU, tf, status, iters, kkt):
+    def __init__(self, X, U, NU, tf, status, iters, kkt, g_tf=None):
         self.X, self.U, self.NU, self.tf, self.status, self.iters, self.kkt = X, U, NU, tf, status, iters, kkt
+        self.g_tf = g_tf          # fixed-tf solves only: each satellite's term of the tf stationarity row (include/mpcx.h)
 
 
-def _solver_flags(solver, linear_vt):
+def _solver_flags(solver, linear_vt, fixed_tf=None):
     """linear_vt: the linearised tangential pair the reference keeps commented out (optimizer.py:471-489, 575-576;
-    tolerance options['eps_vt']) instead of the exact equality it enables (:577) -- MPCX_SOLVE_LINEAR_VT."""
+    tolerance options['eps_vt']) instead of the exact equality it enables (:577) -- MPCX_SOLVE_LINEAR_VT.
+    fixed_tf: hold every satellite's final time at the given value(s) -- MPCX_SOLVE_FIXED_TF."""
     solver = dict(solver)
     if linear_vt:
         solver["flags"] = int(solver.get("flags", 0)) | _ffi.SOLVE_LINEAR_VT
+    if fixed_tf is not None:
+        solver["flags"] = int(solver.get("flags", 0)) | _ffi.SOLVE_FIXED_TF
     return solver
 
 
+def _tf_io(S, fixed_tf):
+    """tf_out buffer: plain output, or (fixed-tf mode) the values to hold on entry and g_s on exit"""
+    if fixed_tf is None:
+        return np.empty(S), None
+    held = _ffi.as_f64(np.broadcast_to(np.asarray(fixed_tf, dtype=np.float64), (S,))).copy()
+    return held.copy(), held
+
+
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, **solver):
+                   linear_vt=False, fixed_tf=None, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays."""
-    solver = _solver_flags(solver, linear_vt)
+    solver = _solver_flags(solver, linear_vt, fixed_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     if xbar.shape[1] != 7 or ubar.shape != (S, 3, K):
@@ -38,7 +50,8 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
     consts = _ffi.as_f64(consts)
     opts = _ffi.make_solve_opts(options, **solver)
-    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); tfo = np.empty(S); kkt = np.empty(S)
+    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); kkt = np.empty(S)
+    tfo, held = _tf_io(S, fixed_tf)
     status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
@@ -47,12 +60,13 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
                                  _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
                                  _ffi.iptr(iters), _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
-    return SolveResult(X, U, NU, tfo, status, iters, kkt)
+    return SolveResult(X, U, NU, tfo, status, iters, kkt) if held is None else SolveResult(X, U, NU, held, status, iters, kkt, tfo)
 
 
-def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, **solver):
+def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, fixed_tf=None,
+                **solver):
     """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""
-    solver = _solver_flags(solver, linear_vt)
+    solver = _solver_flags(solver, linear_vt, fixed_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     arrs = [_ffi.as_f64(a) for a in (A, Bp, Bn, Sigma, xi)]
@@ -60,7 +74,8 @@ def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=Non
     r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
     consts = _ffi.as_f64(consts)
     opts = _ffi.make_solve_opts(options, **solver)
-    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); tfo = np.empty(S); kkt = np.empty(S)
+    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); kkt = np.empty(S)
+    tfo, held = _tf_io(S, fixed_tf)
     status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
     lib = _ffi.load(); ctx = _ffi.context(device)
     import ctypes as C
@@ -69,23 +84,81 @@ def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=Non
                               _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status), _ffi.iptr(iters),
                               _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_solve_batch")
-    return SolveResult(X, U, NU, tfo, status, iters, kkt)
+    return SolveResult(X, U, NU, tfo, status, iters, kkt) if held is None else SolveResult(X, U, NU, held, status, iters, kkt, tfo)
+
+
+def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
+    """Root of the tf stationarity row G(tf) = 1 + sum_s g_s(tf) on (0, tf_max] (G increasing), or tf_max when
+    G(tf_max) <= 0 (range constraint optimizer.py:588 active).  From the reference final time towards the root with doubling
+    steps until the sign changes, then a bracketing secant (Illinois); every G is one batched device solve at fixed tf."""
+    ev = []
+
+    def g(t):
+        v = G(t); ev.append((t, v)); return v
+    a = min(tf0, tf_max); ga = g(a)
+    if abs(ga) <= gtol or (a == tf_max and ga <= 0.0): return a, ev
+    h = 0.05 * a
+    while True:
+        b = a - h if ga > 0.0 else a + h
+        b = min(max(b, 0.05 * a), tf_max)
+        gb = g(b)
+        if abs(gb) <= gtol: return b, ev
+        if (ga > 0.0) != (gb > 0.0): break
+        if b == tf_max and gb <= 0.0: return tf_max, ev
+        a, ga = b, gb; h *= 2.0
+        if len(ev) > 40: return b, ev
+    lo, glo, hi, ghi = (a, ga, b, gb) if ga < 0.0 else (b, gb, a, ga)
+    side = 0; t = 0.5 * (lo + hi)
+    for _ in range(40):
+        if hi - lo <= xtol: break
+        t = (lo * ghi - hi * glo) / (ghi - glo)
+        gt = g(t)
+        if abs(gt) <= gtol: return t, ev
+        if gt > 0.0:
+            hi, ghi = t, gt
+            if side == 1: glo *= 0.5
+            side = 1
+        else:
+            lo, glo = t, gt
+            if side == -1: ghi *= 0.5
+            side = -1
+    return t, ev
+
+
+def solve_shared_tf(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, **solver):
+    """S satellites that share ONE final time, as in a reference Optimizer holding several satellites
+    (optimizer.py:287,311,322,336).  Given tf the NLP separates into the S per-satellite problems the device solves in one
+    batch (MPCX_SOLVE_FIXED_TF); what remains is the scalar row 1 + sum_s g_s(tf) = 0 (or tf on its bound), solved here.
+    Returns (SolveResult of the final inner solve, list of (tf, G(tf)) evaluations)."""
+    opts = {**DEFAULT_OPTIONS, **(options or {})}
+    S = np.asarray(xbar).shape[0]
+
+    def inner(t):
+        return solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options, device, linear_vt,
+                           fixed_tf=np.full(S, float(t)), **solver)
+
+    def G(t):
+        r = inner(t)
+        if not np.isin(r.status, (0, 7)).all():
+            raise _ffi.MpcxError(f"shared-tf inner solve at tf = {t}: status {r.status.tolist()}")
+        return 1.0 + float(np.sum(r.g_tf))
+    tfs, ev = shared_tf_root(G, float(opts["tf_max"]), float(np.asarray(tf).reshape(-1)[0]))
+    return inner(tfs), ev
 
 
 class Optimizer:
     def __init__(self, x_bar, u_bar, nu_bar, tf, d, f, scale, verbose=True, shared_tf=None):
         """Same arguments as the reference (optimizer.py:13-39).  With more than one satellite the
-        reference couples all of them through a single tf variable (:287); that mode is not implemented:
-        pass shared_tf=False to solve the satellites as independent problems (own tf each)."""
+        reference couples all of them through a single tf variable (:287): that is the default here too
+        (solve_shared_tf: batched device solves at fixed tf inside a scalar root search on the host);
+        pass shared_tf=False to solve the satellites as independent problems (own tf each, one device call)."""
         self.x_bar, self.u_bar, self.nu_bar = x_bar, u_bar, nu_bar
         self.tf, self.d, self.f, self.scale = tf, d, f, scale
         self.const = scale.get_normalized_constants()
         self._N = len(x_bar)
         self._K = x_bar[0].shape[1]
         self.verbose = verbose
-        if self._N > 1 and shared_tf is not False:
-            raise NotImplementedError("one tf shared by several satellites (optimizer.py:287) is not implemented; "
-                                      "pass shared_tf=False for independent per-satellite problems")
+        self.shared_tf = (self._N > 1) if shared_tf is None else bool(shared_tf)
         self.result = None
 
     @staticmethod
@@ -144,9 +217,16 @@ class Optimizer:
         xbar = np.stack([np.asarray(x, dtype=np.float64) for x in self.x_bar])
         ubar = np.stack([np.asarray(u, dtype=np.float64) for u in self.u_bar])
         consts = np.tile(self.const.as_vector(), (self._N, 1))
-        self.result = mpc_step_batch(xbar, ubar, self.tf, consts, options['r_des'], options,
-                                     include_J2=self.d.include_J2, max_step=self.d.ivp_max_step,
-                                     device=getattr(self.d, "device", 0), **solver)
+        if self.shared_tf and self._N > 1:
+            A, Bp, Bn, Sig, xi, dst = self.d.discretize_batch(xbar, ubar, self.tf, consts)       # optimizer.py:243-249
+            if (dst != 0).any():
+                raise RuntimeError(f"discretize failed: {[_ffi.STATUS_TEXT.get(int(c), c) for c in dst if c]}")
+            self.result, self.tf_search = solve_shared_tf(A, Bp, Bn, Sig, xi, xbar, ubar, self.tf, consts, options['r_des'],
+                                                          options, device=getattr(self.d, "device", 0), **solver)
+        else:
+            self.result = mpc_step_batch(xbar, ubar, self.tf, consts, options['r_des'], options,
+                                         include_J2=self.d.include_J2, max_step=self.d.ivp_max_step,
+                                         device=getattr(self.d, "device", 0), **solver)
         self.status = self.result.status
         bad = [int(c) for c in self.result.status if c not in (0, 7)]
         if bad and self.verbose:
@@ -157,6 +237,7 @@ class Optimizer:
         return self.result.X[s].copy()
 
     def get_solved_tf(self, s):
+        """(the reference ignores s, :199-203: one tf for all; so does the shared mode, where every entry is the same)"""
         return float(self.result.tf[s])
 
     def get_solved_u(self, s):

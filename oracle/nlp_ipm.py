@@ -126,12 +126,15 @@ class MpcProblem:
     """One satellite's SCP subproblem.  stage = dict(A (K-1,7,7), Bp, Bn (K-1,7,3), Sigma, xi (7,K-1));
     terms = output of Optimizer.get_constraint_terms for this satellite (optimizer.py:80-170)."""
 
-    def __init__(self, xbar, ubar, tfbar, mu_grav, stage, terms, options=None, variant="exact"):
+    def __init__(self, xbar, ubar, tfbar, mu_grav, stage, terms, options=None, variant="exact", fixed_tf=None):
         """variant "exact": the quartic tangential-velocity equality the reference enables (optimizer.py:577);
         "linvt": the linearised pair it keeps commented out (:471-489, :575-576) instead -- a convex problem."""
         o = {**DEFAULT_OPTIONS, **(options or {})}
         self.o = o; self.variant = variant
         assert variant in ("exact", "linvt")
+        # fixed_tf: the final time is not a variable but held at this value (its range constraint :588 and its
+        # stationarity row drop out); the inner problem of the shared-tf decomposition (solve_shared_tf below)
+        self.fixed_tf = None if fixed_tf is None else float(fixed_tf)
         self.xbar = np.array(xbar, dtype=float); self.ubar = np.array(ubar, dtype=float)
         self.tfbar = float(tfbar)
         self.K = K = self.xbar.shape[1]
@@ -179,7 +182,7 @@ class MpcProblem:
     def ineq(self, X, U, NU, T, tf):
         """all inequality constraints in g(w) <= 0 form (relaxed bounds), keyed by family"""
         K = self.K
-        return {
+        g = {
             "u": (U ** 2).sum(0) - self.b_u,                                             # k = 0..K-1
             "rmax": (X[:3, 1:] ** 2).sum(0) - self.b_rmax,                               # k = 1..K-1
             "rmin": -(self.rbar_hat[:, 1:] * X[:3, 1:K - 1]).sum(0) - self.b_rmin,       # k = 1..K-2
@@ -188,6 +191,8 @@ class MpcProblem:
             "tp": NU - T, "tn": -NU - T,                                                 # :579-585
             "tf": np.array([-tf, tf]) - self.b_tf,
         }
+        if self.fixed_tf is not None: del g["tf"]
+        return g
 
 
 class Iterate:
@@ -216,6 +221,7 @@ def initial_iterate(P, start="ref", prm=FAST):
         it.X = np.zeros_like(P.xbar); it.X[:, 0] = P.xbar[:, 0]; it.U = np.zeros_like(P.ubar); it.tf = 0.0
     else:
         it.X = P.xbar.copy(); it.U = P.ubar.copy(); it.tf = P.tfbar
+    if P.fixed_tf is not None: it.tf = P.fixed_tf
     it.NU = np.zeros((7, K - 1)); it.T = np.zeros((7, K - 1))
     if isinstance(start, dict) and "NU" in start: it.NU = np.array(start["NU"], dtype=float)[:, :K - 1].copy()
     it.lam = np.zeros((7, K - 1)); it.lam_vt = 0.0
@@ -252,7 +258,7 @@ def lagrangian_gradient(P, it, zz, with_lambda=True):
     gx[:3, 1:K - 1] += -P.rbar_hat[:, 1:] * zz["rmin"][None, :]
     gx[:, K - 1] += P.aT.T @ zz["term"]
     gx[:3, K - 1] += 2 * X[:3, K - 1] * zz["rfmax"][0]
-    gtf += -zz["tf"][0] + zz["tf"][1]
+    if "tf" in zz: gtf += -zz["tf"][0] + zz["tf"][1]
     gnu = zz["tp"] - zz["tn"] - (it.lam if with_lambda else 0.0)
     gt = P.w_nu - zz["tp"] - zz["tn"]
     return gx, gu, gtf, gnu, gt, cv, gv, Hv
@@ -263,7 +269,7 @@ def residual_vectors(P, it, mu):
     gx, gu, gtf, gnu, gt, cv, _, _ = lagrangian_gradient(P, it, it.z)
     g = P.ineq(it.X, it.U, it.NU, it.T, it.tf)
     e = P.dyn_residual(it.X, it.U, it.NU, it.tf)
-    dual = [gx[:, 1:], gu, np.array([gtf]), gnu, gt]
+    dual = [gx[:, 1:], gu, np.array([gtf if P.fixed_tf is None else 0.0]), gnu, gt]
     prim = [e, np.array([cv])] + [g[k] + it.s[k] for k in g]
     comp = [it.s[k] * it.z[k] - mu for k in g]
     return dual, prim, comp
@@ -343,7 +349,7 @@ def newton_blocks(P, it, mu, delta_w=0.0):
     a_ = sig["tp"] + sig["tn"]; b_ = sig["tn"] - sig["tp"]
     D = 4 * sig["tp"] * sig["tn"] / a_
     avt = np.zeros(7); avt[:6] = gv
-    return dict(Wx=Wx, Wu=Wu, Wx0=Wx0, Wu0=Wu0, stiff=stiff, WxK_soft=WxK_soft, gxK_soft=gxK_soft, term=term, Wtf=2 * P.w_tr + delta_w + sig["tf"].sum(),
+    return dict(Wx=Wx, Wu=Wu, Wx0=Wx0, Wu0=Wu0, stiff=stiff, WxK_soft=WxK_soft, gxK_soft=gxK_soft, term=term, Wtf=2 * P.w_tr + delta_w + (sig["tf"].sum() if "tf" in sig else 0.0),
                 D=D, rho=gnu - (b_ / a_) * gt, gx=gx, gu=gu, gtf=gtf, e=P.dyn_residual(it.X, it.U, it.NU, it.tf),
                 cv=cv, avt=avt, Hv=Hv, a_=a_, b_=b_, gt=gt, g=g, sig=sig, zhat=zhat)
 
@@ -515,6 +521,8 @@ def riccati_solve(P, nb, F, rhs):
     Mb[0, 0] = nb["Wtf"]
     for c in range(1, 1 + nbd): Mb[0, c - 1] -= (P.Sig * chans[c][3]).sum()
     rb[0] = -rhs["gtf"] + (P.Sig * chans[0][3]).sum()
+    if P.fixed_tf is not None:                         # dtf = 0: its row and column leave the border (pivot +1)
+        Mb[0, :] = 0.0; Mb[:, 0] = 0.0; Mb[0, 0] = 1.0; rb[0] = 0.0
     for i, a in enumerate(vecs):
         for c in range(1, 1 + nbd): Mb[1 + i, c - 1] += a @ chans[c][0][:, K - 1]
         rb[1 + i] = -(a @ chans[0][0][:, K - 1])
@@ -574,7 +582,7 @@ def newton_direction(P, it, mu, delta_w=0.0, n_refine=1):
                 lam=-it.lam.copy(), lam_vt=-it.lam_vt, zeta=np.zeros(len(nb["term"])))   # so that lam + dlam = 0: rhs has no multipliers
     d = zero
     # refinement once a barrier weight z/s (terminal rank-1 terms, stage balls and planes, tf bounds) costs digits
-    stiff = max(max(w for (a, w, gh) in nb["term"]), max(nb["sig"][k].max() for k in ("u", "rmax", "rmin", "tf")))
+    stiff = max(max(w for (a, w, gh) in nb["term"]), max(nb["sig"][k].max() for k in ("u", "rmax", "rmin", "tf") if k in nb["sig"]))
     passes = 1 + (n_refine if stiff > REFINE_TW else 0)
     for _ in range(passes):
         rhs = reduced_residual(P, nb, it, d, F["win"])
@@ -595,6 +603,7 @@ def finish_direction(P, it, nb, d):
           "rfmax": np.array([(2 * X[:3, K - 1] * d["X"][:3, K - 1]).sum()]),
           "tp": d["NU"] - d["T"], "tn": -d["NU"] - d["T"],
           "tf": np.array([-d["tf"], d["tf"]])}
+    if "tf" not in nb["g"]: del dg["tf"]
     g, sig, zhat = nb["g"], nb["sig"], nb["zhat"]
     d["s"] = {k: -(g[k] + it.s[k]) - dg[k] for k in g}
     d["z"] = {k: zhat[k] + sig[k] * dg[k] - it.z[k] for k in g}
@@ -619,6 +628,7 @@ def newton_direction_dense(P, it, mu, delta_w=0.0):
     for k in range(1, K): M[ix(k), ix(k)] = Wx[k]; rhs[ix(k)] = -gx[:, k]
     for k in range(K): M[iu(k), iu(k)] = nb["Wu"][k]; rhs[iu(k)] = -nb["gu"][:, k]
     M[itf, itf] = nb["Wtf"]; rhs[itf] = -nb["gtf"]
+    fixed = P.fixed_tf is not None
     for k in range(K - 1):
         J = np.zeros((7, npr)); J[:, ix(k + 1)] = np.eye(7)
         if k >= 1: J[:, ix(k)] = -P.A[k]
@@ -630,6 +640,8 @@ def newton_direction_dense(P, it, mu, delta_w=0.0):
         M[ivt, ix(K - 1)] = nb["avt"]; M[ix(K - 1), ivt] = nb["avt"]; rhs[ivt] = -nb["cv"]
     else:
         M[ivt, ivt] = -1.0                                          # no equality row: decoupled placeholder (keeps the inertia count)
+    if fixed:
+        M[itf, :] = 0.0; M[:, itf] = 0.0; M[itf, itf] = 1.0; rhs[itf] = 0.0
     sol = np.linalg.solve(M, rhs)
     d = dict(X=np.zeros((7, K)), U=sol[nx:nx + nu_].reshape(K, 3).T.copy(), tf=sol[itf])
     d["X"][:, 1:] = sol[:nx].reshape(K - 1, 7).T
@@ -730,5 +742,69 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU
     T = np.zeros((7, K)); T[:, :K - 1] = it.T
+    # this satellite's term of the tf stationarity row: d/dtf of its optimal value at fixed tf (envelope theorem)
+    g_tf = 2 * P.w_tr * (it.tf - P.tfbar) - sum(P.Sig[:, k] @ it.lam[:, k] for k in range(K - 1))
     return dict(X=it.X, U=it.U, NU=NU, T=T, tf=it.tf, status=status, iters=k_it, n_regularised=n_reg, first_regularised=first_reg,
-                kkt=optimality_error(P, it, 0.0)[0], objective=P.objective(it.X, it.U, it.T, it.tf), iterate=it)
+                kkt=optimality_error(P, it, 0.0)[0], objective=P.objective(it.X, it.U, it.T, it.tf), iterate=it, g_tf=g_tf)
+
+
+def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
+    """The scalar outer problem of the shared-tf decomposition: the root of the tf stationarity row G(tf) = 1 + sum_s g_s(tf)
+    on (0, tf_max] (G increasing: tf enters convexly), or tf_max when G(tf_max) <= 0 (the range constraint active).
+    Starts at the reference final time, walks towards the root with doubling steps until the sign changes (the inner
+    problems are linearised around tf_bar: far from it they are hard and never needed), then a bracketing secant
+    (Illinois).  Each G costs one batched inner solve; its accuracy is that of the inner multipliers (~1e-6), hence gtol.
+    Returns (tf, evaluations [(tf, G)]).  The device host code (optimizer.py) runs the same procedure."""
+    ev = []
+    def g(t):
+        v = G(t); ev.append((t, v)); return v
+    a = min(tf0, tf_max); ga = g(a)
+    if abs(ga) <= gtol or (a == tf_max and ga <= 0.0): return a, ev
+    h = 0.05 * a
+    while True:
+        b = a - h if ga > 0.0 else a + h
+        b = min(max(b, 0.05 * a), tf_max)
+        gb = g(b)
+        if abs(gb) <= gtol: return b, ev
+        if (ga > 0.0) != (gb > 0.0): break
+        if b == tf_max and gb <= 0.0: return tf_max, ev
+        a, ga = b, gb; h *= 2.0
+        if len(ev) > 40: return b, ev
+    lo, glo, hi, ghi = (a, ga, b, gb) if ga < 0.0 else (b, gb, a, ga)
+    side = 0; t = 0.5 * (lo + hi)
+    for _ in range(40):
+        if hi - lo <= xtol: break
+        t = (lo * ghi - hi * glo) / (ghi - glo)
+        gt = g(t)
+        if abs(gt) <= gtol: return t, ev
+        if gt > 0.0:
+            hi, ghi = t, gt
+            if side == 1: glo *= 0.5
+            side = 1
+        else:
+            lo, glo = t, gt
+            if side == -1: ghi *= 0.5
+            side = -1
+    return t, ev
+
+
+def solve_shared_tf(problems, tf_max, **kw):
+    """Several satellites in one Optimizer share ONE final time (optimizer.py:287,311,322,336; get_solved_tf ignores s,
+    :199-203).  The NLP then separates given tf: min_tf [ tf + sum_s V_s(tf) ], V_s = satellite s's problem at fixed tf
+    (its trust-region term w_tr (tf - tf_bar)^2 included), V_s'(tf) = g_tf of the inner solution.  The KKT conditions of
+    the monolithic NLP are exactly: every inner problem's KKT conditions + 1 + sum_s g_s = 0 (or tf on its bound)."""
+    import copy
+    def G(t):
+        tot = 1.0
+        for P in problems:
+            Q = copy.copy(P); Q.fixed_tf = float(t)
+            r = solve(Q, **kw)
+            assert r["status"] in (ST_OK, ST_ACCEPTABLE), r["status"]
+            tot += r["g_tf"]
+        return tot
+    tf, ev = shared_tf_root(G, tf_max, problems[0].tfbar)
+    out = []
+    for P in problems:
+        Q = copy.copy(P); Q.fixed_tf = float(tf)
+        out.append(solve(Q, **kw))
+    return tf, out, ev

@@ -69,8 +69,10 @@ def test_constraint_terms_mirror(golden_dir):
     for k, v in ct.items():
         assert np.allclose(v[0], d["ct_" + k], rtol=0, atol=1e-13, equal_nan=True), k
     assert opt.init_options({"r_des": 1.3})["r_des"] == 1.3 and opt.init_options({})["w_nu"] == 1000
-    with pytest.raises(NotImplementedError):                 # one tf shared by several satellites (optimizer.py:287)
-        Optimizer([d["x"], d["x"]], [d["u"], d["u"]], [None, None], 2, None, None, scale)
+    # several satellites share one tf by default, as in the reference (optimizer.py:287)
+    assert Optimizer([d["x"], d["x"]], [d["u"], d["u"]], [None, None], 2, None, None, scale).shared_tf
+    assert not Optimizer([d["x"], d["x"]], [d["u"], d["u"]], [None, None], 2, None, None, scale, shared_tf=False).shared_tf
+    assert not opt.shared_tf
 
 
 def test_host_dynamics_matches_oracle(golden_dir):

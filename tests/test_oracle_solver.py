@@ -192,3 +192,44 @@ def test_zero_like_start_exact_variant(golden_dir):
     base = N.solve(P)
     r = N.solve(P, start=dict(X=1e-3 * P.xbar, U=np.zeros_like(P.ubar), tf=0.0), mode="ipopt_default", max_iter=600)
     assert r["status"] == N.ST_OK and np.abs(r["X"] - base["X"]).max() < 5e-6 and abs(r["tf"] - base["tf"]) < 1e-6
+
+
+# ---- several satellites sharing one tf (optimizer.py:287) ----
+def shared_problems(golden_dir, case):
+    f = np.load(os.path.join(golden_dir, f"xcheck_{case}.npz"))
+    Ps = []
+    for name in f["fixture"]:
+        d = np.load(os.path.join(golden_dir, f"disc_{str(name)}.npz"))
+        x, u, tf, cst = d["x"], d["u"], float(d["tf"]), d["const"]
+        Ps.append(N.MpcProblem(x, u, tf, cst[0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
+                               O.constraint_terms(x, u, cst[0]), {"r_des": float(f["r_des"])}, variant=str(f["variant"])))
+    return Ps, f
+
+
+@pytest.mark.parametrize("case", ["shared_tf_K30", "shared_tf_K30_linvt"])
+def test_shared_tf_vs_independent_monolithic_solution(golden_dir, case):
+    """The fixture is the MONOLITHIC two-satellite NLP (one tf variable, 2 x 24K + 1 unknowns) solved by trust-constr;
+    the oracle solves it by the decomposition the device uses (inner problems at fixed tf + scalar root search)."""
+    Ps, f = shared_problems(golden_dir, case)
+    assert f["X"].shape == (2, 7, 30) and f["optimality"] < 1e-8
+    tf, out, ev = N.solve_shared_tf(Ps, 5.0)
+    assert abs(tf - float(f["tf_opt"])) < 1e-6 and len(ev) <= 15
+    assert abs(1.0 + sum(o["g_tf"] for o in out)) < 1e-6          # the tf stationarity row of the monolithic problem
+    for s, o in enumerate(out):
+        assert o["status"] == N.ST_OK
+        assert np.abs(o["X"] - f["X"][s]).max() < 1e-5 and np.abs(o["NU"] - f["NU"][s]).max() < 1e-6
+    # the coupling matters: solved separately the two satellites want different final times
+    sep = []
+    for P in Ps:
+        sep.append(N.solve(P)["tf"])
+    assert abs(sep[0] - sep[1]) > 1e-3 and min(sep) - 1e-6 < tf < max(sep) + 1e-6
+
+
+def test_fixed_tf_inner_problem(golden_dir):
+    """at the free-tf optimum the tf stationarity row reads 1 + g = 0, and fixing tf there reproduces the solution"""
+    P = problem(golden_dir, "tan_K30_tf1")
+    base = N.solve(P)
+    Q = problem(golden_dir, "tan_K30_tf1"); Q.fixed_tf = base["tf"]
+    r = N.solve(Q)
+    assert r["status"] == N.ST_OK and abs(1.0 + r["g_tf"]) < 2e-5 and r["tf"] == base["tf"]
+    assert np.abs(r["X"] - base["X"]).max() < 5e-6

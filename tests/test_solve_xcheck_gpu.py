@@ -83,3 +83,61 @@ def test_convex_variant_batch_is_order_independent(golden_dir):
     assert np.array_equal(a.X, b.X[rev]) and np.array_equal(a.tf, b.tf[rev])
     e = solve_batch(*args, x, u, np.ones(len(idx)), cs, r_des)                   # the exact variant differs (another constraint)
     assert (e.status == 0).all() and np.abs(e.tf - a.tf).max() > 1e-6
+
+
+# ---- several satellites sharing one tf (optimizer.py:287): device = batched inner solves at fixed tf + host root search ----
+def shared_inputs(golden_dir, case):
+    f = np.load(os.path.join(golden_dir, f"xcheck_{case}.npz"))
+    ds = [np.load(os.path.join(golden_dir, f"disc_{str(n)}.npz")) for n in f["fixture"]]
+    st = lambda k: np.stack([d[k] for d in ds])
+    return f, ds, [st(k) for k in ("A", "Bp", "Bn", "Sigma", "xi")], st("x"), st("u"), st("const")
+
+
+@pytest.mark.parametrize("case", ["shared_tf_K30", "shared_tf_K30_linvt"])
+def test_shared_tf_device_vs_monolithic_fixture(golden_dir, case):
+    from mpconstellation_amd import solve_shared_tf
+    f, ds, mats, x, u, cs = shared_inputs(golden_dir, case)
+    res, ev = solve_shared_tf(*mats, x, u, np.ones(2), cs, np.full(2, float(f["r_des"])), linear_vt=(str(f["variant"]) == "linvt"))
+    assert (res.status == 0).all() and len(ev) <= 15
+    assert res.tf[0] == res.tf[1] and abs(res.tf[0] - float(f["tf_opt"])) < 1e-6
+    assert abs(1.0 + res.g_tf.sum()) < 1e-6
+    assert np.abs(res.X - f["X"]).max() < 1e-5 and np.abs(res.NU - f["NU"]).max() < 1e-6
+    # the oracle runs the same decomposition: same tf to the root tolerance
+    Ps = [N.MpcProblem(d["x"], d["u"], 1.0, d["const"][0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
+                       O.constraint_terms(d["x"], d["u"], d["const"][0]), {"r_des": float(f["r_des"])}, variant=str(f["variant"])) for d in ds]
+    tf_o, out, _ = N.solve_shared_tf(Ps, 5.0)
+    assert abs(res.tf[0] - tf_o) < 1e-6
+    for s in range(2):
+        assert np.abs(res.X[s] - out[s]["X"]).max() < 5e-6
+
+
+def test_fixed_tf_flag_vs_oracle(golden_dir):
+    """MPCX_SOLVE_FIXED_TF: tf held at the value passed in, g_s returned in its place; same iterations as the oracle's
+    fixed-tf solve"""
+    from mpconstellation_amd import solve_batch
+    f, ds, mats, x, u, cs = shared_inputs(golden_dir, "shared_tf_K30")
+    held = np.array([0.97, 1.02])
+    res = solve_batch(*mats, x, u, np.ones(2), cs, np.full(2, float(f["r_des"])), fixed_tf=held)
+    assert (res.status == 0).all() and np.array_equal(res.tf, held)
+    for s, d in enumerate(ds):
+        P = N.MpcProblem(d["x"], d["u"], 1.0, d["const"][0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
+                         O.constraint_terms(d["x"], d["u"], d["const"][0]), {"r_des": float(f["r_des"])}, fixed_tf=held[s])
+        r = N.solve(P)
+        assert r["status"] == 0 and abs(int(res.iters[s]) - r["iters"]) <= 3
+        assert np.abs(res.X[s] - r["X"]).max() < 5e-6 and abs(res.g_tf[s] - r["g_tf"]) < 1e-5 * max(1.0, abs(r["g_tf"]))
+
+
+def test_optimizer_class_shares_tf_by_default(golden_dir):
+    """the reference's multi-satellite Optimizer (one tf, get_solved_tf ignores s, optimizer.py:199-203)"""
+    from mpconstellation_amd import Optimizer, Discretizer, Simulator, SatelliteScale, Satellite
+    f, ds, mats, x, u, cs = shared_inputs(golden_dir, "shared_tf_K30")
+    sat = Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+    scale = SatelliteScale(sat=sat)
+    assert np.array_equal(scale.get_normalized_constants().as_vector(), cs[0])
+    d = Discretizer(scale.get_normalized_constants())
+    opt = Optimizer([x[0], x[1]], [u[0], u[1]], [None, None], 1.0, d, Simulator.satellite_dynamics, scale, verbose=False)
+    opt.solve_OPT(input_options={"r_des": float(f["r_des"])})
+    assert opt.get_solved_tf(0) == opt.get_solved_tf(1)
+    # device discretisation instead of the fixture's (reference) matrices: the same answer at the solver tolerance
+    assert abs(opt.get_solved_tf(0) - float(f["tf_opt"])) < 5e-6
+    assert np.abs(opt.get_solved_trajectory(1) - f["X"][1]).max() < 1e-5
