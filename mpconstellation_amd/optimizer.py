@@ -87,7 +87,7 @@ def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=Non
     return SolveResult(X, U, NU, tfo, status, iters, kkt) if held is None else SolveResult(X, U, NU, held, status, iters, kkt, tfo)
 
 
-def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
+def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=2e-8):
     """Root of the tf stationarity row G(tf) = 1 + sum_s g_s(tf) on (0, tf_max] (G increasing), or tf_max when
     G(tf_max) <= 0 (range constraint optimizer.py:588 active).  From the reference final time towards the root with doubling
     steps until the sign changes, then a bracketing secant (Illinois); every G is one batched device solve at fixed tf."""
@@ -111,7 +111,9 @@ def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
     side = 0; t = 0.5 * (lo + hi)
     for _ in range(40):
         if hi - lo <= xtol: break
+        t_prev = t
         t = (lo * ghi - hi * glo) / (ghi - glo)
+        if abs(t - t_prev) <= 1e-9 * max(1.0, abs(t)): break       # G carries the noise of the inner multipliers: no finer root
         gt = g(t)
         if abs(gt) <= gtol: return t, ev
         if gt > 0.0:

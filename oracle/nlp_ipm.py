@@ -748,7 +748,7 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
                 kkt=optimality_error(P, it, 0.0)[0], objective=P.objective(it.X, it.U, it.T, it.tf), iterate=it, g_tf=g_tf)
 
 
-def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
+def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=2e-8):
     """The scalar outer problem of the shared-tf decomposition: the root of the tf stationarity row G(tf) = 1 + sum_s g_s(tf)
     on (0, tf_max] (G increasing: tf enters convexly), or tf_max when G(tf_max) <= 0 (the range constraint active).
     Starts at the reference final time, walks towards the root with doubling steps until the sign changes (the inner
@@ -774,7 +774,9 @@ def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=1e-9):
     side = 0; t = 0.5 * (lo + hi)
     for _ in range(40):
         if hi - lo <= xtol: break
+        t_prev = t
         t = (lo * ghi - hi * glo) / (ghi - glo)
+        if abs(t - t_prev) <= 1e-9 * max(1.0, abs(t)): break       # G carries the noise of the inner multipliers: no finer root
         gt = g(t)
         if abs(gt) <= gtol: return t, ev
         if gt > 0.0:
