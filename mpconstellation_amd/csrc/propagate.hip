@@ -30,33 +30,94 @@ struct Ctrl {
     double end_tau;
 };
 
-// control.py thrust laws u(x, tau)
-__device__ __forceinline__ void ctrl_eval(const Ctrl &c, const double (&y)[7], double tau, double (&u)[3], int &err)
+// 1/d and 1/sqrt(d) for d > 0 well inside the normal range: hardware seed + two Newton steps (half an ulp, measured:
+// profiles/tools/rcp_accuracy.hip) instead of the IEEE division / square-root sequences (scaling, fix-up: ~3x the
+// instructions).  The rollout is ~1000 sequential RK45 steps x 6 right-hand sides of one lane: its time is the number
+// of instructions of the right-hand side.
+__device__ __forceinline__ double rcp_fast(double d)
 {
-    if (c.kind == MPCX_CTRL_CONSTANT) { u[0] = c.v[0]; u[1] = c.v[1]; u[2] = c.v[2]; return; }
-    if (c.kind == MPCX_CTRL_TANGENTIAL) {                   // control.py:66-84
-        const double rn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-        double h[3] = {y[1] * y[5] - y[2] * y[4], y[2] * y[3] - y[0] * y[5], y[0] * y[4] - y[1] * y[3]};
-        const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
-        const double rh[3] = {y[0] / rn, y[1] / rn, y[2] / rn}, hh[3] = {h[0] / hn, h[1] / hn, h[2] / hn};
-        const double t[3] = {hh[1] * rh[2] - hh[2] * rh[1], hh[2] * rh[0] - hh[0] * rh[2], hh[0] * rh[1] - hh[1] * rh[0]};
+    double r = __builtin_amdgcn_rcp(d);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = rh[i] * 0.0 + t[i] * c.v[0] + hh[i] * 0.0;
-        return;
-    }
-    if (c.kind == MPCX_CTRL_SEQUENCE) {                     // control.py:132-142
-        if (tau <= c.end_tau) { foh3(tau / c.end_tau, c.useq, c.Ku, u, err); return; }
-    }
-    u[0] = u[1] = u[2] = 0.0;
+    for (int n = 0; n < 2; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    return r;
+}
+__device__ __forceinline__ double rsq_fast(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const double e = fma(-d * r, r, 1.0); r = fma(0.5 * r, e, r); }
+    return r;
 }
 
-__device__ __forceinline__ void prop_rhs(const Ctrl &c, const SatConst &cst, int flags, double tf, double tau,
+// First-order hold of a (3,Ku) table at tau in [0,1] (control.py:104-126), same node index as foh3: k = int(tau // dtau) is
+// the floor of the exact quotient (Python's float floor division goes through an exact fmod); floor(tau * (Ku-1)) is
+// that number unless the product sits within rounding of an integer, and only then the exact routine is needed.
+__device__ __forceinline__ void foh3_fast(double tau, const double *__restrict__ u, int Ku, double (&out)[3], int &err)
+{
+    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
+    const double km1 = (double)(Ku - 1);
+    const double q = tau * km1;
+    int k = (fabs(q - rint(q)) > 1e-9 * fmax(1.0, q)) ? (int)floor(q) : (int)py_floordiv(tau, 1.0 / km1);
+    if (k < 0 || k + 1 >= Ku) {          // the reference raises IndexError here
+        err = MPCX_ST_FOH;
+        k = k < 0 ? 0 : Ku - 2;
+        if (Ku < 2) { out[0] = out[1] = out[2] = 0.0; return; }
+    }
+    const double tau_k = (double)k / km1, tau_kp1 = (double)(k + 1) / km1;
+    const double id = 1.0 / (tau_kp1 - tau_k);
+    const double lam_n = (tau_kp1 - tau) * id, lam_p = (tau - tau_k) * id;
+    out[0] = lam_n * u[k] + lam_p * u[k + 1];
+    out[1] = lam_n * u[Ku + k] + lam_p * u[Ku + k + 1];
+    out[2] = lam_n * u[2 * Ku + k] + lam_p * u[2 * Ku + k + 1];
+}
+
+// Simulator.satellite_dynamics (simulator.py:116-161) under the controller's thrust law (control.py), times tf -- the
+// same quantities as dynamics_unscaled / ctrl_eval (which the discretizer keeps using, division for division as numpy
+// evaluates them), arranged around one reciprocal each of |r|, |h|, m instead of a division per component: results
+// differ from those forms by rounding only (a few ulp per evaluation; rollouts agree with the reference's to 1e-12,
+// the accepted step sequence is the same -- max_step clips every step).  inv_gi = 1 / (g0 Isp).
+__device__ __forceinline__ void prop_rhs(const Ctrl &c, const SatConst &cst, double inv_gi, int flags, double tf, double tau,
                                          const double (&y)[7], double (&yd)[7], int &err)
 {
-    double u[3];
-    ctrl_eval(c, y, tau, u, err);
-    if (y[6] <= 0.0) err = MPCX_ST_MASS;
-    dynamics_unscaled(y, u, cst, flags, yd);
+    const double r2 = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+    const double irn = rsq_fast(r2), irn2 = irn * irn;
+    const double m = y[6];
+    if (m <= 0.0) err = MPCX_ST_MASS;
+    const double im = rcp_fast(m > 0.0 ? m : 1.0);
+    double u[3], un;
+    if (c.kind == MPCX_CTRL_CONSTANT) {
+        u[0] = c.v[0]; u[1] = c.v[1]; u[2] = c.v[2];
+        un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    } else if (c.kind == MPCX_CTRL_TANGENTIAL) {            // control.py:66-84: u = mag * h_hat x r_hat = mag (h x r) / (|h| |r|)
+        const double h[3] = {y[1] * y[5] - y[2] * y[4], y[2] * y[3] - y[0] * y[5], y[0] * y[4] - y[1] * y[3]};
+        const double ihn = rsq_fast(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+        const double k = c.v[0] * (ihn * irn);
+        u[0] = k * (h[1] * y[2] - h[2] * y[1]); u[1] = k * (h[2] * y[0] - h[0] * y[2]); u[2] = k * (h[0] * y[1] - h[1] * y[0]);
+        un = fabs(c.v[0]);                                   // |h_hat x r_hat| = 1 (h is normal to r)
+    } else if (c.kind == MPCX_CTRL_SEQUENCE && tau <= c.end_tau) {      // control.py:132-142
+        foh3_fast(tau / c.end_tau, c.useq, c.Ku, u, err);
+        un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    } else { u[0] = u[1] = u[2] = 0.0; un = 0.0; }
+    const double kg = -cst.mu * (irn2 * irn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        yd[i] = y[3 + i];
+        yd[3 + i] = kg * y[i] + u[i] * im;
+    }
+    if (flags & MPCX_FLAG_DRAG) {                            // simulator.py:150-153
+        const double vn = sqrt(y[3] * y[3] + y[4] * y[4] + y[5] * y[5]);
+        const double coef = -0.5 * kCd * cst.s * im * (kRho500 / cst.rho) * vn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) yd[3 + i] += coef * y[3 + i];
+    }
+    if (flags & MPCX_FLAG_J2) {                              // simulator.py:154-158
+        const double q2 = (y[2] * y[2]) * irn2;
+        const double coef = 1.5 * cst.j2 * cst.mu * (cst.re * cst.re) * (irn2 * irn2 * irn);
+        yd[3] += coef * ((5.0 * q2 - 1.0) * y[0]);
+        yd[4] += coef * ((5.0 * q2 - 1.0) * y[1]);
+        yd[5] += coef * ((5.0 * q2 - 3.0) * y[2]);
+    }
+    yd[6] = -un * inv_gi;
 #pragma unroll
     for (int i = 0; i < 7; ++i) yd[i] = tf * yd[i];
 }
@@ -80,13 +141,14 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
     else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }
     const int flags = a.flags, n_eval = a.n_eval;
+    const double inv_gi = 1.0 / (cst.g0 * cst.isp);
     const double rtol = 1e-3, atol = 1e-6, t_bound = 1.0;
     int err = 0;
     double y[7], f[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) y[i] = a.y0[(size_t)sat * 7 + i];
     double t = 0.0;
-    prop_rhs(c, cst, flags, tf, t, y, f, err);
+    prop_rhs(c, cst, inv_gi, flags, tf, t, y, f, err);
     // select_initial_step (scipy common.py:68-134)
     double h_abs;
     {
@@ -99,7 +161,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         double y1[7], f1[7], dd[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
-        prop_rhs(c, cst, flags, tf, t + h0, y1, f1, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + h0, y1, f1, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) dd[i] = (f1[i] - f[i]) / sc[i];
         const double d2 = rms7(dd) / h0;
@@ -127,27 +189,27 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
-        prop_rhs(c, cst, flags, tf, t + RK_C[1] * h, yt, K1, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[1] * h, yt, K1, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[2][0] + K1[i] * RK_A[2][1]) * h;
-        prop_rhs(c, cst, flags, tf, t + RK_C[2] * h, yt, K2, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[2] * h, yt, K2, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[3][0] + K1[i] * RK_A[3][1] + K2[i] * RK_A[3][2]) * h;
-        prop_rhs(c, cst, flags, tf, t + RK_C[3] * h, yt, K3, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[3] * h, yt, K3, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yt[i] = y[i] + (f[i] * RK_A[4][0] + K1[i] * RK_A[4][1] + K2[i] * RK_A[4][2] + K3[i] * RK_A[4][3]) * h;
-        prop_rhs(c, cst, flags, tf, t + RK_C[4] * h, yt, K4, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[4] * h, yt, K4, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yt[i] = y[i] + (f[i] * RK_A[5][0] + K1[i] * RK_A[5][1] + K2[i] * RK_A[5][2] + K3[i] * RK_A[5][3] +
                             K4[i] * RK_A[5][4]) * h;
-        prop_rhs(c, cst, flags, tf, t + RK_C[5] * h, yt, K5, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[5] * h, yt, K5, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yn[i] = y[i] + h * (f[i] * RK_B[0] + K1[i] * RK_B[1] + K2[i] * RK_B[2] + K3[i] * RK_B[3] + K4[i] * RK_B[4] +
                                 K5[i] * RK_B[5]);
-        prop_rhs(c, cst, flags, tf, t + h, yn, K6, err);
+        prop_rhs(c, cst, inv_gi, flags, tf, t + h, yn, K6, err);
         double eh[7], ssq = 0.0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
