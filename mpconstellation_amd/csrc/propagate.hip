@@ -25,9 +25,13 @@ struct PropArgs {
 
 struct Ctrl {
     int kind, Ku;
-    double v[3];
+    double v[3], vn;          // vn = |v| (constant thrust)
     const double *useq;
-    double end_tau;
+    double end_tau, inv_end_tau;
+    // first-order hold: the interval in use (an RK45 step is at most max_step = 1e-3 long against intervals of 1/(Ku-1):
+    // the six stages of a step and many steps in a row read the same two table columns -- kept in registers)
+    int kc;
+    double uk[3], uk1[3], tau_k, tau_kp1, id;
 };
 
 // 1/d and 1/sqrt(d) for d > 0 well inside the normal range: hardware seed + two Newton steps (half an ulp, measured:
@@ -52,8 +56,10 @@ __device__ __forceinline__ double rsq_fast(double d)
 // First-order hold of a (3,Ku) table at tau in [0,1] (control.py:104-126), same node index as foh3: k = int(tau // dtau) is
 // the floor of the exact quotient (Python's float floor division goes through an exact fmod); floor(tau * (Ku-1)) is
 // that number unless the product sits within rounding of an integer, and only then the exact routine is needed.
-__device__ __forceinline__ void foh3_fast(double tau, const double *__restrict__ u, int Ku, double (&out)[3], int &err)
+__device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3], int &err)
 {
+    const int Ku = c.Ku;
+    const double *__restrict__ u = c.useq;
     if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
     const double km1 = (double)(Ku - 1);
     const double q = tau * km1;
@@ -63,12 +69,16 @@ __device__ __forceinline__ void foh3_fast(double tau, const double *__restrict__
         k = k < 0 ? 0 : Ku - 2;
         if (Ku < 2) { out[0] = out[1] = out[2] = 0.0; return; }
     }
-    const double tau_k = (double)k / km1, tau_kp1 = (double)(k + 1) / km1;
-    const double id = 1.0 / (tau_kp1 - tau_k);
-    const double lam_n = (tau_kp1 - tau) * id, lam_p = (tau - tau_k) * id;
-    out[0] = lam_n * u[k] + lam_p * u[k + 1];
-    out[1] = lam_n * u[Ku + k] + lam_p * u[Ku + k + 1];
-    out[2] = lam_n * u[2 * Ku + k] + lam_p * u[2 * Ku + k + 1];
+    if (k != c.kc) {
+        c.kc = k;
+        c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
+        c.id = 1.0 / (c.tau_kp1 - c.tau_k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * Ku + k]; c.uk1[i] = u[i * Ku + k + 1]; }
+    }
+    const double lam_n = (c.tau_kp1 - tau) * c.id, lam_p = (tau - c.tau_k) * c.id;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
 }
 
 // Simulator.satellite_dynamics (simulator.py:116-161) under the controller's thrust law (control.py), times tf -- the
@@ -76,27 +86,33 @@ __device__ __forceinline__ void foh3_fast(double tau, const double *__restrict__
 // evaluates them), arranged around one reciprocal each of |r|, |h|, m instead of a division per component: results
 // differ from those forms by rounding only (a few ulp per evaluation; rollouts agree with the reference's to 1e-12,
 // the accepted step sequence is the same -- max_step clips every step).  inv_gi = 1 / (g0 Isp).
-__device__ __forceinline__ void prop_rhs(const Ctrl &c, const SatConst &cst, double inv_gi, int flags, double tf, double tau,
+template <int KIND, int FLAGS>
+__device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double inv_gi, double tf, double tau,
                                          const double (&y)[7], double (&yd)[7], int &err)
 {
+    constexpr int flags = FLAGS;
     const double r2 = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
     const double irn = rsq_fast(r2), irn2 = irn * irn;
     const double m = y[6];
     if (m <= 0.0) err = MPCX_ST_MASS;
     const double im = rcp_fast(m > 0.0 ? m : 1.0);
     double u[3], un;
-    if (c.kind == MPCX_CTRL_CONSTANT) {
+    if (KIND == MPCX_CTRL_CONSTANT) {
         u[0] = c.v[0]; u[1] = c.v[1]; u[2] = c.v[2];
-        un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    } else if (c.kind == MPCX_CTRL_TANGENTIAL) {            // control.py:66-84: u = mag * h_hat x r_hat = mag (h x r) / (|h| |r|)
+        un = c.vn;
+    } else if (KIND == MPCX_CTRL_TANGENTIAL) {            // control.py:66-84: u = mag * h_hat x r_hat = mag (h x r) / (|h| |r|)
         const double h[3] = {y[1] * y[5] - y[2] * y[4], y[2] * y[3] - y[0] * y[5], y[0] * y[4] - y[1] * y[3]};
         const double ihn = rsq_fast(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
         const double k = c.v[0] * (ihn * irn);
         u[0] = k * (h[1] * y[2] - h[2] * y[1]); u[1] = k * (h[2] * y[0] - h[0] * y[2]); u[2] = k * (h[0] * y[1] - h[1] * y[0]);
         un = fabs(c.v[0]);                                   // |h_hat x r_hat| = 1 (h is normal to r)
-    } else if (c.kind == MPCX_CTRL_SEQUENCE && tau <= c.end_tau) {      // control.py:132-142
-        foh3_fast(tau / c.end_tau, c.useq, c.Ku, u, err);
-        un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    } else if (KIND == MPCX_CTRL_SEQUENCE && tau <= c.end_tau) {      // control.py:132-142
+        // tau / end_tau: reciprocal, product and one correction step (the quotient as the division sequence rounds it)
+        double tn = tau * c.inv_end_tau;
+        tn = fma(fma(-tn, c.end_tau, tau), c.inv_end_tau, tn);
+        foh3_cached(tn, c, u, err);
+        const double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        un = uu * rsq_fast(fmax(uu, 1e-300));                 // |u| (0 for u = 0)
     } else { u[0] = u[1] = u[2] = 0.0; un = 0.0; }
     const double kg = -cst.mu * (irn2 * irn);
 #pragma unroll
@@ -130,17 +146,22 @@ __device__ __forceinline__ double rms7(const double (&v)[7])
     return sqrt(s) / sqrt(7.0);
 }
 
+// One instantiation per thrust law and truth-model flag set (both are launch constants): the right-hand side appears
+// eight times in the step and every variant it does not need would sit in each copy.
+template <int KIND, int FLAGS>
 __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
 {
     const int sat = blockIdx.x * blockDim.x + threadIdx.x;
     if (sat >= a.S) return;
     SatConst cst; cst.load(a.consts + (size_t)sat * MPCX_NCONST);
     const double tf = a.tf[sat];
-    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0;
-    if (a.ctrl_kind == MPCX_CTRL_CONSTANT) for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i];
+    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1;
+    if (a.ctrl_kind == MPCX_CTRL_CONSTANT) { for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i]; }
     else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
     else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }
-    const int flags = a.flags, n_eval = a.n_eval;
+    c.vn = sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]);
+    c.inv_end_tau = 1.0 / c.end_tau;
+    const int n_eval = a.n_eval;
     const double inv_gi = 1.0 / (cst.g0 * cst.isp);
     const double rtol = 1e-3, atol = 1e-6, t_bound = 1.0;
     int err = 0;
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
 #pragma unroll
     for (int i = 0; i < 7; ++i) y[i] = a.y0[(size_t)sat * 7 + i];
     double t = 0.0;
-    prop_rhs(c, cst, inv_gi, flags, tf, t, y, f, err);
+    prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t, y, f, err);
     // select_initial_step (scipy common.py:68-134)
     double h_abs;
     {
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         double y1[7], f1[7], dd[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
-        prop_rhs(c, cst, inv_gi, flags, tf, t + h0, y1, f1, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h0, y1, f1, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) dd[i] = (f1[i] - f[i]) / sc[i];
         const double d2 = rms7(dd) / h0;
@@ -189,27 +210,27 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
-        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[1] * h, yt, K1, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[1] * h, yt, K1, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[2][0] + K1[i] * RK_A[2][1]) * h;
-        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[2] * h, yt, K2, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[2] * h, yt, K2, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[3][0] + K1[i] * RK_A[3][1] + K2[i] * RK_A[3][2]) * h;
-        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[3] * h, yt, K3, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[3] * h, yt, K3, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yt[i] = y[i] + (f[i] * RK_A[4][0] + K1[i] * RK_A[4][1] + K2[i] * RK_A[4][2] + K3[i] * RK_A[4][3]) * h;
-        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[4] * h, yt, K4, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[4] * h, yt, K4, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yt[i] = y[i] + (f[i] * RK_A[5][0] + K1[i] * RK_A[5][1] + K2[i] * RK_A[5][2] + K3[i] * RK_A[5][3] +
                             K4[i] * RK_A[5][4]) * h;
-        prop_rhs(c, cst, inv_gi, flags, tf, t + RK_C[5] * h, yt, K5, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[5] * h, yt, K5, err);
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             yn[i] = y[i] + h * (f[i] * RK_B[0] + K1[i] * RK_B[1] + K2[i] * RK_B[2] + K3[i] * RK_B[3] + K4[i] * RK_B[4] +
                                 K5[i] * RK_B[5]);
-        prop_rhs(c, cst, inv_gi, flags, tf, t + h, yn, K6, err);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h, yn, K6, err);
         double eh[7], ssq = 0.0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -292,7 +313,24 @@ extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const 
     if ((ctrl_kind == MPCX_CTRL_CONSTANT || ctrl_kind == MPCX_CTRL_TANGENTIAL) && !ctrl_vec) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: thrust parameters missing");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
     PropArgs a{S, n_eval, flags, ctrl_kind, Ku, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
-    hipLaunchKernelGGL(propagate_kernel, dim3((S + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    const dim3 grid((S + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+#define MPCX_PROP_LAUNCH(KIND, FLAGS) hipLaunchKernelGGL((propagate_kernel<KIND, FLAGS>), grid, block, 0, st, a)
+#define MPCX_PROP_FLAGS(KIND)                                                                                         \
+    switch (flags & 3) {                                                                                              \
+    case 0: MPCX_PROP_LAUNCH(KIND, 0); break;                                                                         \
+    case 1: MPCX_PROP_LAUNCH(KIND, 1); break;                                                                         \
+    case 2: MPCX_PROP_LAUNCH(KIND, 2); break;                                                                         \
+    default: MPCX_PROP_LAUNCH(KIND, 3); break;                                                                        \
+    }
+    switch (ctrl_kind) {
+    case MPCX_CTRL_ZERO: MPCX_PROP_FLAGS(MPCX_CTRL_ZERO); break;
+    case MPCX_CTRL_CONSTANT: MPCX_PROP_FLAGS(MPCX_CTRL_CONSTANT); break;
+    case MPCX_CTRL_TANGENTIAL: MPCX_PROP_FLAGS(MPCX_CTRL_TANGENTIAL); break;
+    default: MPCX_PROP_FLAGS(MPCX_CTRL_SEQUENCE); break;
+    }
+#undef MPCX_PROP_FLAGS
+#undef MPCX_PROP_LAUNCH
     MPCX_HIP(ctx, hipGetLastError());
     return MPCX_OK;
 }
