@@ -61,6 +61,8 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
     const int Ku = c.Ku;
     const double *__restrict__ u = c.useq;
     if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
+    // well inside the interval in use (away from its ends by more than any rounding of the index computation): same k
+    if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
     const double km1 = (double)(Ku - 1);
     const double q = tau * km1;
     int k = (fabs(q - rint(q)) > 1e-9 * fmax(1.0, q)) ? (int)floor(q) : (int)py_floordiv(tau, 1.0 / km1);
@@ -75,6 +77,7 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
         c.id = 1.0 / (c.tau_kp1 - c.tau_k);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * Ku + k]; c.uk1[i] = u[i * Ku + k + 1]; }
+    }
     }
     const double lam_n = (c.tau_kp1 - tau) * c.id, lam_p = (tau - c.tau_k) * c.id;
 #pragma unroll
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     if (sat >= a.S) return;
     SatConst cst; cst.load(a.consts + (size_t)sat * MPCX_NCONST);
     const double tf = a.tf[sat];
-    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1;
+    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0;
     if (a.ctrl_kind == MPCX_CTRL_CONSTANT) { for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i]; }
     else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
     else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }

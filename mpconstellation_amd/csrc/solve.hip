@@ -78,7 +78,7 @@ __host__ __device__ inline int padded_nodes(int K) { return (K + 15) & ~15; }
 __host__ __device__ inline size_t ws_doubles(int K)
 {
     const size_t KP = (size_t)padded_nodes(K);
-    const size_t n = KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 3 * GL_N;
+    const size_t n = KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 3 * GL_N + 64;
     return (n + 15) & ~(size_t)15;
 }
 
@@ -295,12 +295,26 @@ struct Col {
     __device__ __forceinline__ Col node(int dk) const { return Col{base, k + dk, ld}; }   // same fields, node k + dk
 };
 
+// Store to element `e` of the satellite's workspace (wave-uniform base): scalar base + 32-bit vector offset.  The recursions issue
+// their factor-record / trajectory stores for every lane (lanes with nothing to store aim at the satellite's sink): code
+// without divergent store blocks is straight-line, so the compiler can count the stores issued after the node-ahead
+// prefetch loads and waits for those loads with vmcnt(#stores) -- behind a branch it falls back to vmcnt(0), which puts
+// the full HBM latency of the node's stores on the critical path of every node.
+__device__ __forceinline__ void ustore(gf64 *ubase, int e, double v)
+{
+    typedef __attribute__((address_space(1))) char gchar;
+    *(gf64 *)((gchar *)ubase + (unsigned)(e * 8)) = v;
+}
+
 struct Sat {
     int K, KP;
     cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
     gf64 *it, *dr, *nbs, *stT, *rbh;            // field-major [field][KP]: iterate, direction, Newton scalars, stage copy, r-hat
     gf64 *itg, *drg, *nb, *fac, *ch, *traj;     // globals; record-per-node arrays read by the recursion (one wave, one record)
     gf64 *itB, *itgB;                           // the candidate iterate of the line search (swapped with it, itg on acceptance)
+    gf64 *sink;                                 // 64 doubles nobody reads: target of the lanes a branch-free store leaves idle
+    gf64 *ws;                                   // base of the satellite's workspace and the element offsets of the arrays the
+    int o_fac, o_ch, o_traj, o_sink;            // recursions store to (plain integers: see ustore)
     __device__ Col<gf64> itn(int k) const { return Col<gf64>{wave_uniform(it), k, KP}; }
     __device__ Col<gf64> itBn(int k) const { return Col<gf64>{wave_uniform(itB), k, KP}; }
     __device__ Col<gf64> drn(int k) const { return Col<gf64>{wave_uniform(dr), k, KP}; }
@@ -316,6 +330,25 @@ struct Sat {
     __device__ cgf64 *A(int k) const { return stage + (size_t)k * MPCX_STAGE_DOUBLES; }
     __device__ cgf64 *Sig(int k) const { return A(k) + 91; }
 };
+
+// Private copy of the view for the recursions with everything that is the same in all 64 lanes forced into scalar
+// registers (node count, array bases): the compiler cannot see that these are wave-uniform -- they reach the function
+// through a reference -- and otherwise keeps K, the loop counter derived from it and every 64-bit base in vector
+// registers, which in riccati_factor meant spills reloaded inside the node loop behind an s_waitcnt vmcnt(0), i.e.
+// behind every outstanding factor-record store of the node before.
+__device__ __forceinline__ Sat uniform_view(const Sat &v)
+{
+    Sat s = v;
+    s.K = __builtin_amdgcn_readfirstlane(v.K); s.KP = __builtin_amdgcn_readfirstlane(v.KP);
+    s.stage = wave_uniform(v.stage); s.xbar = wave_uniform(v.xbar); s.ubar = wave_uniform(v.ubar);
+    s.it = wave_uniform(v.it); s.dr = wave_uniform(v.dr); s.nbs = wave_uniform(v.nbs); s.stT = wave_uniform(v.stT); s.rbh = wave_uniform(v.rbh);
+    s.itg = wave_uniform(v.itg); s.drg = wave_uniform(v.drg); s.nb = wave_uniform(v.nb); s.fac = wave_uniform(v.fac);
+    s.ch = wave_uniform(v.ch); s.traj = wave_uniform(v.traj); s.itB = wave_uniform(v.itB); s.itgB = wave_uniform(v.itgB);
+    s.sink = wave_uniform(v.sink); s.ws = wave_uniform(v.ws);
+    s.o_fac = __builtin_amdgcn_readfirstlane(v.o_fac); s.o_ch = __builtin_amdgcn_readfirstlane(v.o_ch);
+    s.o_traj = __builtin_amdgcn_readfirstlane(v.o_traj); s.o_sink = __builtin_amdgcn_readfirstlane(v.o_sink);
+    return s;
+}
 
 // iterate + a * direction for one field, branch-free: both loads always issue (so they can all be in flight
 // together); at a == 0 the direction value, which may be stale, is replaced by 0.
@@ -982,7 +1015,7 @@ __device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, gf64 *f
 // right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
 __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
 {
-    const Sat s = s_in;   // private copy: lives in registers, is not re-read after every LDS fence
+    const Sat s = uniform_view(s_in);   // private copy: scalar registers, not re-read after every LDS fence
     const int K = s.K;
     bool good = true;
     const int sc = lane >> 3, sr = lane & 7;
@@ -1021,13 +1054,11 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
 #pragma unroll
         for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
     };
+    const int sink_e = s.o_sink + lane;                       // this lane's sink slot (element offset in the workspace)
     auto sweep_store = [&](int j, double pp, double qu) {
-        if (sact) {
-            gf64 *ch = s.ch + (size_t)j * CH_N;
-            ch[C_P + sc * 7 + sr] = pp;
-            if (sr < 3) ch[C_QU + sc * 3 + sr] = qu;
-            pnext = pp;
-        }
+        ustore(s.ws, sact ? s.o_ch + j * CH_N + C_P + sc * 7 + sr : sink_e, pp);
+        ustore(s.ws, (sact && sr < 3) ? s.o_ch + j * CH_N + C_QU + sc * 3 + sr3 : sink_e, qu);
+        pnext = sact ? pp : pnext;
     };
     // operand prefetch: node k's (A, Bn | Bpm | Wx, Wu, D) -> registers -> LDS buffer.  Three branch-free loads per
     // lane: A, Bn are the head of stage record k, Bpm = B_kp of record k-1 (same offset), Wx|Wu|D the head of the
@@ -1090,7 +1121,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         FT_DECL
         if (k >= 1) fetch(k - 1);
         const bool dyn = (k <= K - 2);
-        if (fuse_sweep && dyn) nraw = chan_fetch(s, k, sc, srr, sr3);
+        if (fuse_sweep) nraw = chan_fetch(s, k, sc, srr, sr3);
         FT_MARK(0)
         // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm
         {
@@ -1152,28 +1183,32 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         if (fuse_sweep && dyn) sweep_store(k + 1, sw_p, sw_qu);
         wsync();
         FT_MARK(1)
-        if (dyn) {
+        {
             FT_MARK(2)
             // P4: Pt = Pn - X1^T R X1 ; G = X1^T R X2 ; Minv = X2^T R X2 with R = diag(1/d).  Pt is symmetric by
-            // construction: lanes (i,j) and (j,i) evaluate the same expression in (min, max) order on a symmetric Pn
-            if (lane < 49) {
-                const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
-                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            // construction: lanes (i,j) and (j,i) evaluate the same expression in (min, max) order on a symmetric Pn.
+            // Branch-free: every lane computes (idle lanes on element 0), LDS / global stores of idle lanes go to sinks;
+            // the terminal node (no dynamics) stores zeros.
+            const bool on = lane < 49;
+            const int ci = on ? mi : 0, cj = on ? mj : 0;
+            const int lo = (ci < cj) ? ci : cj, hi = (ci < cj) ? cj : ci;
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                for (int l = 0; l < 7; ++l) {
-                    const double x1i = w.WlLi[l * 14 + mi], x1lo = w.WlLi[l * 14 + lo], x1hi = w.WlLi[l * 14 + hi];
-                    const double x2i = w.WlLi[l * 14 + 7 + mi], x2j = w.WlLi[l * 14 + 7 + mj];
-                    a1 += x1lo * (rd[l] * x1hi);
-                    a2 += x1i * (rd[l] * x2j); a3 += x2i * (rd[l] * x2j);
-                }
-                const double pt = w.Pn[lo * 7 + hi] - a1;
-                o.Pt[lane] = pt; o.G[lane] = a2; o.Minv[lane] = a3;
-                fac[F_G + lane] = a2; fac[F_MINV + lane] = a3;
-                if (keep_pt) fac[F_PT + lane] = pt;
+            for (int l = 0; l < 7; ++l) {
+                const double x1i = w.WlLi[l * 14 + ci], x1lo = w.WlLi[l * 14 + lo], x1hi = w.WlLi[l * 14 + hi];
+                const double x2i = w.WlLi[l * 14 + 7 + ci], x2j = w.WlLi[l * 14 + 7 + cj];
+                a1 += x1lo * (rd[l] * x1hi);
+                a2 += x1i * (rd[l] * x2j); a3 += x2i * (rd[l] * x2j);
             }
-            wsync();
-        } else {
-            if (lane < 49) { o.Pt[lane] = 0.0; o.G[lane] = 0.0; o.Minv[lane] = 0.0; fac[F_G + lane] = 0.0; fac[F_MINV + lane] = 0.0; if (keep_pt) fac[F_PT + lane] = 0.0; }
+            const double pt = dyn ? w.Pn[lo * 7 + hi] - a1 : 0.0;
+            a2 = dyn ? a2 : 0.0; a3 = dyn ? a3 : 0.0;
+            *(on ? &o.Pt[lane] : &w.sink[lane]) = pt;
+            *(on ? &o.G[lane] : &w.sink[lane]) = a2;
+            *(on ? &o.Minv[lane] : &w.sink[lane]) = a3;
+            const int fb = s.o_fac + k * FAC_N;
+            ustore(s.ws, on ? fb + F_G + lane : sink_e, a2);
+            ustore(s.ws, on ? fb + F_MINV + lane : sink_e, a3);
+            if (keep_pt) ustore(s.ws, on ? fb + F_PT + lane : sink_e, pt);
             wsync();
         }
         FT_MARK(3)
@@ -1222,19 +1257,42 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
             }
             w.Pn[lane] = a1;
         }
-        if (lane < 21) {
-            const int r = lane / 7, c = lane - 7 * r;
-            const double kg = Qi[r * 3] * w.Quy[c] + Qi[r * 3 + 1] * w.Quy[7 + c] + Qi[r * 3 + 2] * w.Quy[14 + c];
-            o.Kg[lane] = kg; fac[F_KG + lane] = kg; fac[F_BH + lane] = o.F[(lane / 3) * FS + 7 + lane % 3];
+        // (Qi is indexed with constants only and picked by selects: a register array indexed by a lane-dependent value
+        //  is placed in scratch memory, and its store / load pair would sit behind an s_waitcnt vmcnt(0) in every node)
+        {
+            // gain Kg = Qi Quy (lanes 0..20) and the node's record entries Kg, Bh, Qi: branch-free (see ustore)
+            const bool on21 = lane < 21;
+            const int l21 = on21 ? lane : 0;
+            const int r = l21 / 7, c = l21 - 7 * r;
+            const double q0 = w.Quy[c], q1 = w.Quy[7 + c], q2 = w.Quy[14 + c];
+            const double k0 = Qi[0] * q0 + Qi[1] * q1 + Qi[2] * q2, k1 = Qi[3] * q0 + Qi[4] * q1 + Qi[5] * q2,
+                         k2 = Qi[6] * q0 + Qi[7] * q1 + Qi[8] * q2;
+            const double kg = (r == 0) ? k0 : (r == 1 ? k1 : k2);
+            *(on21 ? &o.Kg[lane] : &w.sink[lane]) = kg;
+            const int fb = s.o_fac + k * FAC_N;
+            ustore(s.ws, on21 ? fb + F_KG + lane : sink_e, kg);
+            ustore(s.ws, on21 ? fb + F_BH + lane : sink_e, o.F[(l21 / 3) * FS + 7 + l21 % 3]);
+            double qv = Qi[0];
+#pragma unroll
+            for (int e = 1; e < 9; ++e) qv = (lane == e) ? Qi[e] : qv;
+            ustore(s.ws, lane < 9 ? fb + F_QI + lane : sink_e, qv);
         }
-        if (lane < 9) fac[F_QI + lane] = Qi[lane];
         // stiff stage terms (rare: an active r_min plane / radius or thrust ball late in the iteration): rank-1 update of
         // what was just written; out of line so that the common path keeps its register allocation
         if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) stiff_stage_update(o, w, fac, lane);
         FT_MARK(6)
         FT_MARK(7)
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)
-        if (fuse_sweep) cur = dyn ? chan_mask(nraw, sc, sr, sact) : chan_inputs(s, sd, K - 1, sc, sr, sact);
+        if (fuse_sweep) {
+            // (the terminal node's inputs come through the same branch-free fetch: a conditional load here would make
+            //  the first use of `cur` in the next node wait with vmcnt(0), i.e. for that node's whole prefetch)
+            cur = chan_mask(nraw, sc, sr, sact);
+            if (!dyn) {
+                const double tg = (sc == 2) ? sd.avt[srr] : sd.ta[sc >= 3 ? sc - 3 : 0][srr];
+                cur.gx = (sact && sc >= 2) ? tg : cur.gx;
+                cur.rho = 0.0; cur.aff = 0.0;
+            }
+        }
         FT_MARK(8)
         // a breakdown (every lane sees the same pivots) ends the sweep here: the caller retries with a larger delta_w
         if (!__all(good)) break;
@@ -1287,7 +1345,7 @@ __device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int la
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
 __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
-    const Sat s = s_in;
+    const Sat s = uniform_view(s_in);
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
     const bool act = (c >= c0 && c < c1) && r < 7;
@@ -1341,7 +1399,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
 // accumulates the border coefficients (Sigma.lam, x_K).
 __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
 {
-    const Sat s = s_in;
+    const Sat s = uniform_view(s_in);
     const int K = s.K;
     const int c = lane >> 3, r = lane & 7;
     const bool act = (c >= c0 && c < c1) && r < 7;
@@ -1394,17 +1452,18 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
 #pragma unroll
         for (int q = 0; q < 7; ++q) nu -= Gcol[q] * __shfl(yh, q, 8) + Mrow[q] * __shfl(wv, q, 8);
         FT_MARK(12)
-        if (act) {
-            gf64 *tr = s.traj + ((size_t)k * NCH + c) * TR_N;
-            tr[T_X + r] = x;
-            if (r < 3) tr[T_U + r] = u;
-            if (k == K - 1) sd.xK[c][r] = x;
-            if (dyn) {
-                const double lam = Dr * nu + cur.rho;
-                tr[T_NU + r] = nu; tr[T_LAM + r] = lam;
-                siglam += sgc * lam;
-                y = yh + nu;
-            }
+        {
+            // the channel's trajectory at this node: branch-free stores (see ustore)
+            const int tb = s.o_traj + (k * NCH + c) * TR_N, sink_t = s.o_sink + lane;
+            const double lam = Dr * nu + cur.rho;
+            const bool ad = act && dyn;
+            ustore(s.ws, act ? tb + T_X + r : sink_t, x);
+            ustore(s.ws, (act && r < 3) ? tb + T_U + r3 : sink_t, u);
+            ustore(s.ws, ad ? tb + T_NU + r : sink_t, nu);
+            ustore(s.ws, ad ? tb + T_LAM + r : sink_t, lam);
+            if (act && k == K - 1) sd.xK[c][r] = x;
+            siglam += ad ? sgc * lam : 0.0;
+            y = ad ? yh + nu : y;
         }
         FT_MARK(13)
         if (k + 1 < K) {
@@ -1428,7 +1487,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
 // right-hand side carries no multipliers); otherwise (refinement) the correction is added.
 __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int lane, bool first)
 {
-    const Sat s = s_in;
+    const Sat s = uniform_view(s_in);
     const int K = s.K, KP = s.KP;
     double sol[NBD];
 #pragma unroll
@@ -1988,6 +2047,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     const int KP = padded_nodes(K);
     s.KP = KP;
     gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
+    s.ws = ws;
     s.it = ws; ws += (size_t)KP * IT_N;
     s.dr = ws; ws += (size_t)KP * IT_N;
     s.itB = ws; ws += (size_t)KP * IT_N;
@@ -2000,7 +2060,12 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     s.traj = ws; ws += (size_t)K * NCH * TR_N;
     s.itg = ws; ws += GL_N;
     s.drg = ws; ws += GL_N;
-    s.itgB = ws;
+    s.itgB = ws; ws += GL_N;
+    s.sink = ws;
+    // (offsets as integers computed from the layout, not as pointer differences: the compiler would fold base + (sink -
+    //  base) back into a second pointer and emit a branch with one store per path)
+    s.o_fac = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N);
+    s.o_ch = s.o_fac + K * FAC_N; s.o_traj = s.o_ch + K * CH_N; s.o_sink = s.o_traj + K * NCH * TR_N + 3 * GL_N;
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
