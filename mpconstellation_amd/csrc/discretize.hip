@@ -46,14 +46,15 @@ struct RhsCtx {
     int Ku, flags, c;
     double tf;
     SatConst cst;
+    FohCache foh;        // the thrust table's interval in use (see foh3_cached)
 };
 
 // One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.
-__device__ __forceinline__ void rhs_eval(const RhsCtx &p, const double (&ys)[7], double ts,
+__device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], double ts,
                                          double (&out)[7], int &err)
 {
     double u[3];
-    foh3(ts, p.us, p.Ku, u, err);
+    foh3_cached(ts, p.us, p.Ku, p.foh, u, err);
     const double rx = __shfl(ys[0], 7, 8), ry = __shfl(ys[1], 7, 8), rz = __shfl(ys[2], 7, 8);
     const double m = __shfl(ys[6], 7, 8);
     double G[3][3], gm[3];
@@ -129,7 +130,7 @@ __device__ __forceinline__ bool lu_solve6(double (&P)[6][6], double (&b)[6])
 
 // Quadrature integrand column of this lane at an accepted node (linearize_discretize.py:60-75):
 // g = Phi(t)^-1 [B lam-, B lam+, Sigma, xi][:, c]
-__device__ __forceinline__ void node_integrand(const RhsCtx &p, double *rec, const double (&y)[7],
+__device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const double (&y)[7],
                                                double t, double tau_k, double tau_kp1,
                                                double (&g)[7], int &err)
 {
@@ -138,7 +139,7 @@ __device__ __forceinline__ void node_integrand(const RhsCtx &p, double *rec, con
 #pragma unroll
     for (int i = 0; i < 7; ++i) x[i] = __shfl(y[i], 7, 8);
     double u[3];
-    foh3(t, p.us, p.Ku, u, err);
+    foh3_cached(t, p.us, p.Ku, p.foh, u, err);
     const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);
     const double lam_p = (t - tau_k) / (tau_kp1 - tau_k);
     const double tf = p.tf, m = x[6];
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
 
     RhsCtx p;
     p.us = a.ubar + (size_t)s * 3 * a.Ku;
-    p.Ku = a.Ku; p.flags = a.flags; p.c = c;
+    p.Ku = a.Ku; p.flags = a.flags; p.c = c; p.foh.reset();
     p.tf = a.tf[s];
     p.cst.load(a.consts + (size_t)s * MPCX_NCONST);
     const double *xs = a.xbar + (size_t)s * 7 * a.K;

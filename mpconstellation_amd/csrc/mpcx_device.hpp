@@ -73,6 +73,47 @@ __device__ __forceinline__ void foh3(double tau, const double *__restrict__ u, i
     out[2] = lam_n * u[2 * Ku + k] + lam_p * u[2 * Ku + k + 1];
 }
 
+// The same first-order hold with the interval in use kept in registers: the two table columns, the node index and the
+// interval's end points are reloaded / recomputed only when tau leaves the cached interval (an RK45 step is short
+// against 1/(Ku-1): the stages of a step and many steps in a row stay inside one interval).  Inside -- away from both
+// ends by more than any rounding of the index computation -- k is certain and the result is bit for bit foh3's (same
+// expressions for lam_n, lam_p); otherwise foh3's own index computation decides.  Saves the fmod of py_floordiv and six
+// dependent global loads per right-hand side.
+struct FohCache {
+    int k;
+    double tau_k, tau_kp1, uk[3], uk1[3];
+    __device__ __forceinline__ void reset() { k = -1; tau_k = 2.0; tau_kp1 = -1.0; }
+};
+
+__device__ __forceinline__ void foh3_cached(double tau, const double *__restrict__ u, int Ku, FohCache &c, double (&out)[3],
+                                            int &err)
+{
+    if (tau == 1.0) {
+        out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1];
+        return;
+    }
+    if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
+        const double km1 = (double)(Ku - 1);
+        const double dtau = 1.0 / km1;
+        int k = (int)py_floordiv(tau, dtau);
+        if (k < 0 || k + 1 >= Ku) {          // the reference raises IndexError here
+            err = MPCX_ST_FOH;
+            k = k < 0 ? 0 : Ku - 2;
+            if (Ku < 2) { out[0] = out[1] = out[2] = 0.0; return; }
+        }
+        if (k != c.k) {
+            c.k = k;
+            c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * Ku + k]; c.uk1[i] = u[i * Ku + k + 1]; }
+        }
+    }
+    const double lam_n = (c.tau_kp1 - tau) / (c.tau_kp1 - c.tau_k);
+    const double lam_p = (tau - c.tau_k) / (c.tau_kp1 - c.tau_k);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
+}
+
 struct SatConst {
     double mu, re, j2, g0, isp, s, r0, rho;
     __device__ __forceinline__ void load(const double *__restrict__ c)
