@@ -66,6 +66,12 @@ int mpcx_create(int device, mpcx_ctx **out);
 void mpcx_destroy(mpcx_ctx *ctx);
 const char *mpcx_last_error(const mpcx_ctx *ctx); /* ctx may be NULL: last create error */
 int mpcx_synchronize(mpcx_ctx *ctx, void *stream);
+/* Page-locked host memory for the arrays a caller hands to the host-pointer entry points again and again (the reference
+ * keeps x_bar / u_bar / results in numpy arrays, optimizer.py:13-39, 192-217; a numpy array can live in such a buffer).
+ * Arrays in page-locked memory are transferred by DMA straight from / to the caller's buffer; pageable ones go through the
+ * context's own page-locked staging (an extra host copy each way). */
+void *mpcx_host_alloc(mpcx_ctx *ctx, size_t bytes);
+void mpcx_host_free(mpcx_ctx *ctx, void *p);
 
 /*
  * Replaces Discretizer.discretize (linearize_discretize.py:334-390), i.e. get_matrices (:8-82)

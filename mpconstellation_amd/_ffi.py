@@ -47,6 +47,8 @@ _SIGS = {
     "mpcx_destroy": (None, [_vp]),
     "mpcx_last_error": (C.c_char_p, [_vp]),
     "mpcx_synchronize": (C.c_int, [_vp, _vp]),
+    "mpcx_host_alloc": (_vp, [_vp, C.c_size_t]),
+    "mpcx_host_free": (None, [_vp, _vp]),
     "mpcx_discretize_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                         C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "mpcx_discretize_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
@@ -104,6 +106,42 @@ def context(device=0, slot=0):
                                 f"{lib.mpcx_last_error(None).decode()}")
             _ctxs[device] = h
         return _ctxs[device]
+
+
+class _PinnedOwner:
+    """keeps a page-locked allocation alive as long as a numpy array views it"""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr = ctx, ptr
+        self.buf = (C.c_char * nbytes).from_address(ptr)
+
+    def __del__(self):
+        try:
+            load().mpcx_host_free(self.ctx, self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64, device=0):
+    """numpy array in page-locked host memory (mpcx_host_alloc): the host-pointer entry points transfer such arrays by DMA
+    without a staging copy.  Use it for arrays handed to mpc_step_batch / solve_batch repeatedly."""
+    lib = load(); ctx = context(device)
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = lib.mpcx_host_alloc(ctx, max(n, 1))
+    if not ptr:
+        raise MpcxError(f"mpcx_host_alloc({n}) failed: {lib.mpcx_last_error(ctx).decode()}")
+    owner = _PinnedOwner(ctx, ptr, max(n, 1))
+    owner.buf._mpcx_owner = owner            # the array keeps buf alive, buf keeps the allocation's owner alive
+    arr = np.frombuffer(owner.buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    return arr
+
+
+def pinned_copy(a, device=0):
+    a = np.asarray(a)
+    out = pinned_empty(a.shape, a.dtype, device)
+    out[...] = a
+    return out
 
 
 def check(rc, ctx, what):

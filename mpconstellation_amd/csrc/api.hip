@@ -68,3 +68,18 @@ extern "C" int mpcx_synchronize(mpcx_ctx *ctx, void *stream)
     MPCX_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return MPCX_OK;
 }
+
+extern "C" void *mpcx_host_alloc(mpcx_ctx *ctx, size_t bytes)
+{
+    if (!ctx || !bytes) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { ctx_fail(ctx, MPCX_E_NOMEM, "page-locked allocation failed"); return nullptr; }
+    return p;
+}
+
+extern "C" void mpcx_host_free(mpcx_ctx *ctx, void *p)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (p) (void)hipHostFree(p);
+}

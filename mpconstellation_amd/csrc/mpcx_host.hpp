@@ -97,10 +97,23 @@ class DeviceArena {
         if (!p) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "device staging allocation failed"); return nullptr; }
         return (T *)p;
     }
+    // true if the caller's buffer is page-locked (mpcx_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads /
+    // writes it directly, no staging copy
+    static bool is_pinned(const void *h)
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    }
     template <typename T> T *upload(const T *h, size_t n)
     {
         T *d = alloc<T>(n);
         if (!d) return nullptr;
+        if (is_pinned(h)) {
+            hipError_t e = hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
+            if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+            return d;
+        }
         void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
         if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return nullptr; }
         memcpy(pin, h, n * sizeof(T));
@@ -111,6 +124,11 @@ class DeviceArena {
     template <typename T> void download(T *h, const T *d, size_t n)
     {
         if (code_ || !h) return;
+        if (is_pinned(h)) {
+            hipError_t e = hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
+            if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+            return;
+        }
         void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
         if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return; }
         hipError_t e = hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);

@@ -29,6 +29,23 @@ def _solver_flags(solver, linear_vt, fixed_tf=None):
     return solver
 
 
+_pinned_results = {}
+
+
+def _result_arrays(S, K, device, pinned):
+    """X, U, NU, kkt, status, iters for one call.  pinned: page-locked buffers owned by this module and REUSED by the next
+    call of the same shape on the device (results are DMA targets, no staging copy; copy what must outlive the next call)."""
+    if not pinned:
+        return (np.empty((S, 7, K)), np.empty((S, 3, K)), np.empty((S, 7, K)), np.empty(S), np.zeros(S, dtype=np.int32),
+                np.zeros(S, dtype=np.int32))
+    key = (S, K, device)
+    if key not in _pinned_results:
+        _pinned_results[key] = (_ffi.pinned_empty((S, 7, K), device=device), _ffi.pinned_empty((S, 3, K), device=device),
+                                _ffi.pinned_empty((S, 7, K), device=device), _ffi.pinned_empty((S,), device=device),
+                                _ffi.pinned_empty((S,), np.int32, device), _ffi.pinned_empty((S,), np.int32, device))
+    return _pinned_results[key]
+
+
 def _tf_io(S, fixed_tf):
     """tf_out buffer: plain output, or (fixed-tf mode) the values to hold on entry and g_s on exit"""
     if fixed_tf is None:
@@ -38,9 +55,11 @@ def _tf_io(S, fixed_tf):
 
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, fixed_tf=None, **solver):
+                   linear_vt=False, fixed_tf=None, pinned_results=False, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
-    xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays."""
+    xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
+    Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
+    returns the results in page-locked buffers that the next call of the same shape overwrites."""
     solver = _solver_flags(solver, linear_vt, fixed_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
@@ -50,9 +69,8 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
     consts = _ffi.as_f64(consts)
     opts = _ffi.make_solve_opts(options, **solver)
-    X = np.empty((S, 7, K)); U = np.empty((S, 3, K)); NU = np.empty((S, 7, K)); kkt = np.empty(S)
+    X, U, NU, kkt, status, iters = _result_arrays(S, K, device, pinned_results and slot == 0)
     tfo, held = _tf_io(S, fixed_tf)
-    status = np.zeros(S, dtype=np.int32); iters = np.zeros(S, dtype=np.int32)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
     rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),

@@ -172,3 +172,21 @@ def test_optimizer_class_drop_in(golden_dir):
     sim = Simulator(sats=[sat], controller=c_opt, scale=scale, base_res=10, include_drag=False, include_J2=False)
     sim.run(tf=5)
     assert sim.sim_data[sat.id].shape == (7, 50) and np.isfinite(sim.sim_data[sat.id]).all()
+
+
+def test_page_locked_arrays_give_the_same_result(golden_dir):
+    """mpcx_host_alloc: caller arrays in page-locked memory are transferred without the staging copy; same results bit for
+    bit, and the result buffers of pinned_results=True are reused by the next call of the same shape."""
+    from mpconstellation_amd import mpc_step_batch, _ffi
+    c64 = np.load(os.path.join(golden_dir, "constellation64.npz"))
+    idx = list(c64["idx"])
+    x = np.stack([c64[f"x_{i}"] for i in idx]); u = np.stack([c64[f"u_{i}"] for i in idx])
+    cs = np.stack([c64[f"const_{i}"] for i in idx]); tf = np.ones(len(idx))
+    r_des = np.linalg.norm(x[:, :3, -1], axis=1)
+    a = mpc_step_batch(x, u, tf, cs, r_des)
+    px, pu, pc, pt, pr = (_ffi.pinned_copy(v) for v in (x, u, cs, tf, r_des))
+    b = mpc_step_batch(px, pu, pt, pc, pr, pinned_results=True)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.U, b.U) and np.array_equal(a.tf, b.tf) and np.array_equal(a.iters, b.iters)
+    keep = b.X.copy()
+    c = mpc_step_batch(px, pu, pt, pc, pr, pinned_results=True)
+    assert c.X is b.X and np.array_equal(c.X, keep)
