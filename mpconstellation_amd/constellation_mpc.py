@@ -18,6 +18,7 @@ import numpy as np
 
 from . import _ffi
 from .constellation import tangential_thrust
+from .control import _check_solver_status
 from .optimizer import mpc_step_batch
 from .satellite_scale import SatelliteScale
 from .simulator import propagate_batch
@@ -74,7 +75,7 @@ def _rollouts(jobs, device):
 
 class ConstellationMPC:
     def __init__(self, sats, base_res=100, tf_horizon=1, tf_interval=1, r_des=1.5, scp_iterations=2, sim_base_res=100,
-                 include_drag=True, include_J2=True, device=0):
+                 include_drag=True, include_J2=True, device=0, strict=False):
         self.sats = list(sats)
         self.scales = [SatelliteScale(sat=s) for s in self.sats]
         self.consts = np.stack([sc.get_normalized_constants().as_vector() for sc in self.scales])
@@ -84,6 +85,7 @@ class ConstellationMPC:
         self.scp_iterations = scp_iterations
         self.include_drag, self.include_J2 = include_drag, include_J2
         self.device = device
+        self.strict = strict                  # raise instead of warning when a solve does not converge (control.py mirror)
         self.sim_data, self.sim_time = {}, {}
         self.last_status = None
         self.plan_u, self.plan_tf, self.plan_x = None, None, None
@@ -117,6 +119,7 @@ class ConstellationMPC:
             for Kg, res in zip(keys, solved):
                 idx = groups[Kg]
                 self.last_status[it, idx] = res.status
+                _check_solver_status(res.status, self.strict)
                 tf_u[idx] = res.tf
                 for j, s in enumerate(idx):
                     plan_u[s] = res.U[j]; plan_x[s] = res.X[j]

@@ -6,6 +6,17 @@ import numpy as np
 from . import _ffi
 
 
+def _check_solver_status(status, strict):
+    """the plan of a solve that ended neither OK (0) nor at the acceptable level (7) is not silently flown"""
+    import warnings
+    bad = [int(c) for c in np.atleast_1d(status) if c not in (0, 7)]
+    if bad:
+        msg = f"MPC solve did not converge: status {[_ffi.STATUS_TEXT.get(c, c) for c in bad]}"
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 class Controller:
     """Zero thrust (reference control.py:8-35)."""
 
@@ -99,7 +110,7 @@ class OptimalController(Controller):
     + nonlinear re-rollout) with the discretize+solve step on the device."""
 
     def __init__(self, sats=[], objective=None, base_res=100, tf_horizon=1, tf_interval=1, plot_inter=True,
-                 opt_verbose=True, r_des=1.5):
+                 opt_verbose=True, r_des=1.5, strict=False):
         super().__init__(sats)
         from .satellite_scale import SatelliteScale
         self.u = np.zeros((3, 1))
@@ -113,6 +124,10 @@ class OptimalController(Controller):
         self.plot_intermediate = plot_inter
         self.opt_verbose = opt_verbose
         self.last_status = []
+        # The reference never looks at ipopt's return status (optimizer.py:603).  Here a solve that ends neither OK nor at
+        # the acceptable level always warns (RuntimeWarning, whatever opt_verbose says) and, with strict=True, raises
+        # instead of flying an unconverged plan.
+        self.strict = strict
 
     def update(self):
         from . import simulator
@@ -134,6 +149,7 @@ class OptimalController(Controller):
             opt = Optimizer([x], [u_bar], [nu_bar], tf_u, d, f, self.scale, verbose=self.opt_verbose)
             opt.solve_OPT(input_options=opt_options)
             self.last_status.append(int(opt.status[0]))
+            _check_solver_status(opt.status, self.strict)
             tf_u = opt.get_solved_tf(0)
             u_opt = opt.get_solved_u(0)
             nu_opt = opt.get_solved_nu(0)

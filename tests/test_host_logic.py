@@ -190,3 +190,15 @@ def test_two_rank_gloo_sharding():
     assert all(p.exitcode == 0 for p in procs)
     assert np.array_equal(full, constellation_states(11))
     assert abs(tmax - 0.2) < 1e-12
+
+
+def test_unconverged_plans_are_not_flown_silently():
+    import warnings
+    from mpconstellation_amd.control import _check_solver_status
+    _check_solver_status(np.array([0, 7, 0]), strict=True)                 # OK / acceptable: nothing happens
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _check_solver_status(np.array([0, 5]), strict=False)
+    assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning) and "max_iter" in str(w[0].message)
+    with pytest.raises(RuntimeError):
+        _check_solver_status(np.array([6]), strict=True)
