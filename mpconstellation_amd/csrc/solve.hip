@@ -127,6 +127,41 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Value of lane q of the caller's 8-lane group in all 8 lanes, q a constant after unrolling: two v_mov_b32_dpp per 32-bit
+// half (quad_perm broadcast inside q's quad, then row_half_mirror -- lane i <-> 7 - i of the group -- into the other
+// quad under a bank mask) instead of the ds_bpermute_b32 pair gshfl8(v, q) compiles to.  The sweeps exchange ~70
+// doubles per node this way; as ds_bpermute they were 40 % of the kernel's LDS instructions, and at two waves per SIMD
+// the CU's LDS pipe (shared by its four SIMDs) is the resource the kernel saturates first (profiles/r02/pmc_sq.json:
+// SQ_ACTIVE_INST_LDS).  Checked against __shfl for every q by profiles/tools/dpp_bcast_check.hip.
+template <int Q>
+__device__ __forceinline__ int bcast8_i(int v)
+{
+    constexpr int qp = (Q & 3) * 0x55;                         // quad_perm: [q%4, q%4, q%4, q%4]
+    const int t = __builtin_amdgcn_update_dpp(0, v, qp, 0xF, 0xF, false);
+    constexpr int other = (Q & 4) ? 0x5 : 0xA;                 // the banks (quads) that do not hold lane q
+    return __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, other, false);
+}
+template <int Q>
+__device__ __forceinline__ double bcast8(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = bcast8_i<Q>((int)b), hi = bcast8_i<Q>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double gshfl8(double v, int q)
+{
+    switch (q) {
+    case 0: return bcast8<0>(v);
+    case 1: return bcast8<1>(v);
+    case 2: return bcast8<2>(v);
+    case 3: return bcast8<3>(v);
+    case 4: return bcast8<4>(v);
+    case 5: return bcast8<5>(v);
+    case 6: return bcast8<6>(v);
+    default: return bcast8<7>(v);
+    }
+}
+
 // Barrier for the single-wave workgroups of this kernel when lanes exchange data through LDS only: DS operations of
 // one wave execute in issue order, so it is enough to stop the compiler from moving LDS accesses across this point.
 // Unlike __syncthreads() it does not drain outstanding global loads (the node-ahead prefetch stays in flight).
@@ -1034,7 +1069,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         for (int q = 0; q < 7; ++q) { sw_G[q] = o.G[srr * 7 + q]; sw_Pt[q] = o.Pt[srr * 7 + q]; }
         sw_v = cur.rho + pnext; sw_t = pnext;
     };
-    auto sweep_col = [&](int q) { sw_t += -sw_G[q] * __shfl(sw_v, q, 8) + sw_Pt[q] * __shfl(cur.aff, q, 8); };
+    auto sweep_col = [&](int q) { sw_t += -sw_G[q] * gshfl8(sw_v, q) + sw_Pt[q] * gshfl8(cur.aff, q); };
     auto sweep_finish = [&](const StageOps &o, int j, double &pp, double &qu) {
         const bool dynj = (j <= K - 2);
         double Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
@@ -1046,13 +1081,13 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         if (!dynj || !sact) tt = 0.0;
         qu = cur.gu;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(tt, q, 8);
+        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * gshfl8(cur.gx, q) + Bhcol[q] * gshfl8(tt, q);
         if (sr >= 3 || !sact) qu = 0.0;
         pp = cur.gx;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) pp += Acol[q] * __shfl(tt, q, 8);
+        for (int q = 0; q < 7; ++q) pp += Acol[q] * gshfl8(tt, q);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * __shfl(qu, q, 8);
+        for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * gshfl8(qu, q);
     };
     const int sink_e = s.o_sink + lane;                       // this lane's sink slot (element offset in the workspace)
     auto sweep_store = [&](int j, double pp, double qu) {
@@ -1371,17 +1406,17 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
         const double v = cur.rho + pnext;
         double t = pnext;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) t += -Grow[q] * __shfl(v, q, 8) + Ptrow[q] * __shfl(cur.aff, q, 8);
+        for (int q = 0; q < 7; ++q) t += -Grow[q] * gshfl8(v, q) + Ptrow[q] * gshfl8(cur.aff, q);
         if (!dyn || !act) t = 0.0;
         double qu = cur.gu;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * __shfl(cur.gx, q, 8) + Bhcol[q] * __shfl(t, q, 8);
+        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * gshfl8(cur.gx, q) + Bhcol[q] * gshfl8(t, q);
         if (r >= 3 || !act) qu = 0.0;
         double p = cur.gx;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) p += Acol[q] * __shfl(t, q, 8);
+        for (int q = 0; q < 7; ++q) p += Acol[q] * gshfl8(t, q);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) p -= Kgcol[q] * __shfl(qu, q, 8);
+        for (int q = 0; q < 3; ++q) p -= Kgcol[q] * gshfl8(qu, q);
         if (act) {
             gf64 *ch = s.ch + (size_t)k * CH_N;
             ch[C_P + c * 7 + r] = p;
@@ -1436,21 +1471,21 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
         const double Dr = f[F_D + rr];
         double u = 0.0;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) u -= Kgrow[q] * __shfl(y, q, 8);
+        for (int q = 0; q < 7; ++q) u -= Kgrow[q] * gshfl8(y, q);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) u -= Qirow[q] * __shfl(quc, q, 8);
+        for (int q = 0; q < 3; ++q) u -= Qirow[q] * gshfl8(quc, q);
         if (r >= 3 || !act) u = 0.0;
         double x = y, yh = cur.aff;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const double uq = __shfl(u, q, 8); x += Bpmrow[q] * uq; yh += Bhrow[q] * uq; }
+        for (int q = 0; q < 3; ++q) { const double uq = gshfl8(u, q); x += Bpmrow[q] * uq; yh += Bhrow[q] * uq; }
 #pragma unroll
-        for (int q = 0; q < 7; ++q) yh += Arow[q] * __shfl(y, q, 8);
+        for (int q = 0; q < 7; ++q) yh += Arow[q] * gshfl8(y, q);
         if (!dyn || !act) yh = 0.0;
         FT_MARK(11)
         const double wv = cur.rho + pnc;
         double nu = 0.0;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) nu -= Gcol[q] * __shfl(yh, q, 8) + Mrow[q] * __shfl(wv, q, 8);
+        for (int q = 0; q < 7; ++q) nu -= Gcol[q] * gshfl8(yh, q) + Mrow[q] * gshfl8(wv, q);
         FT_MARK(12)
         {
             // the channel's trajectory at this node: branch-free stores (see ustore)

@@ -2,8 +2,9 @@
 usage: python profiles/tools/ab_timing.py libA.so libB.so [workload ...]"""
 import os, sys, subprocess
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-libs = [os.path.abspath(a) for a in sys.argv[1:3]]
-wls = sys.argv[3:] or ["S64_K30", "S4096_K30"]
+nl = 3 if len(sys.argv) > 3 and sys.argv[3].endswith(".so") else 2
+libs = [os.path.abspath(a) for a in sys.argv[1:1 + nl]]
+wls = sys.argv[1 + nl:] or ["S64_K30", "S4096_K30"]
 code = '''
 import sys
 sys.path.insert(0, "%s")
