@@ -207,3 +207,25 @@ def test_config4_per_gpu_share():
     assert np.array_equal(xb, run.host["xbar"])
     res = mpc_step_batch(xb[pick], ub[pick], np.ones(len(pick)), cs[pick], rd[pick])
     assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])
+
+
+@pytest.mark.parametrize("K,tf,r_des", [(30, 1.0, 1.5), (30, 2.0, 1.2), (60, 2.0, 1.5), (30, 1.0, 1.05)])
+def test_optimal_controller_option_set_converges(K, tf, r_des):
+    """The options OptimalController passes (control.py:192-197: eps_r 1e-6, eps_vr 1e-16, tf_max = horizon, fixed r_des) on
+    512 satellites of the constellation: every problem ends with status 0 (round 1: up to 40 % at MAXITER, the rest only
+    'acceptable' -- the structured linear solve lost the digits these stiff terminal windows need)."""
+    from mpconstellation_amd import mpc_step_batch, _ffi
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
+    from mpconstellation_amd.simulator import propagate_batch
+    S = 512
+    y0, consts = normalize_batch(constellation_states(4096, first=0, count=S))
+    xbar, st, _ = propagate_batch(y0, np.full(S, tf), consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K)
+    assert (st == 0).all()
+    ubar = np.ascontiguousarray(tangential_thrust(xbar, 0.5))
+    opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": tf}
+    res = mpc_step_batch(xbar, ubar, np.full(S, tf), consts, np.full(S, r_des), options=opts)
+    assert (res.status == 0).all() and res.kkt.max() <= 1e-8
+    assert res.iters.mean() <= 22 and res.iters.max() <= 60
+    rK = np.linalg.norm(res.X[:, :3, -1], axis=1)
+    assert np.abs(rK - r_des).max() <= 1e-6 + 2e-8                     # the eps_r window (with ipopt's 1e-8 relaxation)
+    assert (res.tf <= tf * (1 + 1e-8) + 1e-8).all()
