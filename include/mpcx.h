@@ -49,6 +49,11 @@ extern "C" {
 /* dynamics flags (reference include_drag / include_J2 keyword arguments) */
 #define MPCX_FLAG_DRAG 1
 #define MPCX_FLAG_J2 2
+/* discretize entry points only: Discretizer.use_uniform_steps (linearize_discretize.py:27-30, 50-53) with
+ * integrator_steps = n: flags |= MPCX_FLAG_UNIFORM_STEPS | MPCX_UNIFORM_STEPS(n).  The quadrature then runs over n uniform
+ * points per interval of the RK45 dense output instead of the accepted step nodes. */
+#define MPCX_FLAG_UNIFORM_STEPS 4
+#define MPCX_UNIFORM_STEPS(n) ((n) << 8)
 
 /* normalised constants per satellite: reference constants.py:11-20 field order */
 enum { MPCX_C_MU = 0, MPCX_C_R_E, MPCX_C_J2, MPCX_C_G0, MPCX_C_ISP, MPCX_C_S, MPCX_C_R0,

@@ -14,7 +14,7 @@ STATUS_TEXT = {
     3: "FOH index outside the input table", 4: "state-transition matrix singular",
     5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
 }
-FLAG_DRAG, FLAG_J2 = 1, 2
+FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS = 1, 2, 4
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
 NCONST = 8
 STAGE_DOUBLES = 105

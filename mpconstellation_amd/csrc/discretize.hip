@@ -207,7 +207,10 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const dou
     g[6] = R[6];
 }
 
-template <int LAYOUT>
+// UNIFORM: Discretizer.use_uniform_steps (linearize_discretize.py:27-30, 50-53): the quadrature nodes are integrator_steps
+// uniform points per interval taken from the RK45 dense-output interpolant (scipy's t_eval branch), A_k the interpolant
+// at the last of them; a separate instantiation, the default path is untouched.
+template <int LAYOUT, bool UNIFORM>
 #ifndef MPCX_DISC_WAVES
 #define MPCX_DISC_WAVES 1      // waves per SIMD the register allocation is bounded for (360 registers at 1)
 #endif
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
 
     RhsCtx p;
     p.us = a.ubar + (size_t)s * 3 * a.Ku;
-    p.Ku = a.Ku; p.flags = a.flags; p.c = c; p.foh.reset();
+    p.Ku = a.Ku; p.flags = a.flags & (MPCX_FLAG_DRAG | MPCX_FLAG_J2); p.c = c; p.foh.reset();
+    const int n_uni = UNIFORM ? (a.flags >> 8) : 0;                 // integrator_steps
     p.tf = a.tf[s];
     p.cst.load(a.consts + (size_t)s * MPCX_NCONST);
     const double *xs = a.xbar + (size_t)s * 7 * a.K;
@@ -282,6 +286,13 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
 #pragma unroll
     for (int i = 0; i < 7; ++i) acc[i] = 0.0;
     node_integrand(p, rec, y, t, tau_k, tau_kp1, gprev, err);
+
+    // uniform mode: index of the next evaluation point, time of the previous one, the interpolated state at it
+    const double ustep = UNIFORM ? (tau_kp1 - tau_k) / (double)(n_uni - 1) : 0.0;   // np.linspace(tau_k, tau_kp1, n)
+    int ei = 1;                                                    // (point 0 = tau_k: the start state itself, done above)
+    double te_prev = tau_k, ylast[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ylast[i] = y[i];
 
     // ---- adaptive RK45 (rk.py:110-168); retry-after-reject folded into the same loop ----
     bool rejected = false;
@@ -356,16 +367,59 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
             err = MPCX_ST_STEP;
             t = t_bound;
         }
+        double yold[7];
+        const double t_old = t;
         if (accept) {
             rejected = false;
-            const double t_old = t;
             t = t_new;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { y[i] = yn[i]; f[i] = K6[i]; }
-            (void)t_old;
+            for (int i = 0; i < 7; ++i) { yold[i] = y[i]; y[i] = yn[i]; }
+        }
+        if (UNIFORM) {
+            // scipy ivp.py: t_eval points with t_old < te <= t get sol(te) = y_old + h Q p(x), Q = K^T P, x = (te - t_old) / h
+            // (rk.py:552-574); each is a quadrature node.  Groups have different numbers of points in their step: the
+            // loop runs while any group has one (node_integrand is a wave-uniform call), the others idle.
+            if (__any(accept)) {
+                double Q[7][4];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const double kk[7] = {f[i], K1[i], K2[i], K3[i], K4[i], K5[i], K6[i]};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        double q = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < 7; ++jj) q += kk[jj] * RK_P[jj][cc];
+                        Q[i][cc] = q;
+                    }
+                }
+                for (;;) {
+                    const double te = (ei == n_uni - 1) ? tau_kp1 : (double)ei * ustep + tau_k;
+                    const bool has = accept && ei < n_uni && !(te > t);
+                    if (!__any(has)) break;
+                    const double xx = (te - t_old) / h;
+                    const double p1 = xx, p2 = p1 * xx, p3 = p2 * xx, p4 = p3 * xx;
+                    double yd[7], g[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        const double accq = Q[i][0] * p1 + Q[i][1] * p2 + Q[i][2] * p3 + Q[i][3] * p4;
+                        yd[i] = has ? h * accq + yold[i] : y[i];
+                    }
+                    node_integrand(p, rec, yd, has ? te : t, tau_k, tau_kp1, g, err);
+                    if (has) {
+                        const double d = te - te_prev;
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) { acc[i] += d * (g[i] + gprev[i]) / 2.0; gprev[i] = g[i]; ylast[i] = yd[i]; }
+                        te_prev = te; ++ei;
+                    }
+                }
+            }
+        }
+        if (accept) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) f[i] = K6[i];
         }
         // node quadrature (wave-uniform call; only accepting groups commit)
-        if (__any(accept)) {
+        if (!UNIFORM && __any(accept)) {
             double g[7];
             node_integrand(p, rec, y, t, tau_k, tau_kp1, g, err);
             if (accept) {
@@ -382,7 +436,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
     // ---- A_k = Phi(tau_k+1); B_k-, B_k+, Sigma_k, xi_k = A_k @ trapz (:43-44, :77-80) ----
     if (c < 7) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) rec[i * 7 + c] = y[i];
+        for (int i = 0; i < 7; ++i) rec[i * 7 + c] = UNIFORM ? ylast[i] : y[i];
     }
     __syncthreads();
     double out[7];
@@ -451,8 +505,16 @@ static int launch_discretize(mpcx_ctx *ctx, int layout, DiscArgs a, hipStream_t 
     MPCX_HIP(ctx, hipMemsetAsync(a.status, 0, sizeof(int32_t) * a.S, st));
     const long total = (long)a.S * (a.K - 1);
     const unsigned blocks = (unsigned)((total + 7) / 8);
-    if (layout == LAYOUT_STAGE) hipLaunchKernelGGL(discretize_kernel<LAYOUT_STAGE>, dim3(blocks), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(discretize_kernel<LAYOUT_REF>, dim3(blocks), dim3(64), 0, st, a);
+    const bool uni = (a.flags & MPCX_FLAG_UNIFORM_STEPS) != 0;
+    if (uni && (a.flags >> 8) < 2) return ctx_fail(ctx, MPCX_E_BADARG, "discretize: uniform steps need MPCX_UNIFORM_STEPS(n), n >= 2");
+    if (!uni) a.flags &= (MPCX_FLAG_DRAG | MPCX_FLAG_J2);
+    if (layout == LAYOUT_STAGE) {
+        if (uni) hipLaunchKernelGGL((discretize_kernel<LAYOUT_STAGE, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((discretize_kernel<LAYOUT_STAGE, false>), dim3(blocks), dim3(64), 0, st, a);
+    } else {
+        if (uni) hipLaunchKernelGGL((discretize_kernel<LAYOUT_REF, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((discretize_kernel<LAYOUT_REF, false>), dim3(blocks), dim3(64), 0, st, a);
+    }
     MPCX_HIP(ctx, hipGetLastError());
     return MPCX_OK;
 }

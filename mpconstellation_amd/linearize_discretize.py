@@ -46,6 +46,8 @@ class Discretizer:
         lib = _ffi.load()
         ctx = _ffi.context(self.device)
         flags = _ffi.FLAG_J2 if self.include_J2 else 0
+        if self.use_uniform_steps:                           # linearize_discretize.py:27-30: t_eval = linspace(.., integrator_steps)
+            flags |= _ffi.FLAG_UNIFORM_STEPS | (int(self.integrator_steps) << 8)
         rc = lib.mpcx_discretize_batch(ctx, S, K, Ku, _ffi.dptr(x), _ffi.dptr(u), _ffi.dptr(tf),
                                        _ffi.dptr(consts), flags, float(self.ivp_max_step),
                                        _ffi.dptr(A), _ffi.dptr(Bp), _ffi.dptr(Bn), _ffi.dptr(Sig),
@@ -78,8 +80,8 @@ class Discretizer:
             raise NotImplementedError("drag in the linearisation is not supported")
         if self.ivp_solver != 'RK45':
             raise NotImplementedError("only ivp_solver='RK45' is implemented on the device")
-        if self.use_uniform_steps:
-            raise NotImplementedError("use_uniform_steps=True is not implemented on the device")
+        if self.use_uniform_steps and int(self.integrator_steps) < 2:
+            raise ValueError("use_uniform_steps needs integrator_steps >= 2")
 
     @staticmethod
     def extract_uk(x_k, tau_k, controller):

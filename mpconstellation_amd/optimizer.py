@@ -55,7 +55,7 @@ def _tf_io(S, fixed_tf):
 
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, fixed_tf=None, pinned_results=False, **solver):
+                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
@@ -73,8 +73,11 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     tfo, held = _tf_io(S, fixed_tf)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
+    dflags = _ffi.FLAG_J2 if include_J2 else 0
+    if uniform_steps:                         # Discretizer.use_uniform_steps with integrator_steps = uniform_steps
+        dflags |= _ffi.FLAG_UNIFORM_STEPS | (int(uniform_steps) << 8)
     rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
-                                 _ffi.dptr(r_des), _ffi.FLAG_J2 if include_J2 else 0, float(max_step), C.byref(opts),
+                                 _ffi.dptr(r_des), dflags, float(max_step), C.byref(opts),
                                  _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
                                  _ffi.iptr(iters), _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
@@ -246,7 +249,8 @@ class Optimizer:
         else:
             self.result = mpc_step_batch(xbar, ubar, self.tf, consts, options['r_des'], options,
                                          include_J2=self.d.include_J2, max_step=self.d.ivp_max_step,
-                                         device=getattr(self.d, "device", 0), **solver)
+                                         device=getattr(self.d, "device", 0),
+                                         uniform_steps=int(self.d.integrator_steps) if self.d.use_uniform_steps else 0, **solver)
         self.status = self.result.status
         bad = [int(c) for c in self.result.status if c not in (0, 7)]
         if bad and self.verbose:

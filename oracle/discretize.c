@@ -68,7 +68,7 @@ static void linspace01(int K, int j, double *out) /* np.linspace(0, 1, K)[j] */
 
 /* get_matrices for one interval k: linearize_discretize.py:8-82 */
 static int get_matrices(int K, int Ku, const double *x, const double *u, double tf,
-                        const double *cst, int flags, double max_step, int k, double *A_k,
+                        const double *cst, int flags, double max_step, int n_uniform, int k, double *A_k,
                         double *B_kp, double *B_kn, double *Sigma_k, double *xi_k, int32_t *n_nodes,
                         int32_t *n_fev, double *dump_t, double *dump_y, int dump_cap)
 {
@@ -82,15 +82,33 @@ static int get_matrices(int K, int Ku, const double *x, const double *u, double 
     rk45 s;
     rk45_init(&s, 56, dphi, &ctx, tau_k, y0, tau_kp1, max_step, 1e-3, 1e-6);          /* :37-41 */
 
-    int cap = 64, n = 0;
+    int cap = n_uniform > 64 ? n_uniform + 1 : 64, n = 0;
     double *ts = malloc(cap * sizeof(double)), *ys = malloc(cap * 56 * sizeof(double));
-    ts[0] = tau_k; memcpy(ys, y0, sizeof y0); n = 1;
     int status = 0;
-    while (!(s.t == s.t_bound)) {
-        int r = rk45_step(&s);
-        if (r) { status = r; break; }
-        if (n == cap) { cap *= 2; ts = realloc(ts, cap * sizeof(double)); ys = realloc(ys, cap * 56 * sizeof(double)); }
-        ts[n] = s.t; memcpy(ys + n * 56, s.y, 56 * sizeof(double)); ++n;
+    if (n_uniform >= 2) {
+        /* use_uniform_steps (:27-30, :50-53): t_eval = np.linspace(tau_k, tau_kp1, integrator_steps); solve_ivp returns the
+         * dense-output interpolant at those points (ivp.py main loop: searchsorted(t_eval, t, side='right')), the quadrature
+         * nodes are the uniform points and A_k the interpolant at the last one */
+        const double ustep = (tau_kp1 - tau_k) / (double)(n_uniform - 1);
+        int ei = 0;
+        while (!(s.t == s.t_bound)) {
+            int r = rk45_step(&s);
+            if (r) { status = r; break; }
+            while (ei < n_uniform) {
+                double te = (ei == n_uniform - 1) ? tau_kp1 : (double)ei * ustep + tau_k;
+                if (te > s.t) break;
+                ts[n] = te; rk45_dense_eval(&s, te, ys + n * 56); ++n; ++ei;
+            }
+        }
+        if (n == 0) { ts[0] = tau_k; memcpy(ys, y0, sizeof y0); n = 1; }
+    } else {
+        ts[0] = tau_k; memcpy(ys, y0, sizeof y0); n = 1;
+        while (!(s.t == s.t_bound)) {
+            int r = rk45_step(&s);
+            if (r) { status = r; break; }
+            if (n == cap) { cap *= 2; ts = realloc(ts, cap * sizeof(double)); ys = realloc(ys, cap * 56 * sizeof(double)); }
+            ts[n] = s.t; memcpy(ys + n * 56, s.y, 56 * sizeof(double)); ++n;
+        }
     }
     if (ctx.foh_err) status = 3;
     if (s.fun_err && !status) status = 1;
@@ -164,11 +182,21 @@ int oracle_discretize(int K, int Ku, const double *x, const double *u, double tf
                       double *xi, int32_t *node_counts, int32_t *node_nfev, double *node_t,
                       double *node_y, int node_cap)
 {
+    return oracle_discretize_mode(K, Ku, x, u, tf, cst, flags, max_step, 0, A, Bp, Bn, Sigma, xi, node_counts, node_nfev,
+                                  node_t, node_y, node_cap);
+}
+
+/* n_uniform >= 2: Discretizer.use_uniform_steps with integrator_steps = n_uniform; 0: the default adaptive nodes */
+int oracle_discretize_mode(int K, int Ku, const double *x, const double *u, double tf, const double *cst,
+                           int flags, double max_step, int n_uniform, double *A, double *Bp, double *Bn, double *Sigma,
+                           double *xi, int32_t *node_counts, int32_t *node_nfev, double *node_t,
+                           double *node_y, int node_cap)
+{
     int status = 0, used = 0;
     for (int k = 0; k < K - 1; ++k) {
         double S7[7], X7[7];
         int32_t nn = 0, nf = 0;
-        int r = get_matrices(K, Ku, x, u, tf, cst, flags, max_step, k, A + k * 49, Bp + k * 21,
+        int r = get_matrices(K, Ku, x, u, tf, cst, flags, max_step, n_uniform, k, A + k * 49, Bp + k * 21,
                              Bn + k * 21, S7, X7, &nn, &nf, node_t ? node_t + used : 0,
                              node_y ? node_y + used * 56 : 0, node_cap - used);
         if (r && !status) status = r;

@@ -63,6 +63,11 @@ int oracle_discretize(int K, int Ku, const double *x, const double *u, double tf
                       int flags, double max_step, double *A, double *Bp, double *Bn, double *Sigma,
                       double *xi, int32_t *node_counts, int32_t *node_nfev, double *node_t,
                       double *node_y, int node_cap);
+/* the same with Discretizer.use_uniform_steps = True and integrator_steps = n_uniform (>= 2); n_uniform = 0: default */
+int oracle_discretize_mode(int K, int Ku, const double *x, const double *u, double tf, const double *cst,
+                           int flags, double max_step, int n_uniform, double *A, double *Bp, double *Bn, double *Sigma,
+                           double *xi, int32_t *node_counts, int32_t *node_nfev, double *node_t,
+                           double *node_y, int node_cap);
 
 /* simulator.py:164-189: solve_ivp(RK45, max_step, t_eval=linspace(0,1,n_eval)) with dense output.
  * y_out (7, n_eval) row-major as sol.y.  Returns 0, 1 = mass<=0, 2 = step too small. */

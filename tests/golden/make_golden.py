@@ -269,6 +269,23 @@ def gen_propagation_cases():
     save("propagate.npz", **out)
 
 
+def gen_uniform_steps_cases():
+    """Discretizer.use_uniform_steps = True (linearize_discretize.py:27-30, 50-53): solve_ivp evaluates the dense output
+    at integrator_steps uniform points per interval and the quadrature runs over those instead of the accepted nodes."""
+    sat = Satellite(R_HUBBLE, V_HUBBLE, M_HUBBLE)
+    scale = SatelliteScale(sat=sat)
+    const = scale.get_normalized_constants()
+    out = {}
+    ctrl = ConstantTangentialThrustController([sat], 0.5)
+    x, t, u = reference_case(sat, scale, ctrl, 1, 12)
+    for steps in (101, 11):
+        d = Discretizer(const, include_drag=False, include_J2=False)
+        d.use_uniform_steps = True; d.integrator_steps = steps
+        A, Bp, Bn, Sig, xi = d.discretize(F, x, u, 1)
+        out.update({f"A_{steps}": A, f"Bp_{steps}": Bp, f"Bn_{steps}": Bn, f"Sigma_{steps}": Sig, f"xi_{steps}": xi})
+    save("uniform_steps_K12_tf1.npz", const=const_vec(const), x=x, t=t, u=u, tf=np.float64(1), steps=np.array([101, 11]), **out)
+
+
 def gen_csv_case():
     """The trajectory CSV the reference writes (Simulator.save_to_csv, simulator.py:192-201, read by visualizer.m:23-28):
     file name pattern, the file's text and the run that produced it."""
@@ -298,8 +315,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "csv":
         gen_csv_case()
         raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "uniform":
+        gen_uniform_steps_cases()
+        raise SystemExit(0)
     gen_constants_and_pointwise()
     gen_discretize_cases()
     gen_constellation_cases()
     gen_propagation_cases()
     gen_csv_case()
+    gen_uniform_steps_cases()

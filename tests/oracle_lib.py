@@ -58,6 +58,10 @@ def lib():
         _lib.oracle_discretize.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, C.c_int,
                                            C.c_double, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp,
                                            C.c_int]
+        _lib.oracle_discretize_mode.restype = C.c_int
+        _lib.oracle_discretize_mode.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, C.c_int,
+                                                C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp,
+                                                C.c_int]
         _lib.oracle_propagate.argtypes = [_dp, C.c_double, _dp, C.c_int, C.POINTER(OracleCtrl),
                                           C.c_int, C.c_double, _dp, _ip]
         _lib.oracle_extract_uk.argtypes = [C.c_int, _dp, _dp, C.POINTER(OracleCtrl), _dp]
@@ -109,15 +113,16 @@ def u_foh(tau, u):
     return out, rc
 
 
-def discretize(x, u, tf, cst, flags=0, max_step=1e-2, dump_nodes=False):
+def discretize(x, u, tf, cst, flags=0, max_step=1e-2, dump_nodes=False, uniform_steps=0):
+    """uniform_steps = integrator_steps of Discretizer.use_uniform_steps (0: the default adaptive quadrature nodes)"""
     x, u, cst = _c(x), _c(u), _c(cst)
     K, Ku = x.shape[1], u.shape[1]
     A = np.zeros((K - 1, 7, 7)); Bp = np.zeros((K - 1, 7, 3)); Bn = np.zeros((K - 1, 7, 3))
     Sig = np.zeros((7, K - 1)); xi = np.zeros((7, K - 1))
     cnt = np.zeros(K - 1, dtype=np.int32); nfev = np.zeros(K - 1, dtype=np.int32)
-    cap = 64 * (K - 1) if dump_nodes else 0
+    cap = max(64, int(uniform_steps) + 1) * (K - 1) if dump_nodes else 0
     nt = np.zeros(max(cap, 1)); ny = np.zeros((max(cap, 1), 56))
-    rc = lib().oracle_discretize(K, Ku, _p(x), _p(u), float(tf), _p(cst), flags, max_step, _p(A),
+    rc = lib().oracle_discretize_mode(K, Ku, _p(x), _p(u), float(tf), _p(cst), flags, max_step, int(uniform_steps), _p(A),
                                  _p(Bp), _p(Bn), _p(Sig), _p(xi), cnt.ctypes.data_as(_ip),
                                  nfev.ctypes.data_as(_ip), _p(nt) if dump_nodes else None,
                                  _p(ny) if dump_nodes else None, cap)

@@ -100,3 +100,23 @@ def test_status_codes():
         disc.discretize(satellite_dynamics, xbad, u, 1.0)
     with pytest.raises(NotImplementedError):
         disc.discretize(lambda *a: None, x, u, 1.0)
+
+
+@pytest.mark.parametrize("steps", [101, 11])
+def test_uniform_steps_mode_vs_reference(golden_dir, steps):
+    """Discretizer.use_uniform_steps / integrator_steps (linearize_discretize.py:27-30, 50-53, 104-109): quadrature over
+    uniform points of the RK45 dense output.  Golden arrays from the reference itself (make_golden.py uniform)."""
+    from mpconstellation_amd import Discretizer, Simulator
+    from mpconstellation_amd.constants import Constants
+    g = np.load(os.path.join(golden_dir, "uniform_steps_K12_tf1.npz"))
+    d = Discretizer(Constants(*g["const"]))
+    d.use_uniform_steps = True; d.integrator_steps = steps
+    A, Bp, Bn, Sig, xi = d.discretize(Simulator.satellite_dynamics, g["x"], g["u"], float(g["tf"]))
+    for got, key in ((A, "A"), (Bp, "Bp"), (Bn, "Bn"), (Sig, "Sigma"), (xi, "xi")):
+        ref = g[f"{key}_{steps}"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), key
+    # it is a different quadrature: the default mode's result differs from it
+    d.use_uniform_steps = False
+    A0, Bp0, *_ = d.discretize(Simulator.satellite_dynamics, g["x"], g["u"], float(g["tf"]))
+    assert np.abs(Bp0 - Bp).max() > 1e-9

@@ -119,3 +119,14 @@ def test_extract_uk_and_constellation(golden_dir):
         o = O.discretize(c64[f"x_{i}"], c64[f"u_{i}"], 1.0, cs)
         for k in ("A", "Bp", "Bn", "Sigma", "xi"):
             assert relerr(o[k], c64[f"{k}_{i}"]) < RTOL
+
+
+@pytest.mark.parametrize("steps", [101, 11])
+def test_uniform_steps_mode(golden_dir, steps):
+    """use_uniform_steps / integrator_steps: the oracle's dense-output quadrature nodes against the reference's arrays"""
+    g = np.load(os.path.join(golden_dir, "uniform_steps_K12_tf1.npz"))
+    o = O.discretize(g["x"], g["u"], float(g["tf"]), g["const"], uniform_steps=steps)
+    assert o["status"] == 0
+    for k, key in (("A", "A"), ("Bp", "Bp"), ("Bn", "Bn"), ("Sigma", "Sigma"), ("xi", "xi")):
+        ref = g[f"{key}_{steps}"]
+        assert np.abs(o[k] - ref).max() <= 2e-15 * np.abs(ref).max(), key
