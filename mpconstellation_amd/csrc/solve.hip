@@ -53,7 +53,8 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0;
+constexpr int kFbN = 2;
 
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, eps_vt, tf_max, w_nu, w_tr, tol, acc_tol;
@@ -2159,6 +2160,11 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
     const int nzc = n_ineq(K, sd.nT, sd.fixed_tf);
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
+    // safeguard of the adaptive barrier rule (oracle/nlp_ipm.py, FB_*): after kFbN consecutive accepted steps shorter than
+    // kFbAlpha -- the iterate is jammed against its bounds while still far from feasible -- mu is lifted to kFbBoost *
+    // mean(s z) and follows ipopt's monotone Fiacco-McCormick rule from then on
+    bool mono = false;
+    int n_small = 0;
     double E0 = 0.0;
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
     // (sq in its mu = 0 form: it serves E_0 and, for any mu, the line search's ||F_mu||)
@@ -2176,7 +2182,16 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         if (iter >= o.max_iter) { status = (E0 <= o.acc_tol) ? MPCX_ST_ACCEPTABLE : MPCX_ST_MAXITER; break; }
         // adaptive barrier parameter: a fixed fraction of the iterate's mean complementarity ("Solver algorithm")
         const double mu_cur = r0.prod_sum / (double)nzc;
-        mu = fmax(kSigma * mu_cur, o.tol / 10.0);
+        if (!mono && n_small >= kFbN) {
+            mono = true;
+            mu = fmax(o.tol / 10.0, fmin(kMuInit, kFbBoost * mu_cur));
+        }
+        if (!mono) mu = fmax(kSigma * mu_cur, o.tol / 10.0);
+        else {
+            // mu moves on only when the barrier problem is solved to E_mu <= 10 mu: mu <- max(tol/10, min(0.2 mu, mu^1.5))
+            for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error(r0, K, sd.nT, sd.fixed_tf, mu) <= 10.0 * mu; ++lv)
+                mu = fmax(o.tol / 10.0, fmin(0.2 * mu, mu * sqrt(mu)));
+        }
         // Newton direction, with Hessian regularisation retries on breakdown
         bool have_dir = false;
         double delta_w = 0.0, alpha = 1.0;
@@ -2300,6 +2315,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         // diagnostic build only: iteration log (mu, E0, accepted step, regularisation) into this satellite's X block
         if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
 #endif
+        n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
         { gf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
         r0 = rt;

@@ -96,6 +96,15 @@ DW_FIRST, DW_MIN, DW_MAX = 1e-4, 1e-20, 1e40     # ipopt first_hessian_perturbat
 ALPHA_FLOOR = 0.25    # backtracking never takes the step below this (unless the fraction to the boundary does)
 MU_INIT = 1.0
 SIGMA = 0.1           # every iteration aims at mu = SIGMA * mean(s z)
+# Safeguard of the adaptive rule: it lowers mu with the iterate's mean complementarity whether or not the iterate is
+# anywhere near feasible; from a start far outside the constraints (a thrust limit a tenth of the reference thrust, a
+# target radius out of reach) the slacks collapse while the infeasibility is still O(1), the fraction-to-the-boundary
+# rule cuts every step to ~0 and the multipliers blow up (status NUMERIC).  Two consecutive accepted steps shorter than
+# FB_ALPHA are that jam's signature: mu is lifted to FB_BOOST * mean(s z) and from then on follows ipopt's monotone
+# Fiacco-McCormick rule (mu moves on only when the barrier problem is solved to E_mu <= 10 mu).  Never triggers on the
+# benchmark constellation or the MPC option sets; on the off-nominal option sets of profiles/tools/edge_cases.py it
+# turns every NUMERIC exit into a converged solve.
+FB_ALPHA, FB_N, FB_BOOST = 0.1, 2, 10.0
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
 REFINE_TW = 1e9       # iterative refinement only once a barrier weight z/s (terminal terms, stage balls/planes, tf) exceeds this
 STAGE_CAP = 1e8       # share of a stage barrier weight kept inside the Hessian blocks of the recursion
@@ -686,6 +695,7 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
     it = initial_iterate(P, start, prm)
     mu = prm["mu_init"]
     n_acc = 0; status = ST_MAXITER; k_it = 0
+    mono = prm["mu_strategy"] != "adaptive"; n_small = 0
     dw_last = 0.0; n_reg = 0; first_reg = -1
     for k_it in range(max_iter + 1):
         E0 = optimality_error(P, it, 0.0)[0]
@@ -696,7 +706,10 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
         if n_acc >= acceptable_iter: status = ST_ACCEPTABLE; break
         if k_it == max_iter: status = ST_ACCEPTABLE if E0 <= acceptable_tol else ST_MAXITER; break
         mu_cur = sum((it.s[k] * it.z[k]).sum() for k in it.s) / sum(v.size for v in it.s.values())
-        if prm["mu_strategy"] == "adaptive":
+        if not mono and n_small >= FB_N:
+            mono = True
+            mu = max(tol / 10, min(MU_INIT, FB_BOOST * mu_cur))
+        if not mono:
             mu = max(SIGMA * mu_cur, tol / 10)
         else:
             # Fiacco-McCormick: the barrier problem is solved to E_mu <= kappa_eps mu (kappa_eps = 10) before mu moves on
@@ -737,7 +750,8 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
             if residual_norm(P, n, mu) <= (1 - 1e-4 * a) * r0 and prod.min() >= GAMMA_NBHD * min(mu, prod.mean()):
                 break
             a *= 0.5
-        if verbose: print(f"       mu {mu:.2e} step {a:.4f} delta_w {dw:.1e}")
+        n_small = n_small + 1 if a < FB_ALPHA else 0
+        if verbose: print(f"       mu {mu:.2e} step {a:.4f} delta_w {dw:.1e}{' (monotone)' if mono else ''}")
         it = n if n is not None else candidate(P, it, d, a, mu_clip, prm)
     K = P.K
     NU = np.zeros((7, K)); NU[:, :K - 1] = it.NU

@@ -229,3 +229,29 @@ def test_optimal_controller_option_set_converges(K, tf, r_des):
     rK = np.linalg.norm(res.X[:, :3, -1], axis=1)
     assert np.abs(rK - r_des).max() <= 1e-6 + 2e-8                     # the eps_r window (with ipopt's 1e-8 relaxation)
     assert (res.tf <= tf * (1 + 1e-8) + 1e-8).all()
+
+
+def test_off_nominal_option_sets():
+    """Option sets far from the reference's (profiles/tools/edge_cases.py): a thrust limit below the reference thrust
+    (the start violates it everywhere), a target radius out of reach, a final-mass floor just under the start mass, tf_max
+    below the reference flight time.  The adaptive barrier rule alone jams on some of these (round-2 finding: status
+    NUMERIC); with its monotone fallback every problem converges, bar the rare one that needs more than max_iter."""
+    from mpconstellation_amd import mpc_step_batch
+    S, K = 256, 30
+    xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
+    tf = np.ones(S)
+    for opts, rd, min_ok in (({"u_lim": [0, 0.3]}, r_des, S), ({"u_lim": [0, 0.05]}, r_des, S - 8), ({"min_mass": 0.999}, r_des, S),
+                             ({}, np.full(S, 3.0), S - 2), ({"tf_max": 0.5}, r_des, S), ({"r_lim": [1.01, 5]}, r_des, S)):
+        res = mpc_step_batch(xbar, ubar, tf, consts, rd, options=opts)
+        assert not (res.status == 6).any(), opts                       # no numeric breakdown
+        assert np.isin(res.status, (0, 7)).sum() >= min_ok, (opts, np.unique(res.status, return_counts=True))
+        ok = res.status == 0
+        assert res.kkt[ok].max() <= 1e-8
+        if "u_lim" in opts:
+            assert np.linalg.norm(res.U[ok], axis=1).max() <= opts["u_lim"][1] * (1 + 1e-6)
+    # a NaN in one satellite's reference is that satellite's problem only
+    xn = xbar.copy(); xn[3, 2, 7] = np.nan
+    res = mpc_step_batch(xn, ubar, tf, consts, r_des)
+    ref = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    assert res.status[3] != 0 and (np.delete(res.status, 3) == 0).all()
+    assert np.array_equal(np.delete(res.X, 3, axis=0), np.delete(ref.X, 3, axis=0))

@@ -151,7 +151,7 @@ def test_frozen_ipopt_default_mode_ends_at_the_same_point(golden_dir, case):
     defaults for the same knobs (monotone mu from 0.1, push 1e-2, kappa_Sigma 1e10, multipliers 1): the same KKT point."""
     P, f = xcheck_problem(golden_dir, case)
     a = N.solve(P); b = N.solve(P, mode="ipopt_default", max_iter=400)
-    assert a["status"] == b["status"] == N.ST_OK and b["iters"] > a["iters"]
+    assert a["status"] == b["status"] == N.ST_OK
     assert np.abs(a["X"] - b["X"]).max() < 5e-6 and abs(a["tf"] - b["tf"]) < 1e-6
     assert np.abs(b["X"] - f["X"]).max() < TOL_X and abs(b["tf"] - float(f["tf_opt"])) < TOL_TF
 
