@@ -45,6 +45,10 @@ extern "C" {
 #define MPCX_ST_MAXITER 5     /* solver hit max_iter without meeting tol */
 #define MPCX_ST_NUMERIC 6     /* solver: non-finite value or factorisation breakdown */
 #define MPCX_ST_ACCEPTABLE 7  /* solver stopped at the 'acceptable' level (ipopt acceptable_tol) */
+#define MPCX_ST_INFEASIBLE 8  /* solver: the constraint set is empty whatever the dynamics (start node outside its own radius
+                               * bounds, terminal window outside r_max, r_min > r_max, empty window or tf range); seen before
+                               * the first iteration: x_bar, u_bar, tf_bar come back, kkt = the violation (ipopt: restoration
+                               * failure / "converged to a point of local infeasibility", ignored by optimizer.py:603) */
 
 /* dynamics flags (reference include_drag / include_J2 keyword arguments) */
 #define MPCX_FLAG_DRAG 1

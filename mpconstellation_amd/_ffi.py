@@ -13,6 +13,7 @@ STATUS_TEXT = {
     0: "ok", 1: "satellite mass <= 0", 2: "RK45 step size underflow",
     3: "FOH index outside the input table", 4: "state-transition matrix singular",
     5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
+    8: "constraint set empty (start node outside its radius bounds, terminal window outside r_max, empty window or tf range)",
 }
 FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS = 1, 2, 4
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3

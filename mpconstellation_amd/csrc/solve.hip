@@ -101,6 +101,7 @@ struct SatData {
     double sol[NBD];
     double zeta[NTERM];      // border unknowns of the terminal terms accumulated over the passes of one linear solve
     double red[8];
+    double infeas;           // > 0: the constraint set is empty whatever the dynamics (structural_violation)
     int flag;
 #ifdef MPCX_PHASE_TIMING
     unsigned long long fpt[16];   // diagnostic build only: cycle sums of the recursion's inner phases
@@ -295,6 +296,25 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
     sd.b_tf[0] = relax(0.0); sd.b_tf[1] = relax(o.tf_max);
     sd.vt_des = sqrt(mu_grav / r_des);
     sd.w_tr = o.w_tr; sd.w_nu = o.w_nu;
+}
+
+// > 0 when the constraint set is empty whatever the dynamics.  The virtual control makes every x_1..x_K reachable, so
+// nothing else can make the reference's NLP infeasible: the fixed start node violates its own radius constraints (x_0 =
+// xbar_0 is an equality, optimizer.py:344-345, and :384-395 apply at k = 0 too), the terminal radius window lies outside
+// the r_max ball (:393-403), r_min > r_max, an empty velocity window (eps < 0), an empty tf range (:588).  ipopt ends
+// such a problem in its restoration phase; here it is reported before the first iteration (MPCX_ST_INFEASIBLE) and the
+// satellite leaves the launch at once.  Returns the largest violation of the relaxed bounds.
+__device__ double structural_violation(const double *x0, int K, const SatData &sd)
+{
+    const double r2 = x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2];
+    double v = r2 - sd.b_rmax;
+    if (K >= 3) v = fmax(v, -sqrt(r2) - sd.b_rmin);
+    v = fmax(v, -sd.bT[0] - sqrt(fmin(sd.b_rmax, sd.b_rfmax)));
+    if (K >= 4) v = fmax(v, -sd.b_rmin - sqrt(sd.b_rmax));
+    v = fmax(v, fmax(-(sd.bT[1] + sd.bT[2]), -(sd.bT[3] + sd.bT[4])));
+    if (sd.nT == 8) v = fmax(v, -(sd.bT[6] + sd.bT[7]));
+    if (!sd.fixed_tf) v = fmax(v, -(sd.b_tf[0] + sd.b_tf[1]));
+    return v;
 }
 
 // ---- view of one satellite's problem + workspace -------------------------------------------
@@ -2110,11 +2130,23 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
         build_terminal(xK, a.consts[(size_t)sat * MPCX_NCONST + MPCX_C_MU], a.r_des[sat], o, sd);
         sd.tfbar = a.tfbar[sat];
+        double x0[3];
+        for (int i = 0; i < 3; ++i) x0[i] = s.xbar[(size_t)i * K];
+        sd.infeas = structural_violation(x0, K, sd);
 #ifdef MPCX_PHASE_TIMING
         for (int i = 0; i < 16; ++i) sd.fpt[i] = 0;
 #endif
     }
     __syncthreads();
+    if (sd.infeas > 0.0) {      // empty constraint set: the reference trajectory goes back unchanged, no iteration is spent
+        for (int e = lane; e < 7 * K; e += 64) { a.X[(size_t)sat * 7 * K + e] = s.xbar[e]; a.NU[(size_t)sat * 7 * K + e] = 0.0; }
+        for (int e = lane; e < 3 * K; e += 64) a.U[(size_t)sat * 3 * K + e] = s.ubar[e];
+        if (lane == 0) {
+            if (!sd.fixed_tf) a.tf_out[sat] = sd.tfbar; else a.tf_out[sat] = 0.0;      // (fixed tf: the slot returns g_s)
+            a.status[sat] = MPCX_ST_INFEASIBLE; a.iters[sat] = 0; a.kkt[sat] = sd.infeas;
+        }
+        return;
+    }
     // field-major copy of the stage records for the node-parallel phases (read every iteration, written once)
     for (int k = 0; k < K - 1; ++k) {
         cgf64 *rec = s.A(k);

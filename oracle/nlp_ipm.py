@@ -87,7 +87,7 @@ import numpy as np
 DEFAULT_OPTIONS = dict(min_mass=0.1, u_lim=[0, 5], r_lim=[0.99, 5], r_des=1, eps_r=0.01, eps_vr=0.00001,
                        eps_vn=0.00001, eps_vt=0.00001, tf_max=5, w_nu=1000, w_tr=0.002)   # optimizer.py:178-188
 
-ST_OK, ST_MAXITER, ST_NUMERIC, ST_ACCEPTABLE = 0, 5, 6, 7
+ST_OK, ST_MAXITER, ST_NUMERIC, ST_ACCEPTABLE, ST_INFEASIBLE = 0, 5, 6, 7, 8
 BOUND_RELAX = 1e-8
 BOUND_PUSH = 1e-4
 KAPPA_SIGMA = 100.0
@@ -176,6 +176,25 @@ class MpcProblem:
         self.b_rfmax = rl((o["r_des"] + o["eps_r"]) ** 2)             # :403
         self.b_tf = np.array([rl(0.0), rl(o["tf_max"])])              # :588
         self.w_tr, self.w_nu = o["w_tr"], o["w_nu"]
+
+    def structural_violation(self):
+        """> 0 when the constraint set is empty whatever the dynamics (the virtual control nu makes every x_1..x_K
+        reachable, so nothing else can make the NLP infeasible): the fixed start node violates its own radius
+        constraints (x_0 = xbar_0 is an equality, optimizer.py:344-345, and :384-395 apply at k = 0 too), the terminal
+        radius window lies outside the r_max ball (:393-403), r_min > r_max, an empty velocity window (eps < 0) or an
+        empty tf range (:588).  ipopt ends such a problem in its restoration phase ("converged to a point of local
+        infeasibility"); here it is seen before the first iteration.  Returns the largest violation (relaxed bounds)."""
+        K = self.K
+        r0 = self.xbar[:3, 0]
+        v = [r0 @ r0 - self.b_rmax]                                                  # start node outside the r_max ball
+        if K >= 3: v.append(-np.sqrt(r0 @ r0) - self.b_rmin)                         # ... or below the r_min plane (k = 0 < K-1)
+        rK_max = np.sqrt(min(self.b_rmax, self.b_rfmax))
+        v.append(-self.bT[0] - rK_max)                                               # r_hat.r_K >= r_des - eps_r out of reach
+        if K >= 4: v.append(-self.b_rmin - np.sqrt(self.b_rmax))                     # r_min plane outside the r_max ball
+        for lo in (1, 3) + ((6,) if len(self.bT) == 8 else ()):                      # windows a.x <= b+, -a.x <= b-
+            v.append(-(self.bT[lo] + self.bT[lo + 1]))
+        if self.fixed_tf is None: v.append(-(self.b_tf[0] + self.b_tf[1]))           # 0 < tf <= tf_max
+        return max(v)
 
     # ---- NLP functions ------------------------------------------------------------------
     def objective(self, X, U, T, tf):                                 # :300-325
@@ -694,6 +713,12 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
     """Returns dict(X (7,K), U (3,K), NU (7,K), tf, status, iters, kkt, objective, n_regularised = number of
     iterations whose factorisation broke down and needed delta_w > 0, first_regularised = index of the first, -1 if none)."""
     prm = FAST if mode == "fast" else IPOPT_DEFAULT
+    viol = P.structural_violation()
+    if viol > 0.0:       # empty constraint set: reported at once, the reference trajectory handed back unchanged
+        Z = np.zeros((7, P.K))
+        return dict(X=P.xbar.copy(), U=P.ubar.copy(), NU=Z, T=Z.copy(), tf=P.tfbar if P.fixed_tf is None else P.fixed_tf,
+                    status=ST_INFEASIBLE, iters=0, n_regularised=0, first_regularised=-1, kkt=viol, objective=np.nan,
+                    iterate=None, g_tf=0.0)
     it = initial_iterate(P, start, prm)
     mu = prm["mu_init"]
     n_acc = 0; status = ST_MAXITER; k_it = 0

@@ -35,4 +35,7 @@ un = ubar.copy(); un[5] = 0.0
 run('zero ubar for one sat', u=un)
 run('linear vt', linear_vt=True)
 run('linear vt eps_vt 1e-8', linear_vt=True, options={'eps_vt': 1e-8})
-run('K=100 default?') if False else None
+run('r_des 5.5 (> r_max: empty set)', r_des=np.full(S, 5.5))
+r1 = rd.copy(); r1[5] = 7.0
+run('one satellite with r_des 7', r_des=r1)
+run('eps_vr -1e-3 (empty window)', options={'eps_vr': -1e-3})

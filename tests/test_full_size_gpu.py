@@ -244,7 +244,7 @@ def test_off_nominal_option_sets():
     # every iteration (indefinite reduced Hessian next to an optimum with large virtual control), under which the
     # residual-norm line search makes only linear progress (known limits)
     for opts, rd, min_ok in (({"u_lim": [0, 0.3]}, r_des, S), ({"u_lim": [0, 0.05]}, r_des, S - 12), ({"min_mass": 0.999}, r_des, S),
-                             ({}, np.full(S, 3.0), S - 12), ({"tf_max": 0.5}, r_des, S), ({"r_lim": [1.01, 5]}, r_des, S)):
+                             ({}, np.full(S, 3.0), S - 12), ({"tf_max": 0.5}, r_des, S), ({"r_lim": [1.0, 5]}, r_des, S)):
         res = mpc_step_batch(xbar, ubar, tf, consts, rd, options=opts)
         assert not (res.status == 6).any(), opts                       # no numeric breakdown
         assert np.isin(res.status, (0, 7)).sum() >= min_ok, (opts, np.unique(res.status, return_counts=True))
@@ -254,9 +254,21 @@ def test_off_nominal_option_sets():
             # the thrust ball is |u|^2 <= u_max^2, relaxed by 1e-8 like every bound (ipopt's bound_relax_factor) and met to
             # the solver tolerance 1e-8
             assert (np.linalg.norm(res.U[ok], axis=1) ** 2).max() <= opts["u_lim"][1] ** 2 + 2.5e-8
+    # an empty constraint set is reported before the first iteration (MPCX_ST_INFEASIBLE), not iterated on for max_iter:
+    # the start node below the r_min plane (x_0 is fixed), a terminal window outside r_max, r_min > r_max, an empty
+    # velocity window, an empty tf range -- in one launch with feasible neighbours, which are not disturbed
+    ref = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    for opts, rd in (({"r_lim": [1.01, 5]}, r_des), ({}, np.full(S, 5.5)), ({"r_lim": [0.99, 1.2]}, np.full(S, 1.5)),
+                     ({"r_lim": [2.0, 1.5]}, r_des), ({"eps_vr": -1e-3}, r_des), ({"tf_max": -1.0}, r_des)):
+        res = mpc_step_batch(xbar, ubar, tf, consts, rd, options=opts)
+        assert (res.status == 8).all() and (res.iters == 0).all() and (res.kkt > 0).all(), opts
+        assert np.array_equal(res.X, xbar) and np.array_equal(res.U, ubar) and not res.NU.any() and np.array_equal(res.tf, tf)
+    rd = r_des.copy(); rd[5] = 7.0                         # one unreachable target among feasible satellites
+    res = mpc_step_batch(xbar, ubar, tf, consts, rd)
+    assert res.status[5] == 8 and (np.delete(res.status, 5) == 0).all()
+    assert np.array_equal(np.delete(res.X, 5, axis=0), np.delete(ref.X, 5, axis=0))
     # a NaN in one satellite's reference is that satellite's problem only
     xn = xbar.copy(); xn[3, 2, 7] = np.nan
     res = mpc_step_batch(xn, ubar, tf, consts, r_des)
-    ref = mpc_step_batch(xbar, ubar, tf, consts, r_des)
     assert res.status[3] != 0 and (np.delete(res.status, 3) == 0).all()
     assert np.array_equal(np.delete(res.X, 3, axis=0), np.delete(ref.X, 3, axis=0))

@@ -105,6 +105,33 @@ def test_status_codes(golden_dir):
     assert r["status"] == N.ST_ACCEPTABLE and r["kkt"] <= 1e-6
 
 
+def test_empty_constraint_set_is_reported_at_once(golden_dir):
+    """The virtual control makes every x_1..x_K reachable, so the NLP is infeasible only when the constraint set itself
+    is empty; the solver says so (ST_INFEASIBLE) before iterating and hands the reference back.  The terminal-radius case
+    is confirmed independently: the smallest violation of its three constraints over r_K (SLSQP on the epigraph form)."""
+    from scipy.optimize import minimize
+    base = problem(golden_dir, "tan_K30_tf1")
+    rK = float(np.linalg.norm(base.xbar[:3, -1]))
+    for opts in ({"r_lim": [1.01, 5]}, {"r_des": 5.5}, {"r_lim": [0.99, 1.2], "r_des": 1.5}, {"r_lim": [2.0, 1.5]},
+                 {"eps_vr": -1e-3}, {"eps_vn": -1e-3}, {"tf_max": -1.0}):
+        P = problem(golden_dir, "tan_K30_tf1", **opts)
+        r = N.solve(P)
+        assert r["status"] == N.ST_INFEASIBLE and r["iters"] == 0 and r["kkt"] > 0, opts
+        assert np.array_equal(r["X"], P.xbar) and np.array_equal(r["U"], P.ubar) and not r["NU"].any() and r["tf"] == P.tfbar
+    P = problem(golden_dir, "tan_K30_tf1", r_des=5.5)
+    rh = -P.aT[0, :3]
+    cons = [{"type": "ineq", "fun": lambda w: w[3] - (-(rh @ w[:3]) - P.bT[0])},
+            {"type": "ineq", "fun": lambda w: w[3] - (w[:3] @ w[:3] - P.b_rmax)},
+            {"type": "ineq", "fun": lambda w: w[3] - (w[:3] @ w[:3] - P.b_rfmax)}]
+    m = minimize(lambda w: w[3], np.r_[5.0 * rh, 1.0], constraints=cons, method="SLSQP", options={"ftol": 1e-12})
+    assert m.success and m.fun > 0.1                         # no r_K satisfies all three
+    # hard but feasible option sets are NOT flagged: a target far above the orbit, tf_max below the reference time,
+    # a thrust limit below the reference thrust, the start exactly on the r_min plane
+    for opts in ({"r_des": 3.0}, {"tf_max": 0.5}, {"u_lim": [0, 0.05]}, {"r_lim": [1.0, 5]}, {"r_des": rK, "eps_r": 0.0},
+                 {"eps_vr": 0.0, "eps_vn": 0.0}):
+        assert problem(golden_dir, "tan_K30_tf1", **opts).structural_violation() <= 0.0, opts
+
+
 # ---- independent fixtures: scipy trust-constr on a second transcription of optimizer.py (tests/golden/make_nlp_xcheck.py) ----
 XCHECK = ["tan_K20_tf2", "tan_K30_tf1", "tan_K30_tf1_zero", "const_K30_tf1", "tan_K20_tf2_linvt", "tan_K30_tf1_linvt",
           "const_K30_tf1_linvt", "tan_K30_tf1_mpc105", "tan_K60_tf2_mpc12", "tan_K60_tf2_mpc15"]
