@@ -53,7 +53,7 @@ enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0, kMuErr = 1e-6;
 constexpr int kFbN = 4;
 
 struct SolveOpts {
@@ -851,7 +851,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             for (int i = 0; i < 36; ++i) hn += sd.Hv[i] * sd.Hv[i];
             for (int i = 0; i < 6; ++i) an += g6[i] * g6[i];
             // (convex variant: the capped share of the pair's weight takes the place of the AL weight)
-            sd.gam = sd.linvt ? fmin(sd.w_vt, kTermCap) : (1.0 + 10.0 * fabs(lvt) * sqrt(hn)) / an;
+            sd.gam = sd.linvt ? fmin(sd.w_vt, kTermCap) : (kTermCap + 10.0 * fabs(lvt) * sqrt(hn)) / an;
         }
     }
     sigmax = wave_max(sigmax);
@@ -2219,7 +2219,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             mono = true;
             mu = fmax(o.tol / 10.0, fmin(kMuInit, kFbBoost * mu_cur));
         }
-        if (!mono) mu = fmax(kSigma * mu_cur, o.tol / 10.0);
+        // (never below kMuErr * E_0: the mean complementarity may collapse while the iterate is still infeasible)
+        if (!mono) mu = fmax(fmax(kSigma * mu_cur, o.tol / 10.0), kMuErr * E0);
         else {
             // mu moves on only when the barrier problem is solved to E_mu <= 10 mu: mu <- max(tol/10, min(0.2 mu, mu^1.5))
             for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error(r0, K, sd.nT, sd.fixed_tf, mu) <= 10.0 * mu; ++lv)

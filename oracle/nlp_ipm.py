@@ -52,7 +52,7 @@ Deliberate differences from ipopt's path (none changes the NLP or its KKT points
   lower side (z >= mu / (kappa s)) is dropped: raising the multipliers of inactive constraints after every step only
   adds dual infeasibility (measured: 39 -> 32 iterations on long-arc K = 60 references, 51 -> 46 with the MPC loop's
   option set, 21.7 -> 21.2 on the benchmark constellation; the saturated-thrust scenarios pay 26 -> 28).
-* barrier parameter: every iteration aims at mu = max(tol/10, SIGMA mean(s z)) with SIGMA = 0.1, the
+* barrier parameter: every iteration aims at mu = max(tol/10, SIGMA mean(s z), MU_ERR E_0) with SIGMA = 0.1, the
   path-following rule of primal-dual methods (ipopt's mu_strategy = adaptive is the same idea with an oracle choosing
   sigma; its default is the monotone Fiacco-McCormick schedule mu <- max(tol/10, min(0.2 mu, mu^1.5)) once
   E_mu <= 10 mu, which this oracle followed first and which spent several short-stepped iterations on every level).
@@ -96,6 +96,11 @@ DW_FIRST, DW_MIN, DW_MAX = 1e-4, 1e-20, 1e40     # ipopt first_hessian_perturbat
 ALPHA_FLOOR = 0.25    # backtracking never takes the step below this (unless the fraction to the boundary does)
 MU_INIT = 1.0
 SIGMA = 0.1           # every iteration aims at mu = SIGMA * mean(s z)
+# ... but never below MU_ERR times the iterate's total error E_0 (infeasibilities included): the mean complementarity can
+# collapse to the tol/10 floor while the iterate is still 1e-3 from feasible; the fraction-to-the-boundary rule then cuts
+# every step to 0 and the multipliers run away (seen with a thrust limit of 0.3, one of 256 satellites).  Healthy paths
+# keep mu / E_0 above 2e-4, so the bound never binds on them (benchmark iteration paths unchanged)
+MU_ERR = 1e-6
 # Safeguard of the adaptive rule: it lowers mu with the iterate's mean complementarity whether or not the iterate is
 # anywhere near feasible; from a start far outside the constraints (a thrust limit a tenth of the reference thrust, a
 # target radius out of reach) the slacks collapse while the infeasibility is still O(1), the fraction-to-the-boundary
@@ -415,7 +420,13 @@ def riccati_factor(P, nb):
         wi = min(w, TERM_CAP); win.append(wi)
         WxK += wi * np.outer(a, a)
     avt = nb["avt"]
-    gam = (1.0 + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt) if P.variant == "exact" else 0.0
+    # augmented-Lagrangian weight of the tangential equality inside the recursion.  Any value gives the same direction (the
+    # row itself is a border equality); it must be large enough for the recursion's pivots to stay positive whenever the
+    # reduced Hessian is positive definite.  Sized like a capped terminal weight: a weight of the order of lam_vt |H_v|
+    # covers the terminal node only, and the negative curvature lam_vt H_v leaves at x_K grows a thousandfold on its way
+    # back through 30 stages of orbital dynamics (seen with r_des = 3: spurious breakdowns at node 1, delta_w = 0.1..0.5
+    # in every iteration of the endgame, MAXITER)
+    gam = (TERM_CAP + 10.0 * abs(nb["lam_vt_cur"]) * np.linalg.norm(nb["Hv"])) / (avt @ avt) if P.variant == "exact" else 0.0
     WxK += gam * np.outer(avt, avt)
     F = dict(P=np.zeros((K, 7, 7)), Minv=np.zeros((K, 7, 7)), G=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
              Qi=np.zeros((K, 3, 3)), Kg=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)), win=win, gam=gam, WxK=WxK)
@@ -737,7 +748,7 @@ def solve(P, tol=1e-8, max_iter=200, acceptable_tol=1e-6, acceptable_iter=15, n_
             mono = True
             mu = max(tol / 10, min(MU_INIT, FB_BOOST * mu_cur))
         if not mono:
-            mu = max(SIGMA * mu_cur, tol / 10)
+            mu = max(SIGMA * mu_cur, tol / 10, MU_ERR * E0)
         else:
             # Fiacco-McCormick: the barrier problem is solved to E_mu <= kappa_eps mu (kappa_eps = 10) before mu moves on
             # to max(tol / 10, min(kappa_mu mu, mu^theta_mu)), kappa_mu = 0.2, theta_mu = 1.5 (Waechter & Biegler eq. (7))
