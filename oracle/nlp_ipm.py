@@ -101,17 +101,15 @@ SIGMA = 0.1           # every iteration aims at mu = SIGMA * mean(s z)
 # every step to 0 and the multipliers run away (seen with a thrust limit of 0.3, one of 256 satellites).  Healthy paths
 # keep mu / E_0 above 2e-4, so the bound never binds on them (benchmark iteration paths unchanged)
 MU_ERR = 1e-6
-# Safeguard of the adaptive rule: it lowers mu with the iterate's mean complementarity whether or not the iterate is
-# anywhere near feasible; from a start far outside the constraints (a thrust limit a tenth of the reference thrust, a
-# target radius out of reach) the slacks collapse while the infeasibility is still O(1), the fraction-to-the-boundary
-# rule cuts every step to ~0 and the multipliers blow up (status NUMERIC).  FB_N consecutive accepted steps shorter than
-# FB_ALPHA are that jam's signature: mu is lifted to FB_BOOST * mean(s z) and from then on follows ipopt's monotone
-# Fiacco-McCormick rule (mu moves on only when the barrier problem is solved to E_mu <= 10 mu).  FB_N = 4 and not less:
-# satellite 123 of the 512 x K=100 workload takes three such steps in a row right after its first step and the adaptive
-# rule then recovers by itself in 19 iterations, where the monotone rule needs 33.  With 4 the fallback stays out of the
-# benchmark constellation and the MPC option sets; on the off-nominal option sets of profiles/tools/edge_cases.py it
-# turns every NUMERIC exit into a converged solve.
-FB_ALPHA, FB_N, FB_BOOST = 0.1, 4, 10.0
+# Second safeguard: FB_N consecutive accepted steps shorter than FB_ALPHA mean the iterate is jammed against its bounds
+# (a start far outside the constraints: a thrust limit a tenth of the reference thrust, tf_max below the reference time);
+# mu is then lifted to FB_BOOST * mean(s z) and follows ipopt's monotone Fiacco-McCormick rule from there on (mu moves on
+# only when the barrier problem is solved to E_mu <= 10 mu).  With the MU_ERR bound in place the fallback is no longer
+# what makes these problems converge; it makes them converge sooner (tf_max 0.5: 44 instead of 65 iterations on
+# average).  FB_N = 8 and not less: benchmark problems at K = 100 take up to seven short regularised steps in a row and
+# then recover by themselves in 16 / 25 iterations, where the monotone rule needs 32 / 41 -- and a launch ends with its
+# slowest satellite.
+FB_ALPHA, FB_N, FB_BOOST = 0.1, 8, 10.0
 TERM_CAP = 1e4        # share of a terminal barrier weight kept inside the Riccati recursion
 REFINE_TW = 1e9       # iterative refinement only once a barrier weight z/s (terminal terms, stage balls/planes, tf) exceeds this
 STAGE_CAP = 1e8       # share of a stage barrier weight kept inside the Hessian blocks of the recursion
