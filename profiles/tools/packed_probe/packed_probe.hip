@@ -41,6 +41,7 @@ struct ProbeArgs {
     const double *rec;     // [S][K][REC_N]: A | Bh | Bpm | Wx | Wu | D (row-major blocks)
     const double *chin;    // [S][K][NCH][24]: gx 7 | gu 3 | rho 7 | aff 7
     double *P, *Kg, *Qi;   // [S][K][49], [S][K][21], [S][K][9]
+    double *Lrd;           // [S][K][28]: L (21, row-wise strict lower triangle) | 1/d (7)
     double *p, *qu;        // [S][K][NCH][7], [S][K][NCH][3]
     long long *cycles;     // [blocks]
 };
@@ -85,6 +86,13 @@ __global__ __launch_bounds__(64, PROBE_WAVES) void packed_probe_kernel(ProbeArgs
                 m[r] = fma(-lrp, mp, m[r]);
             SEND
         SEND
+        if (live && l == 7) {       // the factors of M for the forward sweep (the spare lane of the row stores them)
+            double *lo = a.Lrd + ((size_t)sat * K + k) * 28;
+#pragma unroll
+            for (int e = 0; e < 21; ++e) lo[e] = L[e];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) lo[21 + r] = rd[r];
+        }
         // ---- B: X1 = L^-1 P_{k+1}[:, c] ; X2 = L^-1 e_c (matrix lanes) / L^-1 (rho + p_{k+1}) (channel lanes) ----
         double x1[7], x2[7];
 #pragma unroll
@@ -197,16 +205,132 @@ __global__ __launch_bounds__(64, PROBE_WAVES) void packed_probe_kernel(ProbeArgs
     if (lane == 0) a.cycles[blockIdx.x] = t1 - t0;
 }
 
-extern "C" int packed_probe_run(int S, int K, const double *rec, const double *chin, double *P, double *Kg, double *Qi, double *p,
-                                double *qu, long long *cycles, int reps, float *ms_out)
+extern "C" int packed_probe_run(int S, int K, const double *rec, const double *chin, double *P, double *Kg, double *Qi, double *Lrd,
+                                double *p, double *qu, long long *cycles, int reps, float *ms_out)
 {
-    ProbeArgs a{S, K, rec, chin, P, Kg, Qi, p, qu, cycles};
+    ProbeArgs a{S, K, rec, chin, P, Kg, Qi, Lrd, p, qu, cycles};
     const int blocks = (S + 3) / 4;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(packed_probe_kernel, dim3(blocks), dim3(64), 0, 0, a);
     hipEventRecord(e0, 0);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(packed_probe_kernel, dim3(blocks), dim3(64), 0, 0, a);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) return 1;
+    hipEventElapsedTime(ms_out, e0, e1);
+    *ms_out /= (float)reps;
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// Forward sweep of the 8 channels of four satellites: the channel lanes carry y, u, x, nu, lam of their channel in registers,
+// the matrix lanes only lend their columns (Kg, Bpm, A, Bh, P_{k+1}) to the broadcasts; nu = -L^-T R L^-1 (P_{k+1} yhat + rho
+// + p_{k+1}) from the stored factors of M (no G, no M^-1 in the record: 104 doubles per node instead of 198).
+struct FwdArgs {
+    int S, K;
+    const double *rec, *chin, *P, *Kg, *Qi, *Lrd, *p, *qu;
+    double *X, *U, *NU, *LAM;      // [S][K][NCH][7|3|7|7]
+    long long *cycles;
+};
+
+__global__ __launch_bounds__(64, PROBE_WAVES) void packed_forward_kernel(FwdArgs a)
+{
+    const int lane = threadIdx.x, l = lane & 15;
+    int sat = blockIdx.x * 4 + (lane >> 4);
+    const bool live = sat < a.S;
+    if (!live) sat = a.S - 1;
+    const int K = a.K;
+    const bool mat = l < 7, chn = l >= 8;
+    const int c = mat ? l : 0, c3 = (l < 3) ? l : 0, ch = chn ? l - 8 : 0;
+    double y[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < K; ++k) {
+        const size_t nk = (size_t)sat * K + k;
+        const double *rk = a.rec + nk * REC_N;
+        const double *ck = a.chin + (nk * NCH + ch) * CH_IN;
+        const bool dyn = k <= K - 2;
+        const size_t nk1 = dyn ? nk + 1 : nk;
+        double A[7], bh[7], bpm[7], pn[7], kg[3], D[7], L[21], rd[7], Qi[9], rho[7], aff[7], pp[7], qu[3];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            A[r] = rk[R_A + r * 7 + c]; bh[r] = rk[R_BH + r * 3 + c3]; bpm[r] = rk[R_BPM + r * 3 + c3];
+            pn[r] = dyn ? a.P[nk1 * 49 + r * 7 + c] : 0.0;
+            D[r] = rk[R_D + r]; rd[r] = a.Lrd[nk * 28 + 21 + r];
+            rho[r] = ck[10 + r]; aff[r] = ck[17 + r];
+            pp[r] = dyn ? a.p[(nk1 * NCH + ch) * 7 + r] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 21; ++e) L[e] = a.Lrd[nk * 28 + e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Qi[e] = a.Qi[nk * 9 + e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { kg[j] = a.Kg[nk * 21 + j * 7 + c]; qu[j] = a.qu[(nk * NCH + ch) * 3 + j]; }
+        // u = -Kg y - Quu^-1 qu
+        double u[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) u[j] = -(Qi[j * 3] * qu[0] + Qi[j * 3 + 1] * qu[1] + Qi[j * 3 + 2] * qu[2]);
+        SFOR(cc, 7)
+            SFOR(j, 3)
+                u[j] = fma(-bc<cc>(kg[j]), y[cc], u[j]);
+            SEND
+        SEND
+        // x = y + Bpm u ; yhat = A y + Bh u + aff
+        double x[7], yh[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) { x[r] = y[r]; yh[r] = aff[r]; }
+        SFOR(j, 3)
+            SFOR(r, 7)
+                x[r] = fma(bc<j>(bpm[r]), u[j], x[r]); yh[r] = fma(bc<j>(bh[r]), u[j], yh[r]);
+            SEND
+        SEND
+        SFOR(cc, 7)
+            SFOR(r, 7)
+                yh[r] = fma(bc<cc>(A[r]), y[cc], yh[r]);
+            SEND
+        SEND
+        // z = L^-1 (P_{k+1} yhat + rho + p_{k+1}) ; nu = -L^-T R z
+        double z[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) z[r] = rho[r] + pp[r];
+        SFOR(cc, 7)
+            SFOR(r, 7)
+                z[r] = fma(bc<cc>(pn[r]), yh[cc], z[r]);
+            SEND
+        SEND
+#pragma unroll
+        for (int r = 1; r < 7; ++r)
+#pragma unroll
+            for (int q = 0; q < r; ++q) z[r] = fma(-L[r * (r - 1) / 2 + q], z[q], z[r]);
+#pragma unroll
+        for (int r = 0; r < 7; ++r) z[r] *= -rd[r];
+#pragma unroll
+        for (int q = 6; q >= 1; --q)
+#pragma unroll
+            for (int r = 0; r < q; ++r) z[r] = fma(-L[q * (q - 1) / 2 + r], z[q], z[r]);
+        if (live && chn) {
+            double *xo = a.X + (nk * NCH + ch) * 7, *uo = a.U + (nk * NCH + ch) * 3, *no = a.NU + (nk * NCH + ch) * 7, *lo = a.LAM + (nk * NCH + ch) * 7;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) { xo[r] = x[r]; no[r] = dyn ? z[r] : 0.0; lo[r] = dyn ? fma(D[r], z[r], rho[r]) : 0.0; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) uo[j] = u[j];
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) y[r] = dyn ? yh[r] + z[r] : y[r];
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) a.cycles[blockIdx.x] = t1 - t0;
+}
+
+extern "C" int packed_forward_run(int S, int K, const double *rec, const double *chin, const double *P, const double *Kg, const double *Qi,
+                                  const double *Lrd, const double *p, const double *qu, double *X, double *U, double *NU, double *LAM,
+                                  long long *cycles, int reps, float *ms_out)
+{
+    FwdArgs a{S, K, rec, chin, P, Kg, Qi, Lrd, p, qu, X, U, NU, LAM, cycles};
+    const int blocks = (S + 3) / 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(packed_forward_kernel, dim3(blocks), dim3(64), 0, 0, a);
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(packed_forward_kernel, dim3(blocks), dim3(64), 0, 0, a);
     hipEventRecord(e1, 0);
     if (hipEventSynchronize(e1) != hipSuccess) return 1;
     hipEventElapsedTime(ms_out, e0, e1);

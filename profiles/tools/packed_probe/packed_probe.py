@@ -69,6 +69,25 @@ def reference(rec, ch):
     return outP, outKg, outQi, outp, outqu
 
 
+def reference_forward(rec, ch, outP, outKg, outQi, outp, outqu):
+    K = rec.shape[0]
+    X = np.zeros((K, NCH, 7)); U = np.zeros((K, NCH, 3)); NU = np.zeros((K, NCH, 7)); LAM = np.zeros((K, NCH, 7))
+    for c in range(NCH):
+        y = np.zeros(7)
+        for k in range(K):
+            r = rec[k]
+            A = r[0:49].reshape(7, 7); Bh = r[49:70].reshape(7, 3); Bpm = r[70:91].reshape(7, 3); D = r[149:156]
+            u = -(outKg[k] @ y) - outQi[k] @ outqu[k, c]
+            U[k, c] = u; X[k, c] = y + Bpm @ u
+            if k <= K - 2:
+                rho, aff = ch[k, c, 10:17], ch[k, c, 17:24]
+                yh = A @ y + Bh @ u + aff
+                nu = -np.linalg.solve(np.diag(D) + outP[k + 1], outP[k + 1] @ yh + rho + outp[k + 1, c])
+                NU[k, c] = nu; LAM[k, c] = D * nu + rho
+                y = yh + nu
+    return X, U, NU, LAM
+
+
 def main():
     import torch
     n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -79,6 +98,7 @@ def main():
                                f"-DPROBE_WAVES={waves}", "-o", lib_path, os.path.join(HERE, "packed_probe.hip")])
     snaps = [snapshot(i, K, n_it) for i in (0, 517, 1033, 2049, 3071, 4000, 77, 1999)]
     refs = [reference(r, c) for r, c, _, _ in snaps]
+    frefs = [reference_forward(sn[0], sn[1], *rf) for sn, rf in zip(snaps, refs)]
     # the dense recursion of this file against the oracle's own factorisation (where no stiff stage term is active)
     for (r, c, F, stiff), ref in zip(snaps, refs):
         if stiff == 0:
@@ -94,9 +114,20 @@ def main():
             oP = torch.zeros((S, K, 49), **t64); oKg = torch.zeros((S, K, 21), **t64); oQi = torch.zeros((S, K, 9), **t64)
             op = torch.zeros((S, K, NCH, 7), **t64); oqu = torch.zeros((S, K, NCH, 3), **t64)
             cyc = torch.zeros((S + 3) // 4, dtype=torch.int64, device=dev)
+            oL = torch.zeros((S, K, 28), **t64)
             ms = C.c_float(0)
-            rc = lib.packed_probe_run(S, K, p(rec), p(chin), p(oP), p(oKg), p(oQi), p(op), p(oqu), p(cyc), 5, C.byref(ms))
+            rc = lib.packed_probe_run(S, K, p(rec), p(chin), p(oP), p(oKg), p(oQi), p(oL), p(op), p(oqu), p(cyc), 5, C.byref(ms))
             assert rc == 0, rc
+            fX = torch.zeros((S, K, NCH, 7), **t64); fU = torch.zeros((S, K, NCH, 3), **t64); fN = torch.zeros((S, K, NCH, 7), **t64); fL = torch.zeros((S, K, NCH, 7), **t64)
+            fcyc = torch.zeros((S + 3) // 4, dtype=torch.int64, device=dev); fms = C.c_float(0)
+            rc = lib.packed_forward_run(S, K, p(rec), p(chin), p(oP), p(oKg), p(oQi), p(oL), p(op), p(oqu), p(fX), p(fU), p(fN), p(fL), p(fcyc), 5, C.byref(fms))
+            assert rc == 0, rc
+            ferr = []
+            for s in range(min(S, 16)):
+                fr = frefs[idx[s]]
+                fg = (fX[s].cpu().numpy(), fU[s].cpu().numpy(), fN[s].cpu().numpy(), fL[s].cpu().numpy())
+                ferr.append([np.abs(g - r).max() / max(np.abs(r).max(), 1e-300) for g, r in zip(fg, fr)])
+            ferr = np.max(np.array(ferr), axis=0); fcn = fcyc.cpu().numpy() / K
             errs = []
             for s in range(min(S, 16)):
                 ref = refs[idx[s]]
@@ -108,7 +139,10 @@ def main():
             print(f"waves/SIMD {waves}  S {S:6d} ({(S + 3) // 4:5d} waves): {ms.value:8.3f} ms per pass  "
                   f"cycles per node per wave (4 satellites, 32 channels) median {np.median(cn):7.0f} max {cn.max():7.0f}   "
                   f"max rel err P {errs[0]:.1e} Kg {errs[1]:.1e} Qi {errs[2]:.1e} p {errs[3]:.1e} qu {errs[4]:.1e}", flush=True)
-    print("solve_kernel today (profiles/r02/phase_timing.txt): ~8 450 cycles per node for ONE satellite alone on its SIMD, ~10 800 with two waves per SIMD")
+            print(f"   forward sweep of the 32 channels:        {fms.value:8.3f} ms per pass  cycles per node per wave median {np.median(fcn):7.0f} max {fcn.max():7.0f}   "
+                  f"max rel err x {ferr[0]:.1e} u {ferr[1]:.1e} nu {ferr[2]:.1e} lam {ferr[3]:.1e}", flush=True)
+    print("solve_kernel today (profiles/r02/phase_timing.txt): factorisation ~8 450 cycles per node for ONE satellite alone on its SIMD, ~10 800 with two "
+          "waves per SIMD; forward sweep ~2 700 / ~4 300")
 
 
 if __name__ == "__main__":
