@@ -7,8 +7,8 @@
 // The 56-component ODE state [Phi (7x7) ; x (7)] is held column-wise: lane c < 7 owns column c
 // of Phi, lane 7 owns x.  Every column obeys the same linear ODE d(col)/dtau = A(x,u) col, so
 // the 8 lanes run the same instruction stream; the only cross-lane traffic per RHS evaluation
-// is the broadcast of (r, m) from lane 7 (4 x ds_bpermute pairs) and the 3-step xor butterfly
-// of the RMS error norm.  All groups of a wave take their own adaptive RK45 step sequence
+// is the broadcast of (r, m) from lane 7 (4 x two v_mov_b64_dpp, mpcx_device.hpp) and the 3-step butterfly
+// of the RMS error norm (DPP as well: no LDS round trip in the step loop).  All groups of a wave take their own adaptive RK45 step sequence
 // (scipy's controller, reproduced decision for decision); the loop is wave-uniform and a
 // group that has reached its end point idles under predicate.  At every accepted node each
 // lane forms one of the 8 quadrature columns [B lam-, B lam+, Sigma, xi], solves
@@ -35,10 +35,7 @@ struct DiscArgs {
 
 __device__ __forceinline__ double group_sum(double v)
 {
-    v += __shfl_xor(v, 1, 8);
-    v += __shfl_xor(v, 2, 8);
-    v += __shfl_xor(v, 4, 8);
-    return v;   // bitwise identical on the 8 lanes (each level adds the same two operands)
+    return group_sum8(v);   // bitwise identical on the 8 lanes (each level adds the same two operands); DPP, no LDS round trip
 }
 
 struct RhsCtx {
@@ -55,8 +52,8 @@ __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], doubl
 {
     double u[3];
     foh3_cached(ts, p.us, p.Ku, p.foh, u, err);
-    const double rx = __shfl(ys[0], 7, 8), ry = __shfl(ys[1], 7, 8), rz = __shfl(ys[2], 7, 8);
-    const double m = __shfl(ys[6], 7, 8);
+    const double rx = bcast8<7>(ys[0]), ry = bcast8<7>(ys[1]), rz = bcast8<7>(ys[2]);
+    const double m = bcast8<7>(ys[6]);
     double G[3][3], gm[3];
     jacobian_blocks(rx, ry, rz, m, u, p.cst, p.flags, G, gm);
     const double tf = p.tf;
@@ -137,7 +134,7 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const dou
     const int c = p.c;
     double x[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) x[i] = __shfl(y[i], 7, 8);
+    for (int i = 0; i < 7; ++i) x[i] = bcast8<7>(y[i]);
     double u[3];
     foh3_cached(t, p.us, p.Ku, p.foh, u, err);
     const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);

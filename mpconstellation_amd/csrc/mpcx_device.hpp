@@ -114,6 +114,36 @@ __device__ __forceinline__ void foh3_cached(double tau, const double *__restrict
     for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
 }
 
+// Value of lane q of the caller's 8-lane group in all 8 lanes (q a compile-time constant): two v_mov_b64_dpp -- gfx950 has
+// the 64-bit DPP move for row_newbcast -- lane q of every 16-lane row into the whole row, then lane 8 + q over the row's
+// upper half under a bank mask.  VALU only: no ds_bpermute, no LDS round trip.  Checked against __shfl for every q by
+// profiles/tools/dpp_bcast_check.hip.
+template <int Q>
+__device__ __forceinline__ double bcast8(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const long long t = __builtin_amdgcn_update_dpp((long long)0, b, 0x150 + Q, 0xF, 0xF, true);
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(t, b, 0x150 + 8 + Q, 0xF, 0xC, false));
+}
+
+// Sum over the caller's 8-lane group, bitwise identical on its 8 lanes: neighbours inside the quad by quad_perm, then the
+// other quad by row_half_mirror (lane i <-> 7 - i; both quads hold their quad's sum by then and a + b = b + a bit for bit).
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double group_sum8(double v)
+{
+    v += dpp64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp64<0x141>(v);     // row_half_mirror
+    return v;
+}
+
 struct SatConst {
     double mu, re, j2, g0, isp, s, r0, rho;
     __device__ __forceinline__ void load(const double *__restrict__ c)

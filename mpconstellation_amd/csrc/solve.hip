@@ -129,27 +129,10 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// Value of lane q of the caller's 8-lane group in all 8 lanes, q a constant after unrolling: two v_mov_b32_dpp per 32-bit
-// half (quad_perm broadcast inside q's quad, then row_half_mirror -- lane i <-> 7 - i of the group -- into the other
-// quad under a bank mask) instead of the ds_bpermute_b32 pair gshfl8(v, q) compiles to.  The sweeps exchange ~70
-// doubles per node this way; as ds_bpermute they were 40 % of the kernel's LDS instructions, and at two waves per SIMD
-// the CU's LDS pipe (shared by its four SIMDs) is the resource the kernel saturates first (profiles/r02/pmc_sq.json:
-// SQ_ACTIVE_INST_LDS).  Checked against __shfl for every q by profiles/tools/dpp_bcast_check.hip.
-template <int Q>
-__device__ __forceinline__ int bcast8_i(int v)
-{
-    constexpr int qp = (Q & 3) * 0x55;                         // quad_perm: [q%4, q%4, q%4, q%4]
-    const int t = __builtin_amdgcn_update_dpp(0, v, qp, 0xF, 0xF, false);
-    constexpr int other = (Q & 4) ? 0x5 : 0xA;                 // the banks (quads) that do not hold lane q
-    return __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, other, false);
-}
-template <int Q>
-__device__ __forceinline__ double bcast8(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = bcast8_i<Q>((int)b), hi = bcast8_i<Q>((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
+// gshfl8(v, q): value of lane q of the caller's 8-lane group, q a constant after unrolling -> bcast8<q> (mpcx_device.hpp: two
+// v_mov_b64_dpp) instead of the ds_bpermute_b32 pair __shfl(v, q, 8) compiles to.  The sweeps exchange ~70 doubles per node
+// this way; as ds_bpermute they were 40 % of the kernel's LDS instructions, and at two waves per SIMD the CU's LDS pipe
+// (shared by its four SIMDs) is the resource the kernel saturates first (profiles/r02/pmc_sq.json: SQ_ACTIVE_INST_LDS).
 __device__ __forceinline__ double gshfl8(double v, int q)
 {
     switch (q) {

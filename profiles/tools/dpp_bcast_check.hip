@@ -1,5 +1,6 @@
-// profiling helper: checks the DPP broadcast inside 8-lane groups (two v_mov_b32_dpp per 32-bit half: quad_perm broadcast,
-// then row_half_mirror into the other quad under a bank mask) against __shfl(v, q, 8) for every source lane q.
+// profiling helper: checks the DPP broadcasts inside 8-lane groups (two v_mov_b32_dpp per 32-bit half: quad_perm broadcast,
+// then row_half_mirror into the other quad under a bank mask; and the two-instruction 64-bit row_newbcast form) against
+// __shfl(v, q, 8) for every source lane q.
 // build: hipcc --offload-arch=gfx950 -O2 -o dpp_bcast_check dpp_bcast_check.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,12 +22,22 @@ __device__ __forceinline__ double bcast8(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// The same broadcast as two 64-bit moves (gfx950: v_mov_b64_dpp exists for row_newbcast): lane q of every 16-lane row into
+// the whole row, then lane 8+q over the row's upper half under a bank mask.
+template <int Q>
+__device__ __forceinline__ double bcast8_nb(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const long long t = __builtin_amdgcn_update_dpp((long long)0, b, 0x150 + Q, 0xF, 0xF, true);
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(t, b, 0x150 + 8 + Q, 0xF, 0xC, false));
+}
+
 __global__ void check(int *bad)
 {
     const int lane = threadIdx.x;
     const double v = 1000.0 * lane + 0.25;
     int nb = 0;
-#define CHK(Q) { const double a = bcast8<Q>(v), b = __shfl(v, Q, 8); if (a != b) ++nb; }
+#define CHK(Q) { const double a = bcast8<Q>(v), b = __shfl(v, Q, 8), c = bcast8_nb<Q>(v); if (a != b) ++nb; if (c != b) ++nb; }
     CHK(0) CHK(1) CHK(2) CHK(3) CHK(4) CHK(5) CHK(6) CHK(7)
     if (nb) atomicAdd(bad, nb);
 }
