@@ -58,20 +58,29 @@ __global__ __launch_bounds__(64, PROBE_WAVES) void packed_probe_kernel(ProbeArgs
     const double *rec = a.rec + (size_t)sat * K * REC_N;
     const double *chin = a.chin + ((size_t)sat * K * NCH + ch) * CH_IN;
     double pc[7] = {0, 0, 0, 0, 0, 0, 0};                 // P_{k+1}[:, c] in the matrix lanes, p_{k+1} in the channel lanes
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int k = K - 1; k >= 0; --k) {
+    double nA[7], nbh[7], nbpm[7], nwx[7], nwu[3], nD[7], ngx[7], ngu[3], nrho[7], naff[7];
+    auto fetch = [&](int k) __attribute__((always_inline)) {
         const double *rk = rec + (size_t)k * REC_N;
         const double *ck = chin + (size_t)k * NCH * CH_IN;
-        double A[7], bh[7], bpm[7], wx[7], wu[3], D[7], gx[7], gu[3], rho[7], aff[7];
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            A[r] = rk[R_A + r * 7 + c]; wx[r] = rk[R_WX + r * 7 + c];
-            bh[r] = rk[R_BH + r * 3 + c3]; bpm[r] = rk[R_BPM + r * 3 + c3];
-            D[r] = rk[R_D + r];
-            gx[r] = ck[r]; rho[r] = ck[10 + r]; aff[r] = ck[17 + r];
+            nA[r] = rk[R_A + r * 7 + c]; nwx[r] = rk[R_WX + r * 7 + c];
+            nbh[r] = rk[R_BH + r * 3 + c3]; nbpm[r] = rk[R_BPM + r * 3 + c3];
+            nD[r] = rk[R_D + r];
+            ngx[r] = ck[r]; nrho[r] = ck[10 + r]; naff[r] = ck[17 + r];
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { wu[j] = rk[R_WU + j * 3 + c3]; gu[j] = ck[7 + j]; }
+        for (int j = 0; j < 3; ++j) { nwu[j] = rk[R_WU + j * 3 + c3]; ngu[j] = ck[7 + j]; }
+    };
+    fetch(K - 1);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int k = K - 1; k >= 0; --k) {
+        double A[7], bh[7], bpm[7], wx[7], wu[3], D[7], gx[7], gu[3], rho[7], aff[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) { A[r] = nA[r]; wx[r] = nwx[r]; bh[r] = nbh[r]; bpm[r] = nbpm[r]; D[r] = nD[r]; gx[r] = ngx[r]; rho[r] = nrho[r]; aff[r] = naff[r]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { wu[j] = nwu[j]; gu[j] = ngu[j]; }
+        fetch(k >= 1 ? k - 1 : 0);       // the next node's operands travel while this node computes (branch-free)
         // ---- A: L D L^T of M = D + P_{k+1}; L and 1/d end up replicated in every lane ----
         double m[7], L[21], rd[7];
 #pragma unroll
@@ -242,28 +251,42 @@ __global__ __launch_bounds__(64, PROBE_WAVES) void packed_forward_kernel(FwdArgs
     const bool mat = l < 7, chn = l >= 8;
     const int c = mat ? l : 0, c3 = (l < 3) ? l : 0, ch = chn ? l - 8 : 0;
     double y[7] = {0, 0, 0, 0, 0, 0, 0};
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int k = 0; k < K; ++k) {
+    double nA[7], nbh[7], nbpm[7], npn[7], nkg[3], nD[7], nL[21], nrd[7], nQi[9], nrho[7], naff[7], npp[7], nqu[3];
+    auto fetch = [&](int k) __attribute__((always_inline)) {
         const size_t nk = (size_t)sat * K + k;
         const double *rk = a.rec + nk * REC_N;
         const double *ck = a.chin + (nk * NCH + ch) * CH_IN;
-        const bool dyn = k <= K - 2;
-        const size_t nk1 = dyn ? nk + 1 : nk;
-        double A[7], bh[7], bpm[7], pn[7], kg[3], D[7], L[21], rd[7], Qi[9], rho[7], aff[7], pp[7], qu[3];
+        const size_t nk1 = (k <= K - 2) ? nk + 1 : nk;
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            A[r] = rk[R_A + r * 7 + c]; bh[r] = rk[R_BH + r * 3 + c3]; bpm[r] = rk[R_BPM + r * 3 + c3];
-            pn[r] = dyn ? a.P[nk1 * 49 + r * 7 + c] : 0.0;
-            D[r] = rk[R_D + r]; rd[r] = a.Lrd[nk * 28 + 21 + r];
-            rho[r] = ck[10 + r]; aff[r] = ck[17 + r];
-            pp[r] = dyn ? a.p[(nk1 * NCH + ch) * 7 + r] : 0.0;
+            nA[r] = rk[R_A + r * 7 + c]; nbh[r] = rk[R_BH + r * 3 + c3]; nbpm[r] = rk[R_BPM + r * 3 + c3];
+            npn[r] = a.P[nk1 * 49 + r * 7 + c];
+            nD[r] = rk[R_D + r]; nrd[r] = a.Lrd[nk * 28 + 21 + r];
+            nrho[r] = ck[10 + r]; naff[r] = ck[17 + r];
+            npp[r] = a.p[(nk1 * NCH + ch) * 7 + r];
         }
 #pragma unroll
-        for (int e = 0; e < 21; ++e) L[e] = a.Lrd[nk * 28 + e];
+        for (int e = 0; e < 21; ++e) nL[e] = a.Lrd[nk * 28 + e];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Qi[e] = a.Qi[nk * 9 + e];
+        for (int e = 0; e < 9; ++e) nQi[e] = a.Qi[nk * 9 + e];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { kg[j] = a.Kg[nk * 21 + j * 7 + c]; qu[j] = a.qu[(nk * NCH + ch) * 3 + j]; }
+        for (int j = 0; j < 3; ++j) { nkg[j] = a.Kg[nk * 21 + j * 7 + c]; nqu[j] = a.qu[(nk * NCH + ch) * 3 + j]; }
+    };
+    fetch(0);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < K; ++k) {
+        const size_t nk = (size_t)sat * K + k;
+        const bool dyn = k <= K - 2;
+        double A[7], bh[7], bpm[7], pn[7], kg[3], D[7], L[21], rd[7], Qi[9], rho[7], aff[7], pp[7], qu[3];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) { A[r] = nA[r]; bh[r] = nbh[r]; bpm[r] = nbpm[r]; pn[r] = dyn ? npn[r] : 0.0; D[r] = nD[r]; rd[r] = nrd[r]; rho[r] = nrho[r]; aff[r] = naff[r]; pp[r] = dyn ? npp[r] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 21; ++e) L[e] = nL[e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Qi[e] = nQi[e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { kg[j] = nkg[j]; qu[j] = nqu[j]; }
+        fetch(k + 1 < K ? k + 1 : K - 1);       // branch-free prefetch of the next node
         // u = -Kg y - Quu^-1 qu
         double u[3];
 #pragma unroll
