@@ -440,7 +440,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
 #define TRIAL(P, D, off) trial_value(P, D, off, a, z)
     for (int k = NODE_OF(lane); k < K; k += 32) {
-        const auto p = s.itn(k), d = s.drn(k), w = s.itBn(k);
+        const auto p = s.itn(k), d = s.drn(k), w = s.itBn(k), nsv = s.nsn(k);
         const bool has_prev = (k >= 1), dyn = (k <= K - 2);
         // ---- chunk 0 (both halves, accounted by half 0): states, thrust, ball slacks, objective gradient ----
         double x[7], u[3], gx[7], gu[3], un[3];
@@ -533,6 +533,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
                     ACC_P(xn - acc);
+                    nsv[NS_E + i] = xn - acc;       // e_k of this point: newton_blocks takes it from here (see there)
                     sl += sg * lam;
                     lsum += fabs(lam);
                     // nu / t stationarity
@@ -646,7 +647,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
 {
     const int K = s.K;
     const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
-    const double tf = s.itg[G_TF];
     const int half = HALF_OF(lane);
     const bool h0 = (half == 0);
     double sigmax = 0.0;                                   // largest barrier weight z/s of the stage constraints
@@ -655,9 +655,9 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         const auto rb = s.rbn(k);
         gf64 *nb = s.nb + (size_t)k * NB_N;
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
-        // ---- chunk 0: objective, thrust ball, radius balls; next node's x, u for the dynamics residual ----
+        // ---- chunk 0: objective, thrust ball, radius balls ----
         // (chunk 0 is computed by both halves and stored by half 0)
-        double x[7], u[3], un[3], gx[7], gu[3], Wx3[9];
+        double x[7], u[3], gx[7], gu[3], Wx3[9];
         double zh_rmax = 0.0, sig_rmax = 0.0, zrmax;
         {
             double bs[6], xb[7], ub[3];
@@ -667,9 +667,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; ub[i] = s.ubar[(size_t)i * K + k]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
-            const auto pn = p.node(dyn ? 1 : 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) un[i] = pn[I_U + i];
             const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
             const double rbv[3] = {rb0, rb1, rb2};
             const double su = bs[0], zu = bs[1], srmax = bs[2], srmin = bs[4], zrmin = bs[5];
@@ -745,22 +742,15 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         }
         CHUNK_END
         // ---- four rounds: component i = 4*half + r of the virtual-control block (t eliminated, D and rho kept
-        //      without multipliers) and of the dynamics residual e_k ----
+        //      without multipliers).  The dynamics residual e_k of the iterate is already in the Newton scalars: the
+        //      residual evaluation that produced this iterate (the accepted trial of the line search, or the start
+        //      point's) stored it -- no second pass over the stage matrices here ----
         {
-            const auto A = s.At(dyn ? k : 0), Bn = s.Bnt(dyn ? k : 0), Bp = s.Bpt(dyn ? k : 0), Sg = s.Sigt(dyn ? k : 0), xi = s.xit(dyn ? k : 0);
-            const auto pn = p.node(dyn ? 1 : 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int iv = 4 * half + r;
                 const bool valid = (iv < 7) && dyn;
                 const int i = (iv < 7) ? iv : 6;
-                const double xni = pn[I_X + i];
-                double ar[7], bn[3], bp[3];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) ar[j] = A[i * 7 + j];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; }
-                const double sg = Sg[i], xv = xi[i];
                 const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
                 const double stn = p[I_STN + i], ztn = p[I_ZTN + i];
                 const double g1 = nu - tt, g2 = -nu - tt;
@@ -770,19 +760,13 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
                 const double ia = rcp_pos(aa);
                 const double dd = 4.0 * s1 * s2 * ia;
-                double acc = sg * tf + xv + nu;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc += ar[j] * x[j];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc += bn[j] * u[j] + bp[j] * un[j];
                 if (valid) {
                     nb[N_D + i] = dd; ns[NS_D + i] = dd;
                     ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
                     ns[NS_RHO + i] = (zh1 - zh2) - (bb * ia) * gt;
-                    ns[NS_E + i] = xni - acc;
                 }
-                CHUNK_END
             }
+            CHUNK_END
         }
         if (h0 && k == K - 1) {
             // terminal node: soft gradient, the five rank-1 barrier terms, the pieces of the terminal Hessians (the
