@@ -654,6 +654,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
         gf64 *nb = s.nb + (size_t)k * NB_N;
+        gf64 *rhs = s.ch + (size_t)k * CH_N + C_RHS;
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
         // ---- chunk 0: objective, thrust ball, radius balls ----
         // (chunk 0 is computed by both halves and stored by half 0)
@@ -730,6 +731,14 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
+                // right-hand-side record of the iteration's first solve (= the Newton blocks; the zero direction carries
+                // no multipliers): x_0 is fixed (no row), the terminal node's gradient is written with its Hessians below
+#pragma unroll
+                for (int i = 0; i < 3; ++i) rhs[R_GU + i] = gu[i];
+                if (k != K - 1) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) rhs[R_GX + i] = (k == 0) ? 0.0 : gx[i];
+                }
             }
             if (h0 && k != K - 1) {
                 // stage Hessian of x: diagonal + the 3x3 position block (the terminal node's slot is written below)
@@ -760,11 +769,14 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
                 const double ia = rcp_pos(aa);
                 const double dd = 4.0 * s1 * s2 * ia;
+                const double ek = ns[NS_E + i];
+                const double rho = (zh1 - zh2) - (bb * ia) * gt;
                 if (valid) {
                     nb[N_D + i] = dd; ns[NS_D + i] = dd;
                     ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
-                    ns[NS_RHO + i] = (zh1 - zh2) - (bb * ia) * gt;
+                    ns[NS_RHO + i] = rho;
                 }
+                if (iv < 7) { rhs[R_RHO + i] = dyn ? rho : 0.0; rhs[R_AFF + i] = dyn ? -ek : 0.0; }
             }
             CHUNK_END
         }
@@ -819,6 +831,18 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
             for (int i = 0; i < 6; ++i) an += g6[i] * g6[i];
             // (convex variant: the capped share of the pair's weight takes the place of the AL weight)
             sd.gam = sd.linvt ? fmin(sd.w_vt, kTermCap) : (kTermCap + 10.0 * fabs(lvt) * sqrt(hn)) / an;
+            // terminal node's gradient of the first solve: soft gradient + capped share of the rank-1 gradient terms and
+            // the AL shift (rvt = the vt row's right-hand side at the zero direction, see first_rhs_scalars)
+            {
+                const double rvt = sd.linvt ? -sd.gh_vt / sd.w_vt : -sd.cv;
+                double gK[7];
+                for (int i = 0; i < 7; ++i) gK[i] = gx[i];
+                for (int t = 0; t < NTERM; ++t) {
+                    const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+                    for (int i = 0; i < 7; ++i) gK[i] += sd.tgh[t] * share * sd.ta[t][i];
+                }
+                for (int i = 0; i < 7; ++i) rhs[R_GX + i] = gK[i] - sd.gam * rvt * sd.avt[i];
+            }
         }
     }
     sigmax = wave_max(sigmax);
@@ -1840,45 +1864,14 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
 
 // Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
 // themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).  Lane k writes node k's record.
-__device__ __noinline__ void initial_rhs(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
+__device__ __forceinline__ void first_rhs_scalars(const SatData &sd, double &gtf_rhs, double &rvt_rhs, double *gex)
 {
-    const int K = s.K;
     gtf_rhs = sd.gtf;
     rvt_rhs = sd.linvt ? -sd.gh_vt / sd.w_vt : -sd.cv;       // (convex variant: the pair's zeta row at the zero direction)
-    double gterm[NTERM];
     for (int t = 0; t < NTERM; ++t) {
-        gterm[t] = sd.tgh[t];
         const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-        gex[t] = gterm[t] * (1.0 - share);          // = wex * gh / w: the zeta row's residual at the zero direction, times wex
+        gex[t] = sd.tgh[t] * (1.0 - share);         // = wex * gh / w: the zeta row's residual at the zero direction, times wex
     }
-    for (int k = lane; k < K; k += 64) {
-        const auto ns = s.nsn(k);
-        gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
-        const bool dyn = (k <= K - 2);
-        double gx[7], gu[3], rho[7], e[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { gx[i] = ns[NS_GX + i]; rho[i] = ns[NS_RHO + i]; e[i] = ns[NS_E + i]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = ns[NS_GU + i];
-        if (k == 0) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) gx[i] = 0.0;
-        }
-        if (k == K - 1) {
-            // terminal node: soft gradient + capped share of the rank-1 gradient terms and the AL shift
-            for (int i = 0; i < 7; ++i) gx[i] = sd.gxKsoft[i];
-            for (int t = 0; t < NTERM; ++t) {
-                const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-                for (int i = 0; i < 7; ++i) gx[i] += gterm[t] * share * sd.ta[t][i];
-            }
-            for (int i = 0; i < 7; ++i) gx[i] -= sd.gam * rvt_rhs * sd.avt[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { rec[R_GX + i] = gx[i]; rec[R_RHO + i] = dyn ? rho[i] : 0.0; rec[R_AFF + i] = dyn ? -e[i] : 0.0; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
-    }
-    __syncthreads();
 }
 
 // dt, ds, dz by back-substitution ("Linear solve") and the fraction-to-the-boundary step.
@@ -2207,9 +2200,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             newton_blocks(s, sd, mu, delta_w, lane);
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
-            PT_BEGIN
-            initial_rhs(s, sd, lane, gtf_rhs, rvt_rhs, gex);        // right-hand side of the first solve = the Newton blocks
-            PT_END(5)
+            first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
             // iterative refinement only once a barrier weight (terminal rank-1 terms, stage balls and planes, the tf
             // bounds) is stiff enough to cost digits
             double twmax = sd.sigmax;
