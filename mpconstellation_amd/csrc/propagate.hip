@@ -60,9 +60,11 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
 {
     const int Ku = c.Ku;
     const double *__restrict__ u = c.useq;
-    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
-    // well inside the interval in use (away from its ends by more than any rounding of the index computation): same k
+    // well inside the interval in use (away from its ends by more than any rounding of the index computation): same k.
+    // Everything else -- a new interval, an end point, tau == 1 -- is behind this one rarely taken branch: the right-hand
+    // side is evaluated six times per step and every branch in it costs the in-order wave ~40 cycles.
     if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
+    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
     const double km1 = (double)(Ku - 1);
     const double q = tau * km1;
     int k = (fabs(q - rint(q)) > 1e-9 * fmax(1.0, q)) ? (int)floor(q) : (int)py_floordiv(tau, 1.0 / km1);
@@ -109,13 +111,19 @@ __device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double in
         const double k = c.v[0] * (ihn * irn);
         u[0] = k * (h[1] * y[2] - h[2] * y[1]); u[1] = k * (h[2] * y[0] - h[0] * y[2]); u[2] = k * (h[0] * y[1] - h[1] * y[0]);
         un = fabs(c.v[0]);                                   // |h_hat x r_hat| = 1 (h is normal to r)
-    } else if (KIND == MPCX_CTRL_SEQUENCE && tau <= c.end_tau) {      // control.py:132-142
-        // tau / end_tau: reciprocal, product and one correction step (the quotient as the division sequence rounds it)
+    } else if (KIND == MPCX_CTRL_SEQUENCE) {                          // control.py:132-142
+        // tau / end_tau: reciprocal, product and one correction step (the quotient as the division sequence rounds it).
+        // Past end_tau the thrust is zero: no branch, the table is read at the middle of the interval in use (always a
+        // valid argument) and the result discarded.
+        const bool live = tau <= c.end_tau;
         double tn = tau * c.inv_end_tau;
         tn = fma(fma(-tn, c.end_tau, tau), c.inv_end_tau, tn);
+        tn = live ? tn : ((c.kc >= 0) ? 0.5 * (c.tau_k + c.tau_kp1) : 0.5);
         foh3_cached(tn, c, u, err);
         const double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-        un = uu * rsq_fast(fmax(uu, 1e-300));                 // |u| (0 for u = 0)
+        un = live ? uu * rsq_fast(fmax(uu, 1e-300)) : 0.0;    // |u| (0 for u = 0)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = live ? u[i] : 0.0;
     } else { u[0] = u[1] = u[2] = 0.0; un = 0.0; }
     const double kg = -cst.mu * (irn2 * irn);
 #pragma unroll
