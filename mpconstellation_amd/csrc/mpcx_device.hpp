@@ -88,11 +88,11 @@ struct FohCache {
 __device__ __forceinline__ void foh3_cached(double tau, const double *__restrict__ u, int Ku, FohCache &c, double (&out)[3],
                                             int &err)
 {
-    if (tau == 1.0) {
-        out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1];
-        return;
-    }
-    if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
+    if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {      // rare: everything but "same interval" is behind this branch
+        if (tau == 1.0) {
+            out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1];
+            return;
+        }
         const double km1 = (double)(Ku - 1);
         const double dtau = 1.0 / km1;
         int k = (int)py_floordiv(tau, dtau);
