@@ -174,6 +174,45 @@ def test_optimizer_class_drop_in(golden_dir):
     assert sim.sim_data[sat.id].shape == (7, 50) and np.isfinite(sim.sim_data[sat.id]).all()
 
 
+def test_reference_test_optimizer_as_written():
+    """test_optimizer.py:18-69 with the resolution it hard-codes: Hubble, constant tangential thrust 0.5, tf = 2, base_res = 100
+    -> K = 200 nodes, r_des = |r_bar_K|, every other option at its default.  The reference's classes end to end on the
+    device; the oracle (its own rollout, its own discretisation) must land on the same solution."""
+    from mpconstellation_amd import (Satellite, SatelliteScale, Simulator, Discretizer, Optimizer,
+                                     ConstantTangentialThrustController, SequenceController)
+    sat = Satellite(np.array([5371.4806, -4133.1393, 1399.9594]) * 1000, np.array([4.6921, 4.9848, -3.2752]) * 1000, 12200)
+    scale = SatelliteScale(sat=sat); const = scale.get_normalized_constants()
+    c = ConstantTangentialThrustController([sat], 0.5)
+    tf, base_res = 2, 100
+    sim = Simulator(sats=[sat], controller=c, scale=scale, base_res=base_res, include_drag=False, include_J2=False)
+    sim.run(tf=tf)
+    x = sim.sim_data[sat.id]; K = x.shape[1]
+    assert K == 200
+    d = Discretizer(const, use_scipy_ZOH=False, include_drag=False, include_J2=False)
+    u_bar = Discretizer.extract_uk(x, sim.sim_time[sat.id], c)
+    opt = Optimizer([x], [u_bar], [np.zeros((7, K))], tf, d, Simulator.satellite_dynamics, scale, verbose=False)
+    r_des = float(np.linalg.norm(x[0:3, -1]))
+    opt.solve_OPT(input_options={'r_des': r_des})
+    assert opt.status[0] == 0 and opt.result.kkt[0] <= 1e-8
+    X, U = opt.get_solved_trajectory(0), opt.get_solved_u(0)
+    assert X.shape == (7, K) and U.shape == (3, K) and opt.get_solved_nu(0).shape == (7, K)
+    # oracle chain from the same initial state
+    cst = const.as_vector()
+    tan = O.make_ctrl(O.CTRL_TANGENTIAL, (0.5, 0, 0))
+    xo, rc, _ = O.propagate(x[:, 0], float(tf), cst, tan, K)
+    assert rc == 0 and np.abs(xo - x).max() < 1e-9
+    uo = O.extract_uk(xo, np.linspace(0, 1, K), tan)
+    P, ref = oracle_solve(xo, uo, float(tf), cst, float(np.linalg.norm(xo[:3, -1])))
+    assert ref["status"] == 0
+    assert abs(opt.get_solved_tf(0) - ref["tf"]) < TOL_SOL and np.abs(X - ref["X"]).max() < TOL_SOL
+    assert np.abs(U - ref["U"]).max() < 5e-4                            # u is held only by 2 w_tr = 0.004
+    # the forward simulation the reference test ends with (:66-74)
+    c_opt = SequenceController(u=U, tf_u=opt.get_solved_tf(0), tf_sim=5)
+    sim = Simulator(sats=[sat], controller=c_opt, scale=scale, base_res=base_res, include_drag=False, include_J2=False)
+    sim.run(tf=5)
+    assert sim.sim_data[sat.id].shape == (7, 500) and np.isfinite(sim.sim_data[sat.id]).all()
+
+
 def test_page_locked_arrays_give_the_same_result(golden_dir):
     """mpcx_host_alloc: caller arrays in page-locked memory are transferred without the staging copy; same results bit for
     bit, and the result buffers of pinned_results=True are reused by the next call of the same shape."""
