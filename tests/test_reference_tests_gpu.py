@@ -1,7 +1,7 @@
 """The reference's own test scripts, run as written through the drop-in classes on the device and checked against the CPU
 oracle (the reference's tests only print and plot; their configurations are what is mirrored here):
 test_discretizer.py:88-118 (test_linearize_many), :120-150 (test_linearize_tangential), test_simulator.py:57-77
-(test_run_segment), :149-173 (test_run_segments).  test_optimizer.py and test_mpc are in test_solve_gpu.py /
+(test_run_segment), :149-173 (test_run_segments), :17-34 and :175-203 (the long rollouts).  test_optimizer.py and test_mpc are in test_solve_gpu.py /
 test_mpc_loop_gpu.py."""
 import os
 import sys
@@ -107,3 +107,27 @@ def test_run_segments_as_written():
         assert np.abs(sim.sim_data[s.id] - np.concatenate(parts, axis=1)).max() < 1e-9
     # thrusting along the velocity raises the orbit and burns mass
     assert np.linalg.norm(sim.sim_data[sat.id][:3, -1]) > 1.0 and sim.sim_data[sat.id][6, -1] < 1.0
+
+
+@pytest.mark.parametrize("case", ["default_tf5", "constant_tf15", "tangential_tf5"])
+def test_long_rollouts_as_written(case):
+    """test_simulator.py:17-34, :175-203: the default controller for 5 orbits, ConstantThrustController(thrust=[0, 0, 0.1]) for
+    15, ConstantTangentialThrustController(tangential_thrust=0.1) for 5 -- constructed with the keyword arguments the
+    reference's tests use, default resolution (100 per orbit) and truth model (drag and J2 on)."""
+    from mpconstellation_amd import (Satellite, SatelliteScale, Simulator, ConstantThrustController,
+                                     ConstantTangentialThrustController)
+    sat = Satellite(R0, V0, M0)
+    scale = SatelliteScale(sat=sat); cst = scale.get_normalized_constants().as_vector()
+    if case == "default_tf5":
+        sim, tf, oc = Simulator(sats=[sat], scale=scale), 5, O.make_ctrl(O.CTRL_ZERO)
+    elif case == "constant_tf15":
+        c = ConstantThrustController(thrust=np.array([0., 0., 0.1]))
+        sim, tf, oc = Simulator(sats=[sat], controller=c, scale=scale), 15, O.make_ctrl(O.CTRL_CONSTANT, (0.0, 0.0, 0.1))
+    else:
+        c = ConstantTangentialThrustController(tangential_thrust=0.1)
+        sim, tf, oc = Simulator(sats=[sat], controller=c, scale=scale), 5, O.make_ctrl(O.CTRL_TANGENTIAL, (0.1, 0, 0))
+    data, time = sim.run(tf=tf)
+    x = data[sat.id]
+    assert x.shape == (7, 100 * tf) and time[sat.id].shape == (100 * tf,)
+    xo, rc, _ = O.propagate(scale.normalize_state(sat.get_state_vector()), float(tf), cst, oc, 100 * tf, flags=3)
+    assert rc == 0 and np.abs(x - xo).max() < 1e-8 * max(1.0, np.abs(xo).max())
