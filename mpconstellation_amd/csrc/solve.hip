@@ -15,7 +15,7 @@
 //    solved by a symmetric quasi-definite LDL^T whose pivot signs also give the inertia; eight linear-term sweeps (1 right-hand side + 7 border columns) run side
 //    by side in the 8 lane groups of the wave, the backward one fused into the factorisation loop; iterative
 //    refinement on the reduced KKT system only once a terminal weight is stiff enough to cost digits.
-// Per-satellite state lives in a global-memory workspace (ws_doubles: 224 KB at K = 30); no MFMA.
+// Per-satellite state lives in a global-memory workspace (ws_doubles: 215 KB at K = 30); no MFMA.
 #include <cstddef>
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
@@ -33,9 +33,12 @@ enum { G_STERM = 0, G_ZTERM = 6, G_SRF = 12, G_ZRF = 13, G_STF = 14, G_ZTF = 16,
 __host__ __device__ inline int gs_term(int j) { return j < 6 ? G_STERM + j : G_SVT + (j - 6); }
 __host__ __device__ inline int gz_term(int j) { return j < 6 ? G_ZTERM + j : G_ZVT + (j - 6); }
 // Newton blocks per node: the part the recursion reads as one contiguous record per node ...
-// (N_SX: the stage's stiff barrier terms -- excess weight above kStageCap and direction of the position term (r_min
-//  plane or radius ball) and of the thrust ball; the blocks N_WX / N_WU carry only the capped share, see riccati_factor)
-enum { N_WX = 0, N_WU = 49, N_D = 58, N_SX = 65, NB_N = 73 };
+// (N_W3, N_DIAG, N_ZERO: the stage Hessian of x is diag(N_DIAG) with its 3x3 position block replaced by N_W3 -- stored in
+//  that form, 11 doubles instead of 49 (N_ZERO holds 0.0: what the off-diagonal lanes of the expanding fetch read), and
+//  expanded when the recursion fetches it into LDS; the terminal node's full matrix lives in SatData.  N_SX: the stage's stiff barrier terms -- excess weight above kStageCap and direction of the position
+//  term (r_min plane or radius ball) and of the thrust ball; the blocks N_W3 / N_WU carry only the capped share, see
+//  riccati_factor)
+enum { N_W3 = 0, N_DIAG = 9, N_ZERO = 10, N_WU = 11, N_D = 20, N_SX = 27, NB_N = 35 };
 enum { SX_EX = 0, SX_A = 1, SX_EU = 4, SX_CU = 5, SX_N = 8 };
 // ... and the part only the node-parallel phases touch (field-major, see Col below)
 enum { NS_AA = 0, NS_BB = 7, NS_GT = 14, NS_RHO = 21, NS_GX = 28, NS_GU = 35, NS_E = 38, NS_D = 45, NS_N = 52 };
@@ -741,12 +744,10 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 }
             }
             if (h0 && k != K - 1) {
-                // stage Hessian of x: diagonal + the 3x3 position block (the terminal node's slot is written below)
+                // stage Hessian of x: diagonal + the 3x3 position block (the terminal node's matrix goes to SatData below)
 #pragma unroll
-                for (int i = 0; i < 7; ++i)
-#pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        nb[N_WX + i * 7 + j] = (i < 3 && j < 3) ? Wx3[i * 3 + j] : (i == j ? 2.0 * w_tr + delta_w : 0.0);
+                for (int i = 0; i < 9; ++i) nb[N_W3 + i] = Wx3[i];
+                nb[N_DIAG] = 2.0 * w_tr + delta_w; nb[N_ZERO] = 0.0;
             }
         }
         CHUNK_END
@@ -858,7 +859,6 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
         for (int t = 0; t < NTERM; ++t) full += sd.twin[t] * sd.ta[t][i] * sd.ta[t][j];
         full += sd.gam * sd.avt[i] * sd.avt[j];
         sd.WxKsoft[lane] = soft; sd.WxK[lane] = full;
-        s.nb[(size_t)(K - 1) * NB_N + N_WX + lane] = full;
     }
     if (lane == 0 && sd.fixed_tf) { sd.Wtf = 1.0; sd.gtf = 0.0; sd.sigmax = sigmax; }
     else if (lane == 0) {
@@ -914,7 +914,7 @@ struct StageOps {
     double Bn[21], Bpm[21], Wu[9], D[7], SX[SX_N];        // the rest of the prefetched inputs (fetch order A Bn Bpm Wx Wu D SX)
     double G[49], Pt[49], Minv[49], Kg[21];
 };
-constexpr int OPS_IN = 91 + NB_N;
+constexpr int OPS_IN = 91 + 49 + 9 + 7 + SX_N;   // A 49 | Bn 21 | Bpm 21 | Wx 49 (expanded) | Wu 9 | D 7 | SX 8
 
 struct Scratch {   // LDS working set of the recursion
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
@@ -1108,16 +1108,25 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         pnext = sact ? pp : pnext;
     };
     // operand prefetch: node k's (A, Bn | Bpm | Wx, Wu, D) -> registers -> LDS buffer.  Three branch-free loads per
-    // lane: A, Bn are the head of stage record k, Bpm = B_kp of record k-1 (same offset), Wx|Wu|D the head of the
-    // Newton-block record; what node k does not have (no dynamics at K-1, no Bpm at 0) is zeroed when stashed.
+    // lane: A, Bn are the head of stage record k, Bpm = B_kp of record k-1 (same offset), Wx (expanded from its compact
+    // form) | Wu | D | SX from the Newton-block record; what node k does not have (no dynamics at K-1, no Bpm at 0) is
+    // zeroed when stashed.
     double pre[3];
     const int e1 = lane + 64, e2 = lane + 128;
+    // element q of the 7 x 7 stage Hessian in the compact Newton record: its 3x3 block entry, the common diagonal value, or
+    // the record's zero
+    auto wx_src = [](int q) -> int {
+        const int i = q / 7, j = q - 7 * i;
+        return (i < 3 && j < 3) ? N_W3 + i * 3 + j : (i == j ? N_DIAG : N_ZERO);
+    };
+    const int wx1 = (e1 >= 91) ? wx_src(e1 - 91) : 0;
+    const int src2 = (e2 < 140) ? wx_src(e2 - 91) : (e2 < OPS_IN ? N_WU + (e2 - 140) : 0);
     auto fetch = [&](int k) {
         cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
         cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
         cgf64 *nb = s.nb + (size_t)k * NB_N;
-        cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + (e1 - 91);
-        cgf64 *p2 = nb + (e2 < OPS_IN ? e2 - 91 : 0);
+        cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
+        cgf64 *p2 = nb + src2;
         pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
     };
     // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7 | SX 8]
@@ -1140,6 +1149,8 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     };
     fetch(K - 1);
     stash(w.ops[(K - 1) & 1], K - 1);
+    // (the terminal node's Hessian -- soft part, capped rank-1 terms, AL term -- is a full matrix: from SatData)
+    if (lane < 49) w.ops[(K - 1) & 1].G2[(lane / 7) * FS + lane % 7] = sd.WxK[lane];
     for (int e = lane; e < 49; e += 64) w.Pn[e] = 0.0;
     if (lane == 0) w.zero = 0.0;
     __syncthreads();
@@ -1747,13 +1758,27 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         }
         double gx[7], gu[3];
         if (k >= 1) {
-            const double *W = (k == K - 1) ? (const double *)sd.WxKsoft : (const double *)(nb + N_WX);   // LDS or HBM: generic
+            if (k == K - 1) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                double acc = ((k == K - 1) ? sd.gxKsoft[i] : ns[NS_GX + i]) + ltm[i];
+                for (int i = 0; i < 7; ++i) {
+                    double acc = sd.gxKsoft[i] + ltm[i];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc += W[i * 7 + j] * d[I_X + j];
-                gx[i] = acc;
+                    for (int j = 0; j < 7; ++j) acc += sd.WxKsoft[i * 7 + j] * d[I_X + j];
+                    gx[i] = acc;
+                }
+            } else {
+                // stage Hessian in its compact form: the 3x3 position block, the common diagonal value elsewhere (the
+                // entries left out are exact zeros: same sums as with the full matrix)
+                const double dg = nb[N_DIAG];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    double acc = ns[NS_GX + i] + ltm[i];
+                    if (i < 3) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc += nb[N_W3 + i * 3 + j] * d[I_X + j];
+                    } else acc += dg * d[I_X + i];
+                    gx[i] = acc;
+                }
             }
             if (k == K - 1) {
                 const double lvt = s.itg[G_LVT] + s.drg[G_LVT];
@@ -1771,7 +1796,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             gu[i] = acc;
         }
         {
-            // the stiff stage terms' excess weight, which the blocks N_WX / N_WU do not carry (newton_blocks)
+            // the stiff stage terms' excess weight, which the blocks N_W3 / N_WU do not carry (newton_blocks)
             const double ex_x = nb[N_SX + SX_EX], ex_u = nb[N_SX + SX_EU];
             const double a0 = nb[N_SX + SX_A], a1 = nb[N_SX + SX_A + 1], a2 = nb[N_SX + SX_A + 2];
             const double c0 = nb[N_SX + SX_CU], c1 = nb[N_SX + SX_CU + 1], c2 = nb[N_SX + SX_CU + 2];
