@@ -646,17 +646,23 @@ __device__ double scaled_error(const ResAcc &r, int K, int nT, int fixed_tf, dou
 }
 
 // ---- Newton blocks (stage-parallel) ------------------------------------------------------------
-__device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu, double delta_w, int lane)
+// stg: LDS staging area of 32 * NB_N doubles (the recursion's scratch, idle during this phase).  A node's Newton record is
+// assembled there and the 32 records of a round go out as one contiguous, coalesced block: written straight from the node
+// lanes they were 8-byte stores scattered over 32 cache lines per instruction (measured: the 40 stores per node that the
+// compact Hessian form removed were 6 % of the launch at S = 4096).
+__device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *stg, double mu, double delta_w, int lane)
 {
     const int K = s.K;
     const double w_tr = sd.w_tr, w_nu = sd.w_nu, b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
     const int half = HALF_OF(lane);
     const bool h0 = (half == 0);
     double sigmax = 0.0;                                   // largest barrier weight z/s of the stage constraints
-    for (int k = NODE_OF(lane); k < K; k += 32) {
+    for (int k0 = 0; k0 < K; k0 += 32) {
+      const int k = k0 + NODE_OF(lane);
+      if (k < K) {
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
-        gf64 *nb = s.nb + (size_t)k * NB_N;
+        double *nb = stg + NODE_OF(lane) * NB_N;
         gf64 *rhs = s.ch + (size_t)k * CH_N + C_RHS;
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
         // ---- chunk 0: objective, thrust ball, radius balls ----
@@ -844,7 +850,18 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double mu,
                 }
                 for (int i = 0; i < 7; ++i) rhs[R_GX + i] = gK[i] - sd.gam * rvt * sd.avt[i];
             }
+            // (the terminal node's Hessian lives in SatData: its compact slots are unused, kept defined)
+#pragma unroll
+            for (int i = 0; i <= N_ZERO; ++i) nb[i] = 0.0;
         }
+      }
+      __syncthreads();
+      {
+          const int ne = ((K - k0 < 32) ? K - k0 : 32) * NB_N;
+          gf64 *dst = s.nb + (size_t)k0 * NB_N;
+          for (int e = lane; e < ne; e += 64) dst[e] = stg[e];
+      }
+      __syncthreads();
     }
     sigmax = wave_max(sigmax);
     __syncthreads();
@@ -916,7 +933,7 @@ struct StageOps {
 };
 constexpr int OPS_IN = 91 + 49 + 9 + 7 + SX_N;   // A 49 | Bn 21 | Bpm 21 | Wx 49 (expanded) | Wu 9 | D 7 | SX 8
 
-struct Scratch {   // LDS working set of the recursion
+struct Scratch {   // LDS working set of the recursion (and, between recursions, the staging area of newton_blocks)
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
         StageOps ops[2];
         double flat[2][FLAT_N];    // sweep operands of one node, double-buffered (fac record + A, Bpm, D)
@@ -928,6 +945,8 @@ struct Scratch {   // LDS working set of the recursion
     double Quu[9];
     double zero;                   // constant 0 (addend of the tasks that have none)
 };
+
+static_assert(sizeof(Scratch) >= 32 * NB_N * sizeof(double), "newton_blocks stages 32 Newton records in the recursion's scratch");
 
 template <int N>
 __device__ __forceinline__ double dotN(const double *a, int sa, const double *b, int sb)
@@ -2222,7 +2241,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         // the last value that worked (1e-4 the first time), growing by 8 (by 100 until some value has worked), up to 1e40
         while (!have_dir && delta_w <= kDwMax) {
             PT_BEGIN
-            newton_blocks(s, sd, mu, delta_w, lane);
+            newton_blocks(s, sd, (double *)&w, mu, delta_w, lane);
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
             first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
