@@ -1562,7 +1562,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
 // four components per lane and round so that their loads are in flight together.  `first` (the plain solve of an
 // iteration): the direction is written, with -lam as the starting value of the multiplier part (the first
 // right-hand side carries no multipliers); otherwise (refinement) the correction is added.
-__device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int lane, bool first)
+__device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, double *stg, int lane, bool first)
 {
     const Sat s = uniform_view(s_in);
     const int K = s.K, KP = s.KP;
@@ -1571,30 +1571,42 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, int 
     for (int j = 0; j < NBD; ++j) sol[j] = sd.sol[j];
     gf64 *dr = wave_uniform(s.dr);
     cgf64 *it = wave_uniform((cgf64 *)s.it), *traj = wave_uniform((cgf64 *)s.traj);
-    const int n = K * TR_N;
-    for (int e0 = 0; e0 < n; e0 += 256) {
-        double v[4], base[4];
-        int dst[4];
-        bool act[4];
+    // Rounds of 32 nodes.  The trajectories are read in their own order (node, channel, component: contiguous), the
+    // combination goes through LDS (stg: the recursion's scratch, [component][node of the round]) and leaves in the
+    // direction's field-major order, consecutive lanes on consecutive nodes: written straight from the reading lanes
+    // the direction was 8-byte stores scattered over as many cache lines as lanes.
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int nk = (K - k0 < 32) ? K - k0 : 32;
+        const int n = nk * TR_N;
+        for (int e0 = 0; e0 < n; e0 += 256) {
+            double v[4];
+            int slot[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + 64 * q + lane;
-            const int ec = (e < n) ? e : 0;
-            const int k = ec / TR_N, i = ec - k * TR_N;
-            act[q] = (e < n) && !(k == K - 1 && i >= T_NU);
-            cgf64 *tr = traj + (size_t)k * NCH * TR_N + i;
-            const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
-            dst[q] = off * KP + k;
-            // starting value: -lam for the multiplier part of the first solve, the current direction when refining
-            const double cur = first ? it[dst[q]] : dr[dst[q]];
-            base[q] = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
-            double acc = tr[0];
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + 64 * q + lane;
+                const int ec = (e < n) ? e : 0;
+                const int kl = ec / TR_N, i = ec - kl * TR_N;
+                cgf64 *tr = traj + (size_t)(k0 + kl) * NCH * TR_N + i;
+                double acc = tr[0];
 #pragma unroll
-            for (int j = 0; j < NBD; ++j) acc += sol[j] * tr[(1 + j) * TR_N];
-            v[q] = acc;
+                for (int j = 0; j < NBD; ++j) acc += sol[j] * tr[(1 + j) * TR_N];
+                v[q] = acc; slot[q] = (e < n) ? i * 32 + kl : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (act[q]) dr[dst[q]] = base[q] + v[q];
+        __syncthreads();
+        for (int e = lane; e < TR_N * 32; e += 64) {
+            const int i = e >> 5, kl = e & 31, k = k0 + kl;
+            const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
+            const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
+            const int dst = off * KP + (kl < nk ? k : k0);
+            // starting value: -lam for the multiplier part of the first solve, the current direction when refining
+            const double cur = first ? it[dst] : dr[dst];
+            const double base = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
+            if (act) dr[dst] = base + stg[e];
+        }
+        __syncthreads();
     }
     if (lane == 0) {
         if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = sd.linvt ? 0.0 : -s.itg[G_LVT] + sd.sol[1]; }
@@ -2296,7 +2308,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
                         lg[n++] = sd.Wtf; lg[n++] = sd.gam; lg[n++] = delta_w;
                     }
 #endif
-                    combine_channels(s, sd, lane, pass == 0);
+                    combine_channels(s, sd, (double *)&w, lane, pass == 0);
                     PT_END(7)
                 }
             }
