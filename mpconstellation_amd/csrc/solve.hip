@@ -50,7 +50,7 @@ enum { F_G = 0, F_MINV = 49, F_KG = 98, F_BH = 119, F_QI = 140, F_PT = 149, FAC_
 // stage record; the 15 doubles after it are B_kn, unused), Bpm (B_kp of the record before) and D (Newton record)
 enum { F_A = 256, F_BPM = 320, F_D = 341, FLAT_N = 384 };
 // channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
-enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, CH_N = 104 };
+enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, RHS_N = 24, CH_N = 104 };
 // stored trajectory of one channel at one node
 enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
@@ -646,8 +646,8 @@ __device__ double scaled_error(const ResAcc &r, int K, int nT, int fixed_tf, dou
 }
 
 // ---- Newton blocks (stage-parallel) ------------------------------------------------------------
-// stg: LDS staging area of 32 * NB_N doubles (the recursion's scratch, idle during this phase).  A node's Newton record is
-// assembled there and the 32 records of a round go out as one contiguous, coalesced block: written straight from the node
+// stg: LDS staging area of 32 * (NB_N + RHS_N) doubles (the recursion's scratch, idle during this phase).  A node's Newton and
+// right-hand-side records are assembled there and the 32 records of a round go out as contiguous, coalesced blocks: written straight from the node
 // lanes they were 8-byte stores scattered over 32 cache lines per instruction (measured: the 40 stores per node that the
 // compact Hessian form removed were 6 % of the launch at S = 4096).
 __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *stg, double mu, double delta_w, int lane)
@@ -663,7 +663,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
         double *nb = stg + NODE_OF(lane) * NB_N;
-        gf64 *rhs = s.ch + (size_t)k * CH_N + C_RHS;
+        double *rhs = stg + 32 * NB_N + NODE_OF(lane) * RHS_N;
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
         // ---- chunk 0: objective, thrust ball, radius balls ----
         // (chunk 0 is computed by both halves and stored by half 0)
@@ -860,6 +860,10 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
           const int ne = ((K - k0 < 32) ? K - k0 : 32) * NB_N;
           gf64 *dst = s.nb + (size_t)k0 * NB_N;
           for (int e = lane; e < ne; e += 64) dst[e] = stg[e];
+          // ... and the right-hand-side records (24 contiguous doubles inside each node's channel record)
+          const int nr = ((K - k0 < 32) ? K - k0 : 32) * RHS_N;
+          gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
+          for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[32 * NB_N + e]; }
       }
       __syncthreads();
     }
@@ -944,9 +948,10 @@ struct Scratch {   // LDS working set of the recursion (and, between recursions,
     double Quy[21];
     double Quu[9];
     double zero;                   // constant 0 (addend of the tasks that have none)
+    double stage_pad[32 * (NB_N + RHS_N) - 1129 > 0 ? 32 * (NB_N + RHS_N) - 1129 : 1];   // newton_blocks stages 32 Newton + 32 rhs records here
 };
 
-static_assert(sizeof(Scratch) >= 32 * NB_N * sizeof(double), "newton_blocks stages 32 Newton records in the recursion's scratch");
+static_assert(sizeof(Scratch) >= 32 * (NB_N + RHS_N) * sizeof(double), "newton_blocks stages 32 Newton and right-hand-side records in the recursion's scratch");
 
 template <int N>
 __device__ __forceinline__ double dotN(const double *a, int sa, const double *b, int sb)
