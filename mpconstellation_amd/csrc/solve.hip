@@ -2168,10 +2168,23 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         }
         return;
     }
-    // field-major copy of the stage records for the node-parallel phases (read every iteration, written once)
-    for (int k = 0; k < K - 1; ++k) {
-        cgf64 *rec = s.A(k);
-        for (int e = lane; e < MPCX_STAGE_DOUBLES; e += 64) s.stT[e * KP + k] = rec[e];
+    // field-major copy of the stage records for the node-parallel phases (read every iteration, written once): 16 records
+    // at a time through LDS -- read as one contiguous block, written field by field with 16 consecutive nodes in
+    // consecutive lanes (straight from the record order it was an 8-byte store per cache line)
+    {
+        double *stg = (double *)&w;
+        static_assert(sizeof(Scratch) >= 16 * MPCX_STAGE_DOUBLES * sizeof(double), "stage transposition buffer");
+        for (int k0 = 0; k0 < K - 1; k0 += 16) {
+            const int nk = (K - 1 - k0 < 16) ? K - 1 - k0 : 16;
+            cgf64 *rec = s.A(k0);
+            for (int e = lane; e < nk * MPCX_STAGE_DOUBLES; e += 64) stg[e] = rec[e];
+            __syncthreads();
+            for (int e = lane; e < 16 * MPCX_STAGE_DOUBLES; e += 64) {
+                const int f = e >> 4, kl = e & 15;
+                if (kl < nk) s.stT[f * KP + k0 + kl] = stg[kl * MPCX_STAGE_DOUBLES + f];
+            }
+            __syncthreads();
+        }
     }
     for (int k = lane; k < K; k += 64) {
         double x[7], u[3];
