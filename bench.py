@@ -51,7 +51,7 @@ class Runner:
     so the solver's longest-first launch order (sorted by the PREVIOUS solve's iteration counts) is the imperfect
     predictor it is in use, not the exact one identical inputs would make it."""
 
-    def __init__(self, workload, rank, world, local_rank):
+    def __init__(self, workload, rank, world, local_rank, n_variants=N_VARIANTS):
         import torch
         from mpconstellation_amd import _ffi
         from mpconstellation_amd.constellation import constellation_states, normalize_batch, tangential_thrust
@@ -71,7 +71,7 @@ class Runner:
         t64 = dict(dtype=torch.float64, device=dev)
         T = lambda a: torch.tensor(a, **t64)
         self.variants = []
-        for mag in REF_THRUST[:N_VARIANTS]:
+        for mag in REF_THRUST[:n_variants]:
             xbar, st, _ = propagate_batch(y0, tfbar, consts, (_ffi.CTRL_TANGENTIAL, np.array([mag]), 0, None), K, device=local_rank)
             assert (st == 0).all()
             ubar = np.ascontiguousarray(tangential_thrust(xbar, mag))
@@ -205,6 +205,49 @@ def host_pointer_rate(h, S, local_rank, reps=3):
                     "(mpcx_host_alloc); `pageable`: ordinary numpy arrays, staged through the context's pinned pool"}
 
 
+def also_workload(name, steps, warmup, local_rank, note, with_host=False):
+    """one more BASELINE config measured in the same run under the driver's clock (its own Runner, steps, warmup)"""
+    import torch
+    S, K, n_scp = WORKLOADS[name]
+    r = Runner(name, 0, 1, local_rank)
+    e, sm = measure(r, steps, warmup, 1)
+    st, it, kk = r.solver_stats()
+    out = {"value": S * steps / e, "unit": "satellite-MPC-steps/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": e / steps * 1e3, "roofline": roofline(name, S, K, sm, it),
+           "solver": {"converged": int(((st == 0) | (st == 7)).sum()), "of": S, "ipm_iterations_mean": float(it.mean()),
+                      "ipm_iterations_max": int(it.max()), "kkt_max": float(kk.max())}, "note": note}
+    if n_scp > 1:
+        out["scp_iterations_per_s"] = out["value"] * n_scp
+    if with_host:
+        out["host_pointer_entry"] = host_pointer_rate(r.host, S, local_rank)
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+def closed_loop(S, local_rank, segments=2):
+    """The metric's "MPC steps/sec (whole constellation)" for the loop the hot path sits in: ConstellationMPC.run_segments
+    in the reference's test_mpc configuration (test_simulator.py:79-98: base_res 30, tf_horizon 2, two segments, r_des 1.5,
+    truth model with drag + J2 at base_res 100).  One constellation-MPC-step = controller.update() for every satellite
+    (reference rollout + 2 SCP iterations with re-rollout, control.py:170-235) + the truth propagation of the segment
+    (simulator.py:58-65), host Python included, numpy arrays in and out."""
+    from mpconstellation_amd import Satellite, ConstellationMPC
+    from mpconstellation_amd.constellation import constellation_states
+    st = constellation_states(S)
+    make = lambda: [Satellite(s[:3].copy(), s[3:6].copy(), float(s[6])) for s in st]
+    ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank).run_segments(tf=2, num_segments=1)   # warm-up: workspaces, staging pools
+    mpc = ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank)
+    t0 = time.perf_counter()
+    mpc.run_segments(tf=2, num_segments=segments)
+    dt = time.perf_counter() - t0
+    ok = int(np.isin(mpc.last_status, (0, 7)).sum())
+    t = mpc.timing
+    return {"value": S * segments / dt, "unit": "satellite-MPC-steps/s (1 step = OptimalController.update + segment flight)",
+            "satellites": S, "segments": segments, "s_per_segment": dt / segments, "scp_iterations_per_s": 2 * S * segments / dt,
+            "converged_last_segment": ok, "of": int(mpc.last_status.size),
+            "split_s": {k: round(v, 4) for k, v in t.items()}, "host_python_s": round(dt - sum(t.values()), 4)}
+
+
 def spawn_ranks(args):
     """--gpus N without an outer launcher: start the N ranks as child processes (this parent never touches a GPU) and
     pass their output and exit code through."""
@@ -277,6 +320,9 @@ def main():
         dev_res = (run.d_X.cpu().numpy(), run.d_U.cpu().numpy(), run.d_tfo.cpu().numpy(), status) if n_scp == 1 else None
         if world == 1 and not args.no_also:
             out["host_pointer_entry"] = host_pointer_rate(h, S if n_scp == 1 else S / n_scp, local_rank)
+            # SURVEY 8(d)'s metric with H2D of the inputs and D2H of the results inside the timed region, ordinary numpy
+            # arrays in and out (what the drop-in Optimizer passes): beside `value`, never instead of it
+            out["value_pcie"] = out["host_pointer_entry"]["pageable"]["value"]
             # the default launch order is longest-first by the previous solve's iteration counts (consecutive steps pose
             # similar problems: the Runner cycles through reference-thrust variants); the plain index order beside it
             run.opts.flags = 1; run.solve_events = []
@@ -287,17 +333,15 @@ def main():
         if world == 1 and not args.no_also and workload == DEFAULT_SINGLE:
             del run
             torch.cuda.empty_cache()
-            r2 = Runner("S64_K30", 0, 1, local_rank)
-            e2, s2 = measure(r2, args.steps, args.warmup, 1)
-            st2, it2, k2 = r2.solver_stats()
-            out["also"] = {"S64_K30": {"value": 64 * args.steps / e2, "unit": "satellite-MPC-steps/s", "steps": args.steps,
-                                       "warmup": args.warmup, "ms_per_step": e2 / args.steps * 1e3,
-                                       "roofline": roofline("S64_K30", 64, 30, s2, it2),
-                                       "solver": {"converged": int(((st2 == 0) | (st2 == 7)).sum()), "of": 64,
-                                                  "ipm_iterations_mean": float(it2.mean()), "ipm_iterations_max": int(it2.max()),
-                                                  "kkt_max": float(k2.max())},
-                                       "host_pointer_entry": host_pointer_rate(r2.host, 64, local_rank),
-                                       "note": "BASELINE configs[1] (64 satellites: 64 of the chip's 1024 SIMDs busy), same run"}}
+            out["also"] = {
+                "S64_K30": also_workload("S64_K30", args.steps, args.warmup, local_rank,
+                                         "BASELINE configs[1] (64 satellites: 64 of the chip's 1024 SIMDs busy), same run", with_host=True),
+                "S4096_K100_scp2": also_workload("S4096_K100_scp2", 3, 1, local_rank,
+                                                 "BASELINE configs[3]: K = 100, 2 SCP iterations with device re-rollout per step, same run"),
+                "S8192_K30": also_workload("S8192_K30", 5, 1, local_rank,
+                                           "one GPU's share of BASELINE configs[4] (65 536 satellites over 8 GPUs), same run"),
+            }
+            out["closed_loop"] = {f"S{n}": closed_loop(n, local_rank) for n in (64, 4096)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)
             if err: out["trajectory_error_vs_cpu_oracle"] = err

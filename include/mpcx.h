@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 200
+#define MPCX_VERSION 300
 
 /* return codes */
 #define MPCX_OK 0
@@ -165,6 +165,35 @@ int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *stage, const
                          const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
                          double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
                          void *workspace, void *stream);
+
+/* Per-satellite regularisation record of the LAST solve (or fused step) on this context, out [S][2] int32: the number of
+ * interior-point iterations whose Newton system needed a Hessian regularisation delta_w > 0 (ipopt's inertia correction:
+ * its iteration log prints the same quantity, lg(rg), which optimizer.py:603 shows with tee=verbose), and the index of the
+ * first such iteration (-1: none).  S must be that solve's batch size.  The _dev variant copies on `stream` (the stream of
+ * the solve) into device memory; the host variant returns when `out` is filled. */
+int mpcx_solve_regularised(mpcx_ctx *ctx, int S, int32_t *out);
+int mpcx_solve_regularised_dev(mpcx_ctx *ctx, int S, int32_t *out, void *stream);
+
+/*
+ * Replaces Optimizer.get_constraint_terms (optimizer.py:80-170) as the solver consumes it: what the device builds for
+ * every satellite before its first iteration, returned instead of used.  Terminal inequality rows a_j . x_K <= b_j,
+ *   aT [S][8][7], bT [S][8]:  0: -r_hat.r_K <= -(r_des - eps_r)          (optimizer.py:398-402)
+ *                             1, 2: +-(Vr linearised) <= eps_vr           (:406-416, 432-433)
+ *                             3, 4: +-(Vn linearised) <= eps_vn           (:436-446, 466-467; Dv_h_hat in its precedence form :122)
+ *                             5: -m_K <= -min_mass                        (:351-352, 363)
+ *                             6, 7: +-(Vt - Vc linearised) <= eps_vt      (:471-489; zero rows without MPCX_SOLVE_LINEAR_VT)
+ * every b relaxed by 1e-8 max(1, |b|) (ipopt's bound_relax_factor), and
+ *   scalars [S][MPCX_NTERM_SCALARS]: relaxed u_max^2 (:379-381), r_max^2 (:393-395), -r_min (:384-391), (r_des+eps_r)^2
+ *   (:403), the tf range 0 / tf_max (:588), vt_des = sqrt(mu / r_des) (:492-517), and the structural violation (> 0: the
+ *   constraint set is empty, MPCX_ST_INFEASIBLE).
+ * xbar [S][7][K], consts [S][MPCX_NCONST], r_des [S].
+ */
+#define MPCX_NTERM_SCALARS 8
+int mpcx_constraint_terms(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *consts,
+                          const double *r_des, const mpcx_solve_opts *opts, double *aT, double *bT, double *scalars);
+int mpcx_constraint_terms_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *consts,
+                              const double *r_des, const mpcx_solve_opts *opts, double *aT, double *bT,
+                              double *scalars, void *stream);
 
 /*
  * One satellite-MPC-step = Optimizer.solve_OPT as the reference runs it (optimizer.py:243-251 calls

@@ -19,6 +19,7 @@ FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS = 1, 2, 4
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
 NCONST = 8
 STAGE_DOUBLES = 105
+NTERM_SCALARS = 8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -64,6 +65,10 @@ _SIGS = {
     "mpcx_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mpcx_mpc_step_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mpcx_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int] + [_dp] * 10 + [_po, _dp, _dp, _dp, _dp, _ip, _ip, _dp]),
+    "mpcx_solve_regularised": (C.c_int, [_vp, C.c_int, _ip]),
+    "mpcx_solve_regularised_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mpcx_constraint_terms": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _po, _dp, _dp, _dp]),
+    "mpcx_constraint_terms_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _po, _vp, _vp, _vp, _vp]),
     "mpcx_solve_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 6 + [_po] + [_vp] * 7 + [_vp, _vp]),
     "mpcx_mpc_step_batch": (C.c_int, [_vp, C.c_int, C.c_int] + [_dp] * 5 + [C.c_int, C.c_double, _po, _dp, _dp, _dp, _dp,
                                                                          _ip, _ip, _dp]),

@@ -12,6 +12,7 @@ length of the thrust table played back during the segment; satellites are groupe
 one batch, so each satellite gets exactly the result of the single-satellite path (tests/test_mpc_loop_gpu.py)."""
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -75,9 +76,11 @@ def _rollouts(jobs, device):
 
 class ConstellationMPC:
     def __init__(self, sats, base_res=100, tf_horizon=1, tf_interval=1, r_des=1.5, scp_iterations=2, sim_base_res=100,
-                 include_drag=True, include_J2=True, device=0, strict=False):
+                 include_drag=True, include_J2=True, device=0, strict=False, scales=None, verbose=False):
         self.sats = list(sats)
-        self.scales = [SatelliteScale(sat=s) for s in self.sats]
+        # every satellite in its own "designer units" (so that each sees MU = 4 pi^2) unless the caller brings the scales
+        self.scales = list(scales) if scales is not None else [SatelliteScale(sat=s) for s in self.sats]
+        self.verbose = verbose                # control.py:208-209's prints, per satellite
         self.consts = np.stack([sc.get_normalized_constants().as_vector() for sc in self.scales])
         self.base_res, self.sim_base_res = base_res, sim_base_res
         self.horizon, self.interval = tf_horizon, tf_interval
@@ -88,7 +91,15 @@ class ConstellationMPC:
         self.strict = strict                  # raise instead of warning when a solve does not converge (control.py mirror)
         self.sim_data, self.sim_time = {}, {}
         self.last_status = None
-        self.plan_u, self.plan_tf, self.plan_x = None, None, None
+        self.plan_u, self.plan_tf, self.plan_x, self.plan_nu = None, None, None, None
+        # wall-clock seconds spent inside the batched device calls (host staging included), accumulated over the updates
+        self.timing = {"rollouts": 0.0, "discretize_solve": 0.0, "truth_propagation": 0.0}
+
+    def _timed(self, key, fn, *a, **kw):
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        self.timing[key] += time.perf_counter() - t0
+        return out
 
     def _y0(self):
         return np.stack([sc.normalize_state(s.get_state_vector()) for sc, s in zip(self.scales, self.sats)])
@@ -98,39 +109,43 @@ class ConstellationMPC:
         S = len(self.sats)
         y0 = self._y0()
         K = int(self.base_res * self.horizon)
-        x, st, _ = propagate_batch(y0, self.horizon, self.consts, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K,
-                                   False, False, 0.001, self.device)
+        x, st, _ = self._timed("rollouts", propagate_batch, y0, self.horizon, self.consts,
+                               (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, False, False, 0.001, self.device)
         self._check(st)
         u_bar = tangential_thrust(x, 0.5)                                  # extract_uk of the tangential controller
         tf_u = np.full(S, float(self.horizon))
         groups = {K: np.arange(S)}
         xs = {K: x}; us = {K: u_bar}
         self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
-        plan_u = [None] * S; plan_x = [None] * S
+        plan_u = [None] * S; plan_x = [None] * S; plan_nu = [None] * S
         opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": self.horizon}     # control.py:192-197
         for it in range(self.scp_iterations):
             nxt_groups, nxt_x, nxt_u = {}, {}, {}
             keys = list(groups)
             jobs = [(xs[Kg], us[Kg], tf_u[groups[Kg]], self.consts[groups[Kg]], self.r_des[groups[Kg]]) for Kg in keys]
             if S <= 256:      # small groups: the solves are latency bound and overlap (measured: -12 % at 64 satellites)
-                solved = _concurrently(mpc_step_batch, jobs, self.device, options=opts)
+                solved = self._timed("discretize_solve", _concurrently, mpc_step_batch, jobs, self.device, options=opts)
             else:             # large ones fill the device on their own; separate contexts would only regrow workspaces
-                solved = [mpc_step_batch(*job, options=opts, device=self.device) for job in jobs]
+                solved = self._timed("discretize_solve", lambda: [mpc_step_batch(*job, options=opts, device=self.device) for job in jobs])
             for Kg, res in zip(keys, solved):
                 idx = groups[Kg]
                 self.last_status[it, idx] = res.status
                 _check_solver_status(res.status, self.strict)
                 tf_u[idx] = res.tf
                 for j, s in enumerate(idx):
-                    plan_u[s] = res.U[j]; plan_x[s] = res.X[j]
+                    plan_u[s] = res.U[j]; plan_x[s] = res.X[j]; plan_nu[s] = res.NU[j]
+                    if self.verbose:
+                        print(f"tf for optimizer: {res.tf[j]}")
+                        print(f"Total virtual control effort: {np.abs(res.NU[j]).sum()}")
                 if it == self.scp_iterations - 1:
                     continue          # (the reference re-rolls once more, control.py:227, and drops the result)
                 # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
                 Kn = (self.base_res * res.tf).astype(int)
                 kns = np.unique(Kn)
                 sels = [np.nonzero(Kn == kn)[0] for kn in kns]
-                outs = _rollouts([(y0[idx[sel]], tf_u[idx[sel]], self.consts[idx[sel]], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0),
-                                   int(kn), False, False, 0.001) for kn, sel in zip(kns, sels)], self.device)
+                outs = self._timed("rollouts", _rollouts,
+                                   [(y0[idx[sel]], tf_u[idx[sel]], self.consts[idx[sel]], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0),
+                                     int(kn), False, False, 0.001) for kn, sel in zip(kns, sels)], self.device)
                 for kn, sel, (xr, st, _) in zip(kns, sels, outs):
                     gi = idx[sel]
                     self._check(st)
@@ -141,7 +156,7 @@ class ConstellationMPC:
                     else:
                         nxt_groups[int(kn)] = gi; nxt_x[int(kn)] = xr; nxt_u[int(kn)] = ur
             groups, xs, us = nxt_groups, nxt_x, nxt_u
-        self.plan_u, self.plan_x, self.plan_tf = plan_u, plan_x, tf_u.copy()
+        self.plan_u, self.plan_x, self.plan_nu, self.plan_tf = plan_u, plan_x, plan_nu, tf_u.copy()
         if self.horizon - self.interval > 0.1:                               # control.py:234-235
             self.horizon -= self.interval
 
@@ -156,9 +171,10 @@ class ConstellationMPC:
         kus = np.unique(Ku)
         gis = [np.nonzero(Ku == ku)[0] for ku in kus]
         # SequenceController(tf_u, tf_sim = interval): end_tau = tf_u / interval
-        outs = _rollouts([(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, np.stack([self.plan_u[s] for s in gi]), int(ku),
-                                                         self.plan_tf[gi] / self.interval), n_eval, self.include_drag, self.include_J2,
-                           0.001) for ku, gi in zip(kus, gis)], self.device)
+        outs = self._timed("truth_propagation", _rollouts,
+                           [(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, np.stack([self.plan_u[s] for s in gi]), int(ku),
+                                                           self.plan_tf[gi] / self.interval), n_eval, self.include_drag, self.include_J2,
+                             0.001) for ku, gi in zip(kus, gis)], self.device)
         for gi, (yy, st, _) in zip(gis, outs):
             self._check(st)
             y[gi] = yy

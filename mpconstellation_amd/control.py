@@ -106,11 +106,14 @@ class SequenceController(Controller):
 
 
 class OptimalController(Controller):
-    """MPC / SCP controller (reference control.py:145-246): reference rollout -> SCPn x (discretize + solve
-    + nonlinear re-rollout) with the discretize+solve step on the device."""
+    """MPC / SCP controller (reference control.py:145-246) for `sats[0]` (:162).  Its plan is the one-satellite case of
+    ConstellationMPC.update -- reference rollout, then SCPn x (extract u_bar, discretize + solve on the device, nonlinear
+    re-rollout under the optimised sequence), horizon shrink -- and this class keeps the reference's attributes on top of
+    it: horizon, interval, base_res, r_des, SCPn_iterations (read before every update, as the reference reads them),
+    opt_trajectory, sequence_controller."""
 
     def __init__(self, sats=[], objective=None, base_res=100, tf_horizon=1, tf_interval=1, plot_inter=True,
-                 opt_verbose=True, r_des=1.5, strict=False):
+                 opt_verbose=True, r_des=1.5, strict=False, device=0):
         super().__init__(sats)
         from .satellite_scale import SatelliteScale
         self.u = np.zeros((3, 1))
@@ -128,45 +131,23 @@ class OptimalController(Controller):
         # the acceptable level always warns (RuntimeWarning, whatever opt_verbose says) and, with strict=True, raises
         # instead of flying an unconverged plan.
         self.strict = strict
+        self.device = device
 
     def update(self):
-        from . import simulator
-        from .linearize_discretize import Discretizer
-        from .optimizer import Optimizer
-        const = self.scale.get_normalized_constants()
-        c = ConstantTangentialThrustController([self.sat], 0.5)       # control.py:178-180
-        x, t = self.run_nonlinear(c, self.horizon)
-        tf_u = self.horizon
-        self.last_status = []
-        for i in range(self.SCPn_iterations):
-            K = x.shape[1]
-            d = Discretizer(const, use_scipy_ZOH=False, include_drag=False, include_J2=False)
-            u_bar = Discretizer.extract_uk(x, t, c)
-            nu_bar = np.zeros((7, K))
-            f = simulator.Simulator.satellite_dynamics
-            opt_options = {'r_des': self.r_des, 'eps_r': 0.000001, 'eps_vr': 0.0000000000000001, 'eps_vt': 0.01,
-                           'tf_max': self.horizon}                    # control.py:192-197
-            opt = Optimizer([x], [u_bar], [nu_bar], tf_u, d, f, self.scale, verbose=self.opt_verbose)
-            opt.solve_OPT(input_options=opt_options)
-            self.last_status.append(int(opt.status[0]))
-            _check_solver_status(opt.status, self.strict)
-            tf_u = opt.get_solved_tf(0)
-            u_opt = opt.get_solved_u(0)
-            nu_opt = opt.get_solved_nu(0)
-            if self.opt_verbose:
-                print(f"tf for optimizer: {tf_u}")
-                print(f"Total virtual control effort: {np.abs(nu_opt).sum()}")
-            self.opt_trajectory = opt.get_solved_trajectory(0)
-            self.sequence_controller = SequenceController(u=u_opt, tf_u=tf_u, tf_sim=self.interval)
-            c = SequenceController(u=u_opt, tf_u=tf_u, tf_sim=tf_u)
-            x, t = self.run_nonlinear(c=c, tf=tf_u)
-        if self.horizon - self.interval > 0.1:                        # control.py:234-235
-            self.horizon -= self.interval
+        from .constellation_mpc import ConstellationMPC
+        mpc = ConstellationMPC([self.sat], base_res=self.base_res, tf_horizon=self.horizon, tf_interval=self.interval,
+                               r_des=self.r_des, scp_iterations=self.SCPn_iterations, device=self.device, strict=self.strict,
+                               scales=[self.scale], verbose=self.opt_verbose)
+        mpc.update()
+        self.last_status = [int(c) for c in mpc.last_status[:, 0]]
+        self.opt_trajectory = mpc.plan_x[0]
+        self.sequence_controller = SequenceController(u=mpc.plan_u[0], tf_u=float(mpc.plan_tf[0]), tf_sim=self.interval)
+        self.horizon = mpc.horizon                                   # control.py:234-235
 
     def run_nonlinear(self, c, tf):
         from . import simulator
         s = simulator.Simulator(sats=[self.sat], controller=c, scale=self.scale, base_res=self.base_res,
-                                include_drag=False, include_J2=False)
+                                include_drag=False, include_J2=False, device=self.device)
         s.run(tf=tf)
         return s.sim_data[self.sat.id], s.sim_time[self.sat.id]
 

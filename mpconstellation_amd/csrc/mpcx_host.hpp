@@ -56,6 +56,9 @@ struct mpcx_ctx {
     // longest first; valid only for a following solve of the same batch size
     int32_t *prev_iters, *order;
     int order_S, order_valid, order_cap;
+    // regularisation counts of the last solve ([S][2] int32, include/mpcx.h: mpcx_solve_regularised)
+    int32_t *nreg;
+    int nreg_cap, nreg_S;
     StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
 };
 
@@ -89,7 +92,12 @@ inline void *ctx_workspace(mpcx_ctx *ctx, size_t bytes)
 // Bump allocator over the two pools for the duration of one host-pointer call.
 class DeviceArena {
   public:
-    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0) { pool_reset(c->pool_dev); pool_reset(c->pool_host); }
+    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0), dirty_(false) { pool_reset(c->pool_dev); pool_reset(c->pool_host); }
+    // A call that returns early (an error after its first transfer was queued) leaves copies from / to the staging pools in
+    // flight; the next call resets the pools and would overwrite them.  The stream is drained before that can happen.
+    ~DeviceArena() { if (dirty_) (void)hipStreamSynchronize(ctx_->stream); }
+    DeviceArena(const DeviceArena &) = delete;
+    DeviceArena &operator=(const DeviceArena &) = delete;
     template <typename T> T *alloc(size_t n)
     {
         if (code_) return nullptr;
@@ -109,6 +117,7 @@ class DeviceArena {
     {
         T *d = alloc<T>(n);
         if (!d) return nullptr;
+        dirty_ = true;
         if (is_pinned(h)) {
             hipError_t e = hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
             if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
@@ -124,6 +133,7 @@ class DeviceArena {
     template <typename T> void download(T *h, const T *d, size_t n)
     {
         if (code_ || !h) return;
+        dirty_ = true;
         if (is_pinned(h)) {
             hipError_t e = hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
             if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
@@ -141,6 +151,7 @@ class DeviceArena {
         if (code_) return code_;
         hipError_t e = hipStreamSynchronize(ctx_->stream);
         if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+        dirty_ = false;
         for (const auto &o : out_) memcpy(o.dst, o.src, o.bytes);
         return MPCX_OK;
     }
@@ -151,5 +162,6 @@ class DeviceArena {
     struct Out { void *dst; const void *src; size_t bytes; };
     mpcx_ctx *ctx_;
     int code_;
+    bool dirty_;              // transfers queued and not yet waited for
     std::vector<Out> out_;
 };

@@ -72,6 +72,7 @@ struct SolveArgs {
     double *X, *U, *NU, *tf_out, *kkt;
     int32_t *status, *iters;
     const int32_t *order;     // workgroup b solves satellite order[b]; nullptr = index order
+    int32_t *nreg;            // [S][2]: iterations whose direction needed delta_w > 0, and the first of them (-1: none)
     double *ws;
     size_t ws_stride;
 };
@@ -296,7 +297,7 @@ __device__ double structural_violation(const double *x0, int K, const SatData &s
     double v = r2 - sd.b_rmax;
     if (K >= 3) v = fmax(v, -sqrt(r2) - sd.b_rmin);
     v = fmax(v, -sd.bT[0] - sqrt(fmin(sd.b_rmax, sd.b_rfmax)));
-    if (K >= 4) v = fmax(v, -sd.b_rmin - sqrt(sd.b_rmax));
+    if (K >= 3) v = fmax(v, -sd.b_rmin - sqrt(sd.b_rmax));      // node 1 is an inner node already at K = 3
     v = fmax(v, fmax(-(sd.bT[1] + sd.bT[2]), -(sd.bT[3] + sd.bT[4])));
     if (sd.nT == 8) v = fmax(v, -(sd.bT[6] + sd.bT[7]));
     if (!sd.fixed_tf) v = fmax(v, -(sd.b_tf[0] + sd.b_tf[1]));
@@ -2077,6 +2078,8 @@ __global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t
         int acc = 0;
         for (int key = 255; key >= 0; --key) { base[key] = acc; acc += hist[key]; }
     }
+    // identity first: every slot holds a valid satellite whatever the scatter below leaves unwritten
+    for (int i = tid; i < S; i += 1024) order[i] = i;
     __syncthreads();
     // (prev_iters is written by the previous solve on the SAME stream, include/mpcx.h; the clamp keeps a scatter past
     // the table impossible even if a caller breaks that rule and the two passes see different counts)
@@ -2114,7 +2117,10 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     __shared__ Scratch w;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.S) return;
-    const int sat = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    // (an entry outside [0, S) can only come from a caller that broke the same-stream rule of include/mpcx.h: never an
+    //  out-of-bounds satellite)
+    int sat = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)sat >= (unsigned)a.S) sat = (int)blockIdx.x;
     const int K = a.K;
     Sat s;
     s.K = K;
@@ -2165,6 +2171,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         if (lane == 0) {
             if (!sd.fixed_tf) a.tf_out[sat] = sd.tfbar; else a.tf_out[sat] = 0.0;      // (fixed tf: the slot returns g_s)
             a.status[sat] = MPCX_ST_INFEASIBLE; a.iters[sat] = 0; a.kkt[sat] = sd.infeas;
+            if (a.nreg) { a.nreg[2 * sat] = 0; a.nreg[2 * sat + 1] = -1; }
         }
         return;
     }
@@ -2225,7 +2232,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
 
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
     const int nzc = n_ineq(K, sd.nT, sd.fixed_tf);
-    int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0;
+    int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0, n_reg = 0, first_reg = -1;
     // second safeguard of the adaptive barrier rule (the first is the kMuErr bound below): after kFbN consecutive accepted
     // steps shorter than kFbAlpha -- the iterate is jammed against its bounds -- mu is lifted to kFbBoost * mean(s z) and
     // follows ipopt's monotone Fiacco-McCormick rule from then on.  kFbN = 8: benchmark problems at K = 100 take up to seven
@@ -2343,7 +2350,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             else if (delta_w == 0.0) delta_w = (dw_last == 0.0) ? kDwFirst : fmax(kDwMin, dw_last / 3.0);
             else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
         }
-        if (have_dir && delta_w > 0.0) dw_last = delta_w;
+        if (have_dir && delta_w > 0.0) { dw_last = delta_w; if (n_reg++ == 0) first_reg = iter; }
         if (!have_dir) {
 #ifdef MPCX_ITER_LOG
             if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = -1.0; lg[3] = delta_w; lg[4] = (double)fail_mask; }
@@ -2408,6 +2415,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         a.status[sat] = status;
         a.iters[sat] = it_count;
         a.kkt[sat] = E0;
+        if (a.nreg) { a.nreg[2 * sat] = n_reg; a.nreg[2 * sat + 1] = first_reg; }
 #ifdef MPCX_PHASE_TIMING
         // diagnostic build only: cycle sums per phase into the NU block of this satellite (never shipped)
         double *dbg = a.NU + (size_t)sat * 7 * K;
@@ -2430,6 +2438,84 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
     d.n_refine = o->n_refine; d.linvt = (o->flags & MPCX_SOLVE_LINEAR_VT) ? 1 : 0;
     d.fixed_tf = (o->flags & MPCX_SOLVE_FIXED_TF) ? 1 : 0; d.pad = 0;
     return d;
+}
+
+
+namespace mpcx {
+// Diagnostic export of what solve_kernel builds before its first iteration: the terminal inequality rows a_j . x_K <= b_j
+// (build_terminal: Optimizer.get_constraint_terms, optimizer.py:80-170, as consumed by the rules :398-403, 406-446,
+// 471-489, 351-352) and the relaxed scalar bounds.  Same device function, same lane, same LDS struct as in the solve.
+__global__ __launch_bounds__(64) void constraint_terms_kernel(int S, int K, const double *xbar, const double *consts, const double *r_des,
+                                                              SolveOpts o, double *aT, double *bT, double *scal)
+{
+    __shared__ SatData sd;
+    const int sat = blockIdx.x, lane = threadIdx.x;
+    if (sat >= S) return;
+    if (lane == 0) {
+        double xK[7], x0[3];
+        for (int i = 0; i < 7; ++i) xK[i] = xbar[(size_t)sat * 7 * K + (size_t)i * K + K - 1];
+        for (int i = 0; i < 3; ++i) x0[i] = xbar[(size_t)sat * 7 * K + (size_t)i * K];
+        build_terminal(xK, consts[(size_t)sat * MPCX_NCONST + MPCX_C_MU], r_des[sat], o, sd);
+        sd.infeas = structural_violation(x0, K, sd);
+    }
+    __syncthreads();
+    if (lane < 56) aT[(size_t)sat * 56 + lane] = sd.aT[lane / 7][lane % 7];
+    if (lane < 8) bT[(size_t)sat * 8 + lane] = sd.bT[lane];
+    if (lane == 0) {
+        double *q = scal + (size_t)sat * MPCX_NTERM_SCALARS;
+        q[0] = sd.b_u; q[1] = sd.b_rmax; q[2] = sd.b_rmin; q[3] = sd.b_rfmax; q[4] = sd.b_tf[0]; q[5] = sd.b_tf[1];
+        q[6] = sd.vt_des; q[7] = sd.infeas;
+    }
+}
+}  // namespace mpcx
+
+extern "C" int mpcx_constraint_terms_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *consts,
+                                         const double *r_des, const mpcx_solve_opts *opts, double *aT, double *bT,
+                                         double *scalars, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 2 || !opts || !xbar || !consts || !r_des || !aT || !bT || !scalars)
+        return ctx_fail(ctx, MPCX_E_BADARG, "constraint_terms: need S>=1, K>=2, options and all arrays");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(mpcx::constraint_terms_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, S, K, xbar, consts, r_des,
+                       to_dev_opts(opts), aT, bT, scalars);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_constraint_terms(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *consts,
+                                     const double *r_des, const mpcx_solve_opts *opts, double *aT, double *bT, double *scalars)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 2 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "constraint_terms: need S>=1, K>=2 and options");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceArena ar(ctx);
+    double *dx = ar.upload(xbar, (size_t)S * 7 * K), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    double *da = ar.alloc<double>((size_t)S * 56), *db = ar.alloc<double>((size_t)S * 8), *ds = ar.alloc<double>((size_t)S * MPCX_NTERM_SCALARS);
+    if (ar.failed()) return ar.code();
+    int rc = mpcx_constraint_terms_dev(ctx, S, K, dx, dc, drd, opts, da, db, ds, ctx->stream);
+    if (rc) return rc;
+    ar.download(aT, da, (size_t)S * 56); ar.download(bT, db, (size_t)S * 8); ar.download(scalars, ds, (size_t)S * MPCX_NTERM_SCALARS);
+    return ar.finish();
+}
+
+extern "C" int mpcx_solve_regularised_dev(mpcx_ctx *ctx, int S, int32_t *out, void *stream)
+{
+    if (!ctx || !out) return MPCX_E_BADARG;
+    if (S < 1 || S != ctx->nreg_S || !ctx->nreg) return ctx_fail(ctx, MPCX_E_BADARG, "solve_regularised: S must be the batch size of the last solve on this context");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    MPCX_HIP(ctx, hipMemcpyAsync(out, ctx->nreg, (size_t)S * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_solve_regularised(mpcx_ctx *ctx, int S, int32_t *out)
+{
+    if (!ctx || !out) return MPCX_E_BADARG;
+    if (S < 1 || S != ctx->nreg_S || !ctx->nreg) return ctx_fail(ctx, MPCX_E_BADARG, "solve_regularised: S must be the batch size of the last solve on this context");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    // (the host-pointer solves ran on the context's stream and have completed; a _dev solve is ordered by its stream)
+    MPCX_HIP(ctx, hipMemcpy(out, ctx->nreg, (size_t)S * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MPCX_OK;
 }
 
 extern "C" void mpcx_default_solve_opts(mpcx_solve_opts *o)
@@ -2460,6 +2546,14 @@ extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *s
     a.o = to_dev_opts(opts);
     a.X = X; a.U = U; a.NU = NU; a.tf_out = tf_out; a.kkt = kkt; a.status = status; a.iters = iters;
     a.ws = (double *)workspace; a.ws_stride = ws_doubles(K);
+    // per-satellite regularisation counts of this solve (library-owned, grow-only; read back by mpcx_solve_regularised)
+    if (ctx->nreg_cap < S) {
+        if (ctx->nreg) (void)hipFree(ctx->nreg);
+        ctx->nreg = nullptr; ctx->nreg_cap = 0;
+        MPCX_HIP(ctx, hipMalloc((void **)&ctx->nreg, (size_t)S * 2 * sizeof(int32_t)));
+        ctx->nreg_cap = S;
+    }
+    a.nreg = ctx->nreg; ctx->nreg_S = S;
     // longest-first launch order from the previous solve's iteration counts (include/mpcx.h, MPCX_SOLVE_INDEX_ORDER)
     const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER);
     a.order = nullptr;

@@ -12,9 +12,36 @@ DEFAULT_OPTIONS = {'min_mass': 0.1, 'u_lim': [0, 5], 'r_lim': [0.99, 5], 'r_des'
 class SolveResult:
     """What the reference keeps in self.model (a pyomo object) reduced to what its callers read."""
 
-    def __init__(self, X, U, NU, tf, status, iters, kkt, g_tf=None):
+    def __init__(self, X, U, NU, tf, status, iters, kkt, g_tf=None, regularised=None):
         self.X, self.U, self.NU, self.tf, self.status, self.iters, self.kkt = X, U, NU, tf, status, iters, kkt
         self.g_tf = g_tf          # fixed-tf solves only: each satellite's term of the tf stationarity row (include/mpcx.h)
+        # regularised=True calls only: per satellite, the iterations that needed delta_w > 0 and the first of them (-1: none)
+        self.n_regularised = None if regularised is None else regularised[:, 0]
+        self.first_regularised = None if regularised is None else regularised[:, 1]
+
+
+def _regularised(lib, ctx, S):
+    """mpcx_solve_regularised of the solve that just returned on this context"""
+    out = np.zeros((S, 2), dtype=np.int32)
+    _ffi.check(lib.mpcx_solve_regularised(ctx, S, _ffi.iptr(out)), ctx, "mpcx_solve_regularised")
+    return out
+
+
+def constraint_terms_batch(xbar, consts, r_des, options=None, device=0, linear_vt=False):
+    """What the device builds from Optimizer.get_constraint_terms (optimizer.py:80-170) before its first iteration
+    (include/mpcx.h, mpcx_constraint_terms): aT (S,8,7), bT (S,8), scalars (S,8)."""
+    xbar = _ffi.as_f64(xbar)
+    S, _, K = xbar.shape
+    consts = _ffi.as_f64(consts)
+    r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
+    opts = _ffi.make_solve_opts(options, **_solver_flags({}, linear_vt))
+    aT = np.empty((S, 8, 7)); bT = np.empty((S, 8)); sc = np.empty((S, _ffi.NTERM_SCALARS))
+    lib = _ffi.load(); ctx = _ffi.context(device)
+    import ctypes as C
+    rc = lib.mpcx_constraint_terms(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(consts), _ffi.dptr(r_des), C.byref(opts),
+                                   _ffi.dptr(aT), _ffi.dptr(bT), _ffi.dptr(sc))
+    _ffi.check(rc, ctx, "mpcx_constraint_terms")
+    return aT, bT, sc
 
 
 def _solver_flags(solver, linear_vt, fixed_tf=None):
@@ -55,7 +82,7 @@ def _tf_io(S, fixed_tf):
 
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, **solver):
+                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
@@ -81,11 +108,13 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
                                  _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
                                  _ffi.iptr(iters), _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
-    return SolveResult(X, U, NU, tfo, status, iters, kkt) if held is None else SolveResult(X, U, NU, held, status, iters, kkt, tfo)
+    reg = _regularised(lib, ctx, S) if regularised else None
+    return SolveResult(X, U, NU, tfo, status, iters, kkt, regularised=reg) if held is None else \
+        SolveResult(X, U, NU, held, status, iters, kkt, tfo, reg)
 
 
 def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, fixed_tf=None,
-                **solver):
+                regularised=False, **solver):
     """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""
     solver = _solver_flags(solver, linear_vt, fixed_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
@@ -105,29 +134,50 @@ def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=Non
                               _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status), _ffi.iptr(iters),
                               _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_solve_batch")
-    return SolveResult(X, U, NU, tfo, status, iters, kkt) if held is None else SolveResult(X, U, NU, held, status, iters, kkt, tfo)
+    reg = _regularised(lib, ctx, S) if regularised else None
+    return SolveResult(X, U, NU, tfo, status, iters, kkt, regularised=reg) if held is None else \
+        SolveResult(X, U, NU, held, status, iters, kkt, tfo, reg)
 
 
-def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=2e-8):
+class SharedTfSearch(list):
+    """The (tf, G(tf)) evaluations of a shared-tf root search, with its outcome: `converged` False when no sign change
+    of G was found within the evaluation budget (the returned tf is then the last point tried, not a root), `message`
+    says why."""
+    converged = True
+    message = "root found"
+
+
+def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=2e-8, max_bracket=40):
     """Root of the tf stationarity row G(tf) = 1 + sum_s g_s(tf) on (0, tf_max] (G increasing), or tf_max when
     G(tf_max) <= 0 (range constraint optimizer.py:588 active).  From the reference final time towards the root with doubling
-    steps until the sign changes, then a bracketing secant (Illinois); every G is one batched device solve at fixed tf."""
-    ev = []
+    steps until the sign changes, then a bracketing secant (Illinois); every G is one batched device solve at fixed tf.
+    Returns (tf, SharedTfSearch); the search's `converged` is False when G keeps one sign over the whole search (the
+    downward search stops at 1e-6 tf_max: G > 0 all the way down means the problem wants tf -> 0, which 0 <= tf allows only
+    in the limit)."""
+    ev = SharedTfSearch()
 
     def g(t):
         v = G(t); ev.append((t, v)); return v
+
+    def give_up(t, why):
+        ev.converged = False; ev.message = why
+        return t, ev
     a = min(tf0, tf_max); ga = g(a)
     if abs(ga) <= gtol or (a == tf_max and ga <= 0.0): return a, ev
     h = 0.05 * a
+    t_floor = 1e-6 * tf_max
     while True:
         b = a - h if ga > 0.0 else a + h
-        b = min(max(b, 0.05 * a), tf_max)
+        b = min(max(b, 0.05 * a), tf_max)                # (tf stays positive)
         gb = g(b)
         if abs(gb) <= gtol: return b, ev
         if (ga > 0.0) != (gb > 0.0): break
         if b == tf_max and gb <= 0.0: return tf_max, ev
         a, ga = b, gb; h *= 2.0
-        if len(ev) > 40: return b, ev
+        if b <= t_floor:
+            return give_up(b, f"G > 0 down to tf = {b:.3g}: no root on (0, tf_max]")
+        if len(ev) > max_bracket:
+            return give_up(b, f"no sign change of G in {len(ev)} evaluations (last tf {b:.6g}, G {gb:.3g})")
     lo, glo, hi, ghi = (a, ga, b, gb) if ga < 0.0 else (b, gb, a, ga)
     side = 0; t = 0.5 * (lo + hi)
     for _ in range(40):
@@ -152,9 +202,17 @@ def solve_shared_tf(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options
     """S satellites that share ONE final time, as in a reference Optimizer holding several satellites
     (optimizer.py:287,311,322,336).  Given tf the NLP separates into the S per-satellite problems the device solves in one
     batch (MPCX_SOLVE_FIXED_TF); what remains is the scalar row 1 + sum_s g_s(tf) = 0 (or tf on its bound), solved here.
-    Returns (SolveResult of the final inner solve, list of (tf, G(tf)) evaluations)."""
+    Returns (SolveResult of the final inner solve, SharedTfSearch: the (tf, G(tf)) evaluations and whether a root was
+    found).  An inner solve that ends with a numeric breakdown raises; one whose constraint set is empty
+    (MPCX_ST_INFEASIBLE: it is empty at every tf) ends the search at once, its result is returned with the status set and
+    the search marked not converged; one that stops at max_iter is used as it is and recorded in the search's message --
+    the reference never raises from solve_OPT (optimizer.py:603 ignores ipopt's status)."""
     opts = {**DEFAULT_OPTIONS, **(options or {})}
     S = np.asarray(xbar).shape[0]
+
+    class _Infeasible(Exception):
+        pass
+    notes = []
 
     def inner(t):
         return solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options, device, linear_vt,
@@ -162,10 +220,21 @@ def solve_shared_tf(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options
 
     def G(t):
         r = inner(t)
-        if not np.isin(r.status, (0, 7)).all():
+        if (r.status == 6).any():
             raise _ffi.MpcxError(f"shared-tf inner solve at tf = {t}: status {r.status.tolist()}")
+        if (r.status == 8).any():
+            raise _Infeasible(r)
+        if not np.isin(r.status, (0, 7)).all():
+            notes.append(f"inner solve at tf = {t:.6g} stopped at max_iter for {int((r.status == 5).sum())} satellite(s)")
         return 1.0 + float(np.sum(r.g_tf))
-    tfs, ev = shared_tf_root(G, float(opts["tf_max"]), float(np.asarray(tf).reshape(-1)[0]))
+    try:
+        tfs, ev = shared_tf_root(G, float(opts["tf_max"]), float(np.asarray(tf).reshape(-1)[0]))
+    except _Infeasible as e:
+        ev = SharedTfSearch(); ev.converged = False
+        ev.message = "constraint set empty for at least one satellite (MPCX_ST_INFEASIBLE), at every tf"
+        return e.args[0], ev
+    if notes:
+        ev.message += "; " + "; ".join(notes)
     return inner(tfs), ev
 
 
@@ -252,6 +321,9 @@ class Optimizer:
                                          device=getattr(self.d, "device", 0),
                                          uniform_steps=int(self.d.integrator_steps) if self.d.use_uniform_steps else 0, **solver)
         self.status = self.result.status
+        if self.shared_tf and self._N > 1 and not self.tf_search.converged:
+            import warnings
+            warnings.warn(f"shared-tf search did not find a root: {self.tf_search.message}", RuntimeWarning, stacklevel=2)
         bad = [int(c) for c in self.result.status if c not in (0, 7)]
         if bad and self.verbose:
             print(f"WARNING: solve_OPT status {[_ffi.STATUS_TEXT.get(c, c) for c in bad]}")

@@ -193,7 +193,7 @@ class MpcProblem:
         if K >= 3: v.append(-np.sqrt(r0 @ r0) - self.b_rmin)                         # ... or below the r_min plane (k = 0 < K-1)
         rK_max = np.sqrt(min(self.b_rmax, self.b_rfmax))
         v.append(-self.bT[0] - rK_max)                                               # r_hat.r_K >= r_des - eps_r out of reach
-        if K >= 4: v.append(-self.b_rmin - np.sqrt(self.b_rmax))                     # r_min plane outside the r_max ball
+        if K >= 3: v.append(-self.b_rmin - np.sqrt(self.b_rmax))                     # r_min plane outside the r_max ball
         for lo in (1, 3) + ((6,) if len(self.bT) == 8 else ()):                      # windows a.x <= b+, -a.x <= b-
             v.append(-(self.bT[lo] + self.bT[lo + 1]))
         if self.fixed_tf is None: v.append(-(self.b_tf[0] + self.b_tf[1]))           # 0 < tf <= tf_max

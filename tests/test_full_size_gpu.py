@@ -184,29 +184,72 @@ def test_config3_full_size_scp_loop():
         assert np.abs(X[s] - r["X"]).max() < 5e-6 and abs(tfo[s] - r["tf"]) < 5e-6
 
 
-def test_config4_per_gpu_share():
-    """BASELINE configs[4]: 65 536 satellites over 8 GPUs = 8192 per GPU.  Rank 3's block through the bench harness: every
-    problem converges, and a satellite's result is bit for bit what it is when its generator index is solved in another
-    batch (no cross-satellite state: the shards need no exchange)."""
+def test_config4_every_rank_block():
+    """BASELINE configs[4]: 65 536 satellites over 8 GPUs = 8192 per GPU.  All eight rank blocks (different plane
+    rotations and speed perturbations, mpconstellation_amd/constellation.py), one after the other on this GPU through the
+    bench harness: every problem converges, the properties of test_full_size_properties hold over every satellite, two
+    satellites per block agree with the CPU oracle (which discretises on its own), and a satellite's result is bit for bit
+    what it is when its generator index is solved in another batch (no cross-satellite state: shards need no exchange)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import torch
     import bench
     from mpconstellation_amd import mpc_step_batch
     from mpconstellation_amd.sharding import shard_block
-    rank, world = 3, 8
-    run = bench.Runner("S8192_K30", rank, world, 0)
-    run.step()
-    torch.cuda.synchronize()
-    status, iters, kkt = run.solver_stats()
-    assert run.S == 8192 and (status == 0).all() and kkt.max() <= 1e-8 and iters.mean() <= 13
-    first, count = shard_block(65536, world, rank)
-    assert (first, count) == (3 * 8192, 8192)
-    X = run.d_X.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
-    pick = np.array([0, 1, 4097, 8191])
-    xb, ub, cs, rd = workload(65536, 30, first=first, count=count)            # the same generator indices, rebuilt
-    assert np.array_equal(xb, run.host["xbar"])
-    res = mpc_step_batch(xb[pick], ub[pick], np.ones(len(pick)), cs[pick], rd[pick])
-    assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])
+    world, K = 8, 30
+    for rank in range(world):
+        run = bench.Runner("S8192_K30", rank, world, 0, n_variants=1)
+        run.step()
+        torch.cuda.synchronize()
+        status, iters, kkt = run.solver_stats()
+        assert run.S == 8192 and (status == 0).all() and kkt.max() <= 1e-8 and iters.mean() <= 13 and iters.max() <= 30, rank
+        first, count = shard_block(65536, world, rank)
+        assert (first, count) == (rank * 8192, 8192)
+        X = run.d_X.cpu().numpy(); U = run.d_U.cpu().numpy(); NU = run.d_NU.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
+        h = run.host
+        assert np.abs(X[:, :, 0] - h["xbar"][:, :, 0]).max() == 0.0                               # x_0 fixed   :344-345
+        assert (X[:, 6, -1] >= 0.1 - 1e-6).all()                                                  # final mass  :351-352
+        assert np.linalg.norm(U, axis=1).max() <= 5 + 1e-6 and (np.abs(NU) <= 1e-6).all()         # thrust ball :379-381
+        rn = np.linalg.norm(X[:, :3, :], axis=1)
+        assert rn.max() <= 5 + 1e-6 and np.abs(rn[:, -1] - h["r_des"]).max() <= 0.01 + 1e-6       # r_max, eps_r window
+        assert (tfo > 0).all() and (tfo < 1.0).all()
+        hK = np.cross(X[:, :3, -1], X[:, 3:6, -1])
+        assert np.abs(np.linalg.norm(hK, axis=1) / rn[:, -1] - np.sqrt(h["consts"][:, 0] / h["r_des"])).max() < 1e-7
+        pick = np.array([(977 * (rank + 1)) % 8192, 8191 - 311 * rank])
+        for s in pick:                                     # against the CPU oracle (its own discretisation)
+            x, u, cst, rd = h["xbar"][s], h["ubar"][s], h["consts"][s], float(h["r_des"][s])
+            P = N.MpcProblem(x, u, 1.0, cst[0], O.discretize(x, u, 1.0, cst), O.constraint_terms(x, u, cst[0]), {"r_des": rd})
+            ref = N.solve(P)
+            assert ref["status"] == 0
+            assert np.abs(X[s] - ref["X"]).max() < 5e-6 and np.abs(U[s] - ref["U"]).max() < 5e-6 and abs(tfo[s] - ref["tf"]) < 5e-6
+        res = mpc_step_batch(h["xbar"][pick], h["ubar"][pick], np.ones(len(pick)), h["consts"][pick], h["r_des"][pick])
+        assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])
+        if rank == 3:                                      # the block's inputs are what the generator gives for these indices
+            xb, ub, cs, rd = workload(65536, K, first=first, count=count)
+            assert np.array_equal(xb, h["xbar"]) and np.array_equal(rd, h["r_des"])
+        del run
+        torch.cuda.empty_cache()
+
+
+def test_bench_two_ranks_launched_as_child_processes():
+    """`python bench.py --gpus 2` from a process that is not itself a rank: bench.py starts its two ranks through
+    torch.distributed.run from a parent that never touches the GPU (bench.py: spawn_ranks); on this one-GPU box both ranks
+    share device 0 (MPCX_BENCH_SINGLE_DEVICE=1, gloo for the timing reduction).  The JSON line must report the whole job:
+    two ranks, 2 x 8192 satellites, every problem converged."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, MPCX_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["satellites_total"] == 16384 and out["config"]["workload"] == "S8192_K30"
+    assert out["scaling"] == "weak" and out["solver"]["converged"] == out["solver"]["of"] == 16384
+    assert out["value"] > 0 and abs(out["value"] - 16384 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 
 @pytest.mark.parametrize("K,tf,r_des", [(30, 1.0, 1.5), (30, 2.0, 1.2), (60, 2.0, 1.5), (30, 1.0, 1.05)])

@@ -202,3 +202,21 @@ def test_unconverged_plans_are_not_flown_silently():
     assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning) and "max_iter" in str(w[0].message)
     with pytest.raises(RuntimeError):
         _check_solver_status(np.array([6]), strict=True)
+
+
+def test_shared_tf_root_reports_a_missing_bracket():
+    """The scalar outer search of the shared-tf mode (Optimizer with several satellites, optimizer.py:287): a root, the
+    upper bound when the range constraint is active, and -- instead of silently returning the last point tried -- a search
+    marked not converged when G never changes sign."""
+    from mpconstellation_amd.optimizer import shared_tf_root
+    t, ev = shared_tf_root(lambda t: t - 0.7, 5.0, 1.0)
+    assert ev.converged and abs(t - 0.7) < 1e-6
+    t, ev = shared_tf_root(lambda t: t - 3.3, 5.0, 1.0)
+    assert ev.converged and abs(t - 3.3) < 1e-6
+    t, ev = shared_tf_root(lambda t: -1.0, 5.0, 1.0)                 # G < 0 up to tf_max: the bound is the solution
+    assert ev.converged and t == 5.0
+    t, ev = shared_tf_root(lambda t: 1.0 + t, 5.0, 1.0)              # G > 0 all the way down: no root on (0, tf_max]
+    assert not ev.converged and "no root" in ev.message and len(ev) < 45 and t < 1e-5
+    calls = []
+    t, ev = shared_tf_root(lambda t: (calls.append(t), 1.0)[1], 5.0, 1.0, max_bracket=6)
+    assert not ev.converged and len(calls) == len(ev) <= 8

@@ -173,32 +173,32 @@ def test_scp_update_vs_oracle_chain():
 
 def test_constellation_mpc_equals_single_satellite_loops():
     """the MPC loop for several satellites at once (per-satellite scales, batched planning
-    and flying) gives every satellite what the reference's one-satellite loop gives it."""
+    and flying) gives every satellite what the reference's structure -- one OptimalController + one Simulator per
+    satellite (control.py:162, simulator.py:58-60) -- gives it.  OptimalController.update is the one-satellite case of
+    ConstellationMPC.update, so this checks the batching itself (grouping by node count, concurrent contexts, result
+    scatter): a satellite's plan and flown trajectory do not depend on who shares its batch, bit for bit.  (Against
+    the CPU oracle: test_constellation_mpc_plan_vs_oracle_chain, test_scp_update_vs_oracle_chain.)"""
     from mpconstellation_amd import Satellite, SatelliteScale, Simulator, OptimalController, ConstellationMPC
     r0 = np.array([5371.4806, -4133.1393, 1399.9594]) * 1000; v0 = np.array([4.6921, 4.9848, -3.2752]) * 1000
     make = lambda: [Satellite(r0, v0 * (1 + 0.01 * i), 12200.0) for i in range(3)]
     tf, nseg, base_res, sim_res, r_des = 2, 2, 15, 40, 1.2
-    # reference structure: one controller + one simulator per satellite
     single = []
     for sat in make():
         c = OptimalController(sats=[sat], base_res=base_res, tf_horizon=tf, tf_interval=tf / nseg, plot_inter=False,
                               opt_verbose=False, r_des=r_des)
         sim = Simulator(sats=[sat], controller=c, scale=SatelliteScale(sat=sat), base_res=sim_res, verbose=False)
         sim.run_segments(tf=tf, num_segments=nseg)
-        single.append((sim.sim_data[sat.id], sim.sim_time[sat.id], c.opt_trajectory, sat.get_state_vector().copy()))
+        single.append((sim.sim_data[sat.id], sim.sim_time[sat.id], c.opt_trajectory, sat.get_state_vector().copy(), c.last_status))
     sats = make()
     mpc = ConstellationMPC(sats, base_res=base_res, tf_horizon=tf, tf_interval=tf / nseg, r_des=r_des, sim_base_res=sim_res)
     mpc.run_segments(tf=tf, num_segments=nseg)
-    assert np.isin(mpc.last_status, (0, 7)).all()          # OK or acceptable level (eps_vr = 1e-16 windows, DESIGN.md)
-    for sat, (data, time, plan, state) in zip(sats, single):
+    assert (mpc.last_status == 0).all(), mpc.last_status
+    for i, (sat, (data, time, plan, state, status)) in enumerate(zip(sats, single)):
+        assert status == [0, 0]
         assert mpc.sim_data[sat.id].shape == data.shape == (7, 80)
-        # (not bit for bit: the batched host code forms |r| by sqrt(sum(r*r)) where the reference's per-satellite code
-        # calls the BLAS norm, a last-bit difference in u_bar that the solver returns at its own tolerance)
-        # four solves, several of them stopping at the acceptable level (1e-6), and the rollouts through their plans:
-        # observed 5e-9 .. 6e-6
-        assert np.abs(mpc.sim_data[sat.id] - data).max() < 5e-5 and np.array_equal(mpc.sim_time[sat.id], time)
-        assert np.abs(mpc.plan_x[sats.index(sat)] - plan).max() < 5e-5
-        assert np.abs(sat.get_state_vector() / state - 1).max() < 5e-5
+        assert np.array_equal(mpc.sim_data[sat.id], data) and np.array_equal(mpc.sim_time[sat.id], time)
+        assert np.array_equal(mpc.plan_x[i], plan)
+        assert np.array_equal(sat.get_state_vector(), state)
     assert mpc.horizon == 1.0
 
 

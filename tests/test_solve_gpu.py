@@ -40,17 +40,22 @@ def test_solve_vs_oracle(golden_dir, name):
     stage = {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")}
     P, ref = oracle_solve(x, u, tf, cst, r_des, stage)
     res = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
-                      [tf], cst[None], [r_des])
+                      [tf], cst[None], [r_des], regularised=True)
     assert ref["status"] == 0 and res.status[0] == 0
     assert res.kkt[0] <= 1e-8
+    # the device reports its own regularised iterations (mpcx_solve_regularised): a rounding flip of a breakdown decision
+    # shows as a different count / first index, a path divergence without any regularisation on either side would not
+    n_dev, first_dev = int(res.n_regularised[0]), int(res.first_regularised[0])
+    clean = ref["n_regularised"] == 0 and n_dev == 0
+    firsts = ([ref["first_regularised"]] if ref["n_regularised"] > 0 else []) + ([first_dev] if n_dev > 0 else [])
     # Same data, same algorithm: the same iteration path.  Two things are decided by rounding and may part the paths
     # near their end: whether the last iterate already meets E_0 <= tol (one iteration more or less), and -- on a path
     # that runs through factorisation breakdowns (indefinite reduced Hessian far from the solution, regularised by
     # delta_w) -- whether a pivot of a nearly singular matrix comes out at +1e-17 or -1e-17.  Both sides still end at
     # the same KKT point: the solutions are compared at rounding level when the paths coincide, at the solver
     # tolerance otherwise ...
-    same_path = ref["n_regularised"] == 0 and res.iters[0] == ref["iters"]
-    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if ref["n_regularised"] == 0 else 10)
+    same_path = (clean or (n_dev == ref["n_regularised"] and first_dev == ref["first_regularised"])) and res.iters[0] == ref["iters"]
+    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if clean else 10)
     tol = 5 * TOL if same_path else TOL_SOL
     assert np.abs(res.X[0] - ref["X"]).max() < tol
     assert np.abs(res.U[0] - ref["U"]).max() < tol
@@ -60,7 +65,7 @@ def test_solve_vs_oracle(golden_dir, name):
     # paths are the same: stop both there and compare the iterates.  Tolerance: a direction solved without refinement
     # carries a relative error of 1e-9 .. 1e-6 depending on the barrier weights ("Linear solve"), which the
     # following iterations contract again -- observed up to 2e-8 half way, 1e-14 at the end
-    cap = (ref["first_regularised"] if ref["n_regularised"] > 0 else ref["iters"]) // 2
+    cap = (min(firsts) if firsts else ref["iters"]) // 2
     _, refc = oracle_solve(x, u, tf, cst, r_des, stage, max_iter=cap)
     resc = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
                        [tf], cst[None], [r_des], max_iter=cap)

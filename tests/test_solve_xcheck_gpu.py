@@ -39,7 +39,7 @@ def device_solve(d, opts, r_des, variant, **kw):
 def test_device_vs_independent_nlp_solution(golden_dir, case):
     f, d, opts = load(golden_dir, case)
     variant = str(f["variant"])
-    res = device_solve(d, opts, float(f["r_des"]), variant)
+    res = device_solve(d, opts, float(f["r_des"]), variant, regularised=True)
     assert res.status[0] == 0 and res.kkt[0] <= 1e-8
     tx, tu, ttf = TOL[variant]
     assert np.abs(res.X[0] - f["X"]).max() < tx
@@ -54,7 +54,13 @@ def test_device_vs_independent_nlp_solution(golden_dir, case):
     ref = N.solve(P)
     assert ref["status"] == 0
     assert np.abs(res.X[0] - ref["X"]).max() < 5e-6 and abs(res.tf[0] - ref["tf"]) < 5e-6
-    assert abs(int(res.iters[0]) - ref["iters"]) <= 10
+    # the device's own count of regularised iterations tells a rounding flip of a breakdown decision (both sides
+    # regularise, at possibly different iterations) from a path divergence: without regularisation on either side the
+    # iteration counts agree to the last-iterate decision and the solutions to 1e-8
+    clean = ref["n_regularised"] == 0 and int(res.n_regularised[0]) == 0
+    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if clean else 10)
+    if clean and int(res.iters[0]) == ref["iters"]:
+        assert np.abs(res.X[0] - ref["X"]).max() < 1e-8 and abs(res.tf[0] - ref["tf"]) < 1e-8
 
 
 def test_virtual_control_optimum_on_device(golden_dir):
