@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmpcx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -O2: measured 1.7 % faster than -O3 on solve_kernel (A/B on one box, profiles/tools/ab_timing.py); -Os is 20 % slower
-FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread"]
 
 
 def sources():

@@ -4,8 +4,76 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/mpcx.h"
+
+// Host-side copies between the caller's pageable arrays and the context's page-locked staging, spread over a few
+// persistent worker threads.  A caller's result arrays are usually fresh allocations (numpy hands back newly mapped pages
+// for every large array): the first write to each 4 KB page is a page fault, and one thread filling 17 MB of them was
+// the largest single item of a 4096-satellite host-pointer call (round 2: 20.9 ms against 9.5 ms with page-locked
+// arrays).  Faults of different threads are served concurrently.
+class HostCopier {
+  public:
+    explicit HostCopier(int n) : stop_(false), pending_(0)
+    {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~HostCopier()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    // copy `bytes` from src to dst in page-aligned slices, returns when all of it is done
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const size_t kMin = (size_t)1 << 20;                 // below 1 MB per slice a thread hand-off costs more than it saves
+        size_t n = workers_.empty() ? 1 : (bytes + kMin - 1) / kMin;
+        if (n > workers_.size() + 1) n = workers_.size() + 1;
+        if (n <= 1) { memcpy(dst, src, bytes); return; }
+        size_t slice = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t off = slice; off < bytes; off += slice) {
+                jobs_.push_back({(char *)dst + off, (const char *)src + off, bytes - off < slice ? bytes - off : slice});
+                ++pending_;
+            }
+        }
+        cv_.notify_all();
+        memcpy(dst, src, slice < bytes ? slice : bytes);     // the calling thread takes the first slice
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+  private:
+    struct Job { char *dst; const char *src; size_t bytes; };
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+                if (stop_ && jobs_.empty()) return;
+                j = jobs_.back(); jobs_.pop_back();
+            }
+            memcpy(j.dst, j.src, j.bytes);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::vector<Job> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    bool stop_;
+    size_t pending_;
+};
 
 // Staging for the host-pointer entry points.  The buffers belong to the context and only grow: a device pool and a
 // pinned host pool, each a list of chunks that a call bump-allocates from and the next call reuses from the start --
@@ -60,7 +128,19 @@ struct mpcx_ctx {
     int32_t *nreg;
     int nreg_cap, nreg_S;
     StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
+    HostCopier *copier;                // worker threads of the pageable <-> page-locked copies (created on first use)
+    std::vector<hipEvent_t> events;    // one per download of a host-pointer call: its copy-out starts when ITS transfer is done
 };
+
+inline HostCopier *ctx_copier(mpcx_ctx *ctx)
+{
+    if (!ctx->copier) {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = hw >= 16 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0));      // + the calling thread
+        ctx->copier = new HostCopier(n);
+    }
+    return ctx->copier;
+}
 
 inline int ctx_fail(mpcx_ctx *ctx, int code, const char *msg)
 {
@@ -125,7 +205,7 @@ class DeviceArena {
         }
         void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
         if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return nullptr; }
-        memcpy(pin, h, n * sizeof(T));
+        ctx_copier(ctx_)->copy(pin, h, n * sizeof(T));
         hipError_t e = hipMemcpyAsync(d, pin, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         return d;
@@ -143,23 +223,44 @@ class DeviceArena {
         if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return; }
         hipError_t e = hipMemcpyAsync(pin, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
         if (e != hipSuccess) { code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e)); return; }
-        out_.push_back({h, pin, n * sizeof(T)});
+        // large transfers get their own event: the copy into the caller's array starts as soon as this transfer is done,
+        // while the following ones are still on the bus
+        hipEvent_t ev = nullptr;
+        if (n * sizeof(T) >= ((size_t)1 << 20)) {
+            if (out_ev_ >= ctx_->events.size()) {
+                hipEvent_t ne;
+                if (hipEventCreateWithFlags(&ne, hipEventDisableTiming) == hipSuccess) ctx_->events.push_back(ne);
+            }
+            if (out_ev_ < ctx_->events.size()) {
+                ev = ctx_->events[out_ev_++];
+                if (hipEventRecord(ev, ctx_->stream) != hipSuccess) ev = nullptr;
+            }
+        }
+        out_.push_back({h, pin, n * sizeof(T), ev});
     }
     // wait for the stream, then hand the downloads to the caller's buffers
     int finish()
     {
         if (code_) return code_;
+        HostCopier *cp = ctx_copier(ctx_);
+        for (const auto &o : out_) {                         // (stream order: an event's transfer done = all earlier ones done)
+            if (!o.ev) continue;
+            hipError_t e = hipEventSynchronize(o.ev);
+            if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
+            cp->copy(o.dst, o.src, o.bytes);
+        }
         hipError_t e = hipStreamSynchronize(ctx_->stream);
         if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         dirty_ = false;
-        for (const auto &o : out_) memcpy(o.dst, o.src, o.bytes);
+        for (const auto &o : out_) if (!o.ev) memcpy(o.dst, o.src, o.bytes);
         return MPCX_OK;
     }
     bool failed() const { return code_ != 0; }
     int code() const { return code_; }
 
   private:
-    struct Out { void *dst; const void *src; size_t bytes; };
+    struct Out { void *dst; const void *src; size_t bytes; hipEvent_t ev; };
+    size_t out_ev_ = 0;
     mpcx_ctx *ctx_;
     int code_;
     bool dirty_;              // transfers queued and not yet waited for
