@@ -88,7 +88,8 @@ class Runner:
         self.d_tfo = torch.empty(S, **t64); self.d_kkt = torch.empty(S, **t64)
         i32 = dict(dtype=torch.int32, device=dev)
         self.d_st = torch.empty(S, **i32); self.d_it = torch.empty(S, **i32); self.d_dst = torch.empty(S, **i32)
-        self.d_pst = torch.empty(S, **i32); self.d_pns = torch.empty(S, **i32)
+        self.d_pst = torch.empty(S, **i32); self.d_pns = torch.empty(S, **i32); self.d_rst = torch.empty(S, **i32)
+        self.base_res = K          # tf_bar = 1: K = int(base_res * tf) nodes (simulator.py:38)
         self.d_stage = torch.empty((S, K - 1, _ffi.STAGE_DOUBLES), **t64)
         self.d_ws = torch.empty(self.lib.mpcx_solve_workspace_bytes(S, K) // 8 + 8, **t64)
         self.opts = _ffi.make_solve_opts({})
@@ -107,26 +108,31 @@ class Runner:
             self.d_x.copy_(self.d_x0); self.d_u.copy_(self.d_u0); self.d_tf.copy_(self.d_tf0)
         else:
             self.d_x, self.d_u = self.d_x0, self.d_u0                            # (pointers only: inputs stay resident)
+        ks = None                               # node counts of this SCP iteration (None: K for every satellite)
         for it in range(self.n_scp):
-            # the two launches of mpcx_mpc_step_batch_dev, issued separately so the solve can be bracketed by events
-            ffi.check(lib.mpcx_discretize_stages_dev(ctx, S, K, K, p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c), 0, 1e-2,
-                                                     p(self.d_stage), p(self.d_dst), st), ctx, "discretize")
+            # the two launches of mpcx_mpc_step_batch[_ragged]_dev, issued separately so the solve can be bracketed by events
+            ffi.check(lib.mpcx_discretize_stages_ragged_dev(ctx, S, K, ks, K, ks, p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c), 0,
+                                                            1e-2, p(self.d_stage), p(self.d_dst), st), ctx, "discretize")
             if record:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-            ffi.check(lib.mpcx_solve_batch_dev(ctx, S, K, p(self.d_stage), p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c),
-                                               p(self.d_rd), C.byref(self.opts), p(self.d_X), p(self.d_U), p(self.d_NU), p(self.d_tfo),
-                                               p(self.d_st), p(self.d_it), p(self.d_kkt), p(self.d_ws), st), ctx, "solve")
+            ffi.check(lib.mpcx_solve_batch_ragged_dev(ctx, S, K, ks, p(self.d_stage), p(self.d_x), p(self.d_u), p(self.d_tf), p(self.d_c),
+                                                      p(self.d_rd), C.byref(self.opts), p(self.d_X), p(self.d_U), p(self.d_NU), p(self.d_tfo),
+                                                      p(self.d_st), p(self.d_it), p(self.d_kkt), p(self.d_ws), st), ctx, "solve")
             if record:
                 e1.record(); self.solve_events.append((e0, e1))
-            if self.n_scp > 1:
+            if self.n_scp > 1 and it + 1 < self.n_scp:
                 # SCP re-linearisation point (control.py:221,227): nonlinear rollout under the optimised FOH sequence over
-                # tf_u; the new reference thrust is the sequence itself (FOH at its own nodes).  The reference samples this
-                # rollout at int(base_res * tf_u) nodes, a different count per satellite (ConstellationMPC groups by it);
-                # the benchmark keeps K nodes so that the batch stays one rectangular launch
-                ffi.check(lib.mpcx_propagate_batch_dev(ctx, S, K, p(self.d_y0), p(self.d_tfo), p(self.d_c), 0, ffi.CTRL_SEQUENCE,
-                                                       p(self.d_U), K, p(self.d_one), 1e-3, p(self.d_x), p(self.d_pst), p(self.d_pns),
-                                                       st), ctx, "propagate")
-                self.d_u.copy_(self.d_U); self.d_tf.copy_(self.d_tfo)
+                # tf_u, sampled -- as the reference does, simulator.py:38 -- at int(base_res * tf_u) nodes, a different
+                # count for every satellite: the next iteration is a ragged launch (rows of length K, Kn[s] columns in
+                # use).  The new reference thrust is extract_uk of that sequence at the rollout's nodes.
+                self.d_Kn = (self.d_tfo * float(self.base_res)).to(torch.int32)          # int(base_res * tf_u)
+                ffi.check(lib.mpcx_propagate_batch_ragged_dev(ctx, S, K, p(self.d_Kn), p(self.d_y0), p(self.d_tfo), p(self.d_c), 0,
+                                                              ffi.CTRL_SEQUENCE, p(self.d_U), K, ks, p(self.d_one), 1e-3, p(self.d_x),
+                                                              p(self.d_pst), p(self.d_pns), st), ctx, "propagate")
+                ffi.check(lib.mpcx_resample_sequence_dev(ctx, S, K, ks, p(self.d_U), K, p(self.d_Kn), p(self.d_u), p(self.d_rst), st),
+                          ctx, "resample")
+                self.d_tf.copy_(self.d_tfo)
+                ks = p(self.d_Kn)
 
     def solver_stats(self):
         status = self.d_st.cpu().numpy(); dstat = self.d_dst.cpu().numpy()

@@ -45,6 +45,8 @@ extern "C" {
 #define MPCX_ST_MAXITER 5     /* solver hit max_iter without meeting tol */
 #define MPCX_ST_NUMERIC 6     /* solver: non-finite value or factorisation breakdown */
 #define MPCX_ST_ACCEPTABLE 7  /* solver stopped at the 'acceptable' level (ipopt acceptable_tol) */
+#define MPCX_ST_BADK 9        /* ragged batch: this satellite's node / table-column / output-point count is outside the range
+                               * the call accepts (solve: 3..K, discretize: 2..K, propagate: 1..n_eval, tables: 2..Ku) */
 #define MPCX_ST_INFEASIBLE 8  /* solver: the constraint set is empty whatever the dynamics (start node outside its own radius
                                * bounds, terminal window outside r_max, r_min > r_max, empty window or tf range); seen before
                                * the first iteration: x_bar, u_bar, tf_bar come back, kkt = the violation (ipopt: restoration
@@ -230,6 +232,54 @@ int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0,
                              const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
                              int Ku, const double *end_tau, double max_step, double *y_out,
                              int32_t *status, int32_t *nsteps, void *stream);
+
+/*
+ * Ragged batches.  The reference re-samples every SCP re-rollout at int(base_res * tf_u) nodes (control.py:227 ->
+ * simulator.py:38), a different count for every satellite of a constellation: the next discretize / solve then has K_s
+ * nodes for satellite s.  The *_ragged entry points take one launch of satellites with different counts: arrays keep the
+ * rectangular shapes of the plain entry points with K (n_eval, Ku) the ROW LENGTH, and satellite s uses the first Ks[s]
+ * (n_evals[s], Kus[s]) columns of its rows; np.linspace(0, 1, Ks[s]) is its node grid.  Result columns past a satellite's
+ * count come back zero (stage records past its last interval are unspecified).  A count outside the accepted range gives
+ * that satellite MPCX_ST_BADK and leaves the others alone.  A NULL count array means "all K": the plain entry points are
+ * these with NULL.  Count arrays are int32; device pointers in the _dev variants.
+ */
+int mpcx_discretize_stages_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, int Ku, const int32_t *Kus,
+                                      const double *xbar, const double *ubar, const double *tf,
+                                      const double *consts, int flags, double max_step, double *stage,
+                                      int32_t *status, void *stream);
+int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *stage, const double *xbar,
+                                const double *ubar, const double *tf, const double *consts,
+                                const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
+                                double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                void *workspace, void *stream);
+/* the fused step: thrust tables have as many columns as the satellite has nodes (Kus = Ks) */
+int mpcx_mpc_step_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *xbar, const double *ubar,
+                               const double *tf, const double *consts, const double *r_des, int flags,
+                               double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
+                               double *tf_out, int32_t *status, int32_t *iters, double *kkt);
+int mpcx_mpc_step_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *xbar, const double *ubar,
+                                   const double *tf, const double *consts, const double *r_des, int flags,
+                                   double max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                                   double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                   void *workspace, void *stream);
+/* Simulator.get_trajectory_ODE with t_eval = linspace(0, 1, n_evals[s]) per satellite (simulator.py:38,185-187) and, for
+ * MPCX_CTRL_SEQUENCE, thrust tables of Kus[s] columns */
+int mpcx_propagate_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                const double *tf, const double *consts, int flags, int ctrl_kind,
+                                const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                double max_step, double *y_out, int32_t *status, int32_t *nsteps);
+int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                    const double *tf, const double *consts, int flags, int ctrl_kind,
+                                    const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                    double max_step, double *y_out, int32_t *status, int32_t *nsteps, void *stream);
+/*
+ * Replaces Discretizer.extract_uk (linearize_discretize.py:393-411) for a SequenceController played over its own horizon
+ * (control.py:217-221, tf_sim = tf_u: end_tau = 1): the first-order hold (control.py:104-126) of table u [S][3][Ku]
+ * (Kus[s] columns in use) at the nodes linspace(0, 1, ns[s]) -> u_out [S][3][n], the reference thrust of the next SCP
+ * iteration.  status [S]: MPCX_ST_FOH / MPCX_ST_BADK.
+ */
+int mpcx_resample_sequence_dev(mpcx_ctx *ctx, int S, int Ku, const int32_t *Kus, const double *u, int n,
+                               const int32_t *ns, double *u_out, int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ STATUS_TEXT = {
     0: "ok", 1: "satellite mass <= 0", 2: "RK45 step size underflow",
     3: "FOH index outside the input table", 4: "state-transition matrix singular",
     5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
+    9: "ragged batch: node / table-column / output-point count outside the accepted range",
     8: "constraint set empty (start node outside its radius bounds, terminal window outside r_max, empty window or tf range)",
 }
 FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS = 1, 2, 4
@@ -74,6 +75,19 @@ _SIGS = {
                                                                          _ip, _ip, _dp]),
     "mpcx_mpc_step_batch_dev": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double, _po] + [_vp] * 7
                                 + [_vp, _vp]),
+    # ragged batches (per-satellite node counts)
+    "mpcx_discretize_stages_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                                    C.c_int, C.c_double, _vp, _vp, _vp]),
+    "mpcx_solve_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp] + [_vp] * 6 + [_po] + [_vp] * 7 + [_vp, _vp]),
+    "mpcx_mpc_step_batch_ragged": (C.c_int, [_vp, C.c_int, C.c_int, _ip] + [_dp] * 5 + [C.c_int, C.c_double, _po, _dp, _dp, _dp,
+                                                                                     _dp, _ip, _ip, _dp]),
+    "mpcx_mpc_step_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp] + [_vp] * 5 + [C.c_int, C.c_double, _po] + [_vp] * 7
+                                       + [_vp, _vp]),
+    "mpcx_propagate_batch_ragged": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _ip,
+                                              _dp, C.c_double, _dp, _ip, _ip]),
+    "mpcx_propagate_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                                  _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "mpcx_resample_sequence_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
 }
 
 

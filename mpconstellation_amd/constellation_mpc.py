@@ -8,8 +8,9 @@ is one batched device call over all satellites, each with its own SatelliteScale
     optimised first-order-hold sequence over tf_u ]  ->  fly the segment under the truth model, update the states.
 
 The number of nodes of the second SCP iteration is int(base_res * tf_u) and differs between satellites, as does the
-length of the thrust table played back during the segment; satellites are grouped by node count and every group is
-one batch, so each satellite gets exactly the result of the single-satellite path (tests/test_mpc_loop_gpu.py)."""
+length of the thrust table played back during the segment: those steps are ragged launches (include/mpcx.h,
+mpcx_*_ragged: per-satellite node counts inside one rectangular batch), so each satellite gets exactly the result of the
+single-satellite path (tests/test_mpc_loop_gpu.py) and the host never groups or loops over satellites."""
 import queue
 import threading
 import time
@@ -29,29 +30,47 @@ def foh_resample(u, n):
     """SequenceController(u, tf_u, tf_sim=tf_u).get_u_func() evaluated at linspace(0, 1, n) (control.py:103-131:
     first-order hold with Python's float floor division, the last column at tau == 1) for a batch u (S,3,K)."""
     S, _, K = u.shape
-    tau = np.linspace(0, 1, n)
-    dtau = 1 / (K - 1)
-    out = np.empty((S, 3, n))
-    for i, tq in enumerate(tau):
-        if tq == 1:
-            out[:, :, i] = u[:, :, -1]
-            continue
-        k = int(tq // dtau)
-        tau_k = k / (K - 1); tau_kp1 = (k + 1) / (K - 1)
-        lam_n = (tau_kp1 - tq) / (tau_kp1 - tau_k); lam_p = (tq - tau_k) / (tau_kp1 - tau_k)
-        out[:, :, i] = lam_n * u[:, :, k] + lam_p * u[:, :, k + 1]
-    return out
+    return foh_resample_ragged(u, np.full(S, K), np.full(S, n))
 
 
-MAX_SLOTS = 8      # contexts (streams) used side by side by one ConstellationMPC step
+def foh_resample_ragged(u, Ku, n):
+    """The same for a ragged batch, every satellite at once: table u (S,3,Kmax) with Ku[s] columns in use, evaluated at
+    linspace(0, 1, n[s]) -> (S,3,max(n)), zero past a satellite's last node.  Extract_uk of the reference
+    (linearize_discretize.py:393-411) for SequenceController(u_s, tf_u, tf_sim = tf_u): np.linspace's nodes (i * step, the
+    last one exactly 1), k = int(tau // dtau) (numpy's float floor_divide is CPython's algorithm), tau_k = k / (K-1),
+    the blend as written in control.py:122-126."""
+    u = np.asarray(u, dtype=np.float64)
+    S = u.shape[0]
+    Ku = np.asarray(Ku).reshape(S, 1); nn = np.asarray(n).reshape(S, 1)
+    nmax = int(nn.max())
+    i = np.arange(nmax, dtype=np.float64)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        step = 1.0 / (nn - 1.0)
+        tau = np.where(nn > 1, i * step, 0.0)
+        tau = np.where((i == nn - 1) & (nn > 1), 1.0, tau)
+        km1 = (Ku - 1).astype(np.float64)
+        dtau = 1 / km1
+        k = np.floor_divide(tau, dtau)
+    at1 = tau == 1
+    k = np.clip(np.where(at1, 0, k), 0, Ku - 2).astype(np.int64)
+    tau_k = k / km1; tau_kp1 = (k + 1) / km1
+    lam_n = (tau_kp1 - tau) / (tau_kp1 - tau_k); lam_p = (tau - tau_k) / (tau_kp1 - tau_k)
+    uk = np.take_along_axis(u, np.broadcast_to(k[:, None, :], (S, 3, nmax)), axis=2)
+    uk1 = np.take_along_axis(u, np.broadcast_to(k[:, None, :] + 1, (S, 3, nmax)), axis=2)
+    out = lam_n[:, None, :] * uk + lam_p[:, None, :] * uk1
+    last = np.take_along_axis(u, np.broadcast_to((Ku - 1)[:, None, :], (S, 3, 1)), axis=2)
+    out = np.where(at1[:, None, :], last, out)
+    return np.where((i < nn)[:, None, :], out, 0.0)
+
+
+MAX_SLOTS = 8      # contexts (streams) used side by side (run_concurrently)
 
 
 def _concurrently(fn, jobs, device, **kw):
-    """Several batched calls at once.  A rollout is ~1000 sequential RK45 steps and a solve ~25-50 sequential
-    interior-point iterations however few satellites the call carries, so the groups run concurrently.  A context is
-    not thread-safe (include/mpcx.h: one context per host thread): every worker thread of the pool owns one context
-    slot for its whole life (taken from a queue by the pool initialiser), so however many jobs there are no two calls
-    in flight ever share a context."""
+    """Several batched calls at once, each on its own context / stream (a context is not thread-safe, include/mpcx.h:
+    every worker thread of the pool owns one context slot for its whole life).  ConstellationMPC itself no longer needs
+    it -- a planning step is one ragged launch -- it stays for callers that drive several constellations from one
+    process."""
     if len(jobs) == 1:
         return [fn(*jobs[0], device=device, **kw)]
     n = min(MAX_SLOTS, len(jobs))
@@ -68,10 +87,6 @@ def _concurrently(fn, jobs, device, **kw):
 
     with ThreadPoolExecutor(max_workers=n, initializer=take_slot) as pool:
         return list(pool.map(run, jobs))
-
-
-def _rollouts(jobs, device):
-    return _concurrently(propagate_batch, jobs, device)
 
 
 class ConstellationMPC:
@@ -91,7 +106,7 @@ class ConstellationMPC:
         self.strict = strict                  # raise instead of warning when a solve does not converge (control.py mirror)
         self.sim_data, self.sim_time = {}, {}
         self.last_status = None
-        self.plan_u, self.plan_tf, self.plan_x, self.plan_nu = None, None, None, None
+        self.plan_u, self.plan_tf, self.plan_x, self.plan_nu, self.plan_K = None, None, None, None, None
         # wall-clock seconds spent inside the batched device calls (host staging included), accumulated over the updates
         self.timing = {"rollouts": 0.0, "discretize_solve": 0.0, "truth_propagation": 0.0}
 
@@ -114,49 +129,39 @@ class ConstellationMPC:
         self._check(st)
         u_bar = tangential_thrust(x, 0.5)                                  # extract_uk of the tangential controller
         tf_u = np.full(S, float(self.horizon))
-        groups = {K: np.arange(S)}
-        xs = {K: x}; us = {K: u_bar}
+        Ks = None                                                          # first iteration: K nodes for everybody
         self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
-        plan_u = [None] * S; plan_x = [None] * S; plan_nu = [None] * S
         opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": self.horizon}     # control.py:192-197
+        res = None
         for it in range(self.scp_iterations):
-            nxt_groups, nxt_x, nxt_u = {}, {}, {}
-            keys = list(groups)
-            jobs = [(xs[Kg], us[Kg], tf_u[groups[Kg]], self.consts[groups[Kg]], self.r_des[groups[Kg]]) for Kg in keys]
-            if S <= 256:      # small groups: the solves are latency bound and overlap (measured: -12 % at 64 satellites)
-                solved = self._timed("discretize_solve", _concurrently, mpc_step_batch, jobs, self.device, options=opts)
-            else:             # large ones fill the device on their own; separate contexts would only regrow workspaces
-                solved = self._timed("discretize_solve", lambda: [mpc_step_batch(*job, options=opts, device=self.device) for job in jobs])
-            for Kg, res in zip(keys, solved):
-                idx = groups[Kg]
-                self.last_status[it, idx] = res.status
-                _check_solver_status(res.status, self.strict)
-                tf_u[idx] = res.tf
-                for j, s in enumerate(idx):
-                    plan_u[s] = res.U[j]; plan_x[s] = res.X[j]; plan_nu[s] = res.NU[j]
-                    if self.verbose:
-                        print(f"tf for optimizer: {res.tf[j]}")
-                        print(f"Total virtual control effort: {np.abs(res.NU[j]).sum()}")
-                if it == self.scp_iterations - 1:
-                    continue          # (the reference re-rolls once more, control.py:227, and drops the result)
-                # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
-                Kn = (self.base_res * res.tf).astype(int)
-                kns = np.unique(Kn)
-                sels = [np.nonzero(Kn == kn)[0] for kn in kns]
-                outs = self._timed("rollouts", _rollouts,
-                                   [(y0[idx[sel]], tf_u[idx[sel]], self.consts[idx[sel]], (_ffi.CTRL_SEQUENCE, res.U[sel], Kg, 1.0),
-                                     int(kn), False, False, 0.001) for kn, sel in zip(kns, sels)], self.device)
-                for kn, sel, (xr, st, _) in zip(kns, sels, outs):
-                    gi = idx[sel]
-                    self._check(st)
-                    ur = foh_resample(res.U[sel], int(kn))              # extract_uk of SequenceController(tf_sim = tf_u)
-                    if int(kn) in nxt_groups:
-                        nxt_groups[int(kn)] = np.concatenate([nxt_groups[int(kn)], gi])
-                        nxt_x[int(kn)] = np.concatenate([nxt_x[int(kn)], xr]); nxt_u[int(kn)] = np.concatenate([nxt_u[int(kn)], ur])
-                    else:
-                        nxt_groups[int(kn)] = gi; nxt_x[int(kn)] = xr; nxt_u[int(kn)] = ur
-            groups, xs, us = nxt_groups, nxt_x, nxt_u
-        self.plan_u, self.plan_x, self.plan_nu, self.plan_tf = plan_u, plan_x, plan_nu, tf_u.copy()
+            # one launch for the whole constellation; from the second iteration on it is ragged: the re-rollout of
+            # satellite s was sampled at int(base_res * tf_u[s]) nodes (control.py:227, simulator.py:38)
+            res = self._timed("discretize_solve", mpc_step_batch, x, u_bar, tf_u, self.consts, self.r_des, options=opts,
+                              device=self.device, Ks=Ks)
+            self.last_status[it] = res.status
+            _check_solver_status(res.status, self.strict)
+            if self.verbose:
+                for j in range(S):
+                    print(f"tf for optimizer: {res.tf[j]}")
+                    print(f"Total virtual control effort: {np.abs(res.NU[j]).sum()}")
+            Ku = np.full(S, x.shape[2]) if Ks is None else Ks
+            tf_u = res.tf.copy()
+            if it == self.scp_iterations - 1:
+                break                 # (the reference re-rolls once more, control.py:227, and drops the result)
+            # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
+            Kn = (self.base_res * res.tf).astype(np.int32)
+            x, st, _ = self._timed("rollouts", propagate_batch, y0, tf_u, self.consts, (_ffi.CTRL_SEQUENCE, res.U, res.U.shape[2], 1.0),
+                                   Kn, False, False, 0.001, self.device, Kus=Ku)
+            self._check(st)
+            u_bar = foh_resample_ragged(res.U, Ku, Kn)                     # extract_uk of SequenceController(tf_sim = tf_u)
+            Ks = Kn
+        Kp = np.full(S, res.X.shape[2]) if Ks is None else Ks
+        self.plan_K = Kp.astype(np.int32)
+        self._plan_U = res.U                                               # (S,3,Kmax): the table the segment is flown with
+        self.plan_u = [res.U[s][:, :Kp[s]] for s in range(S)]
+        self.plan_x = [res.X[s][:, :Kp[s]] for s in range(S)]
+        self.plan_nu = [res.NU[s][:, :Kp[s]] for s in range(S)]
+        self.plan_tf = tf_u.copy()
         if self.horizon - self.interval > 0.1:                               # control.py:234-235
             self.horizon -= self.interval
 
@@ -164,20 +169,12 @@ class ConstellationMPC:
     def run_segment(self, tf=1):
         self.update()
         n_eval = int(self.sim_base_res * tf)
-        S = len(self.sats)
         y0 = self._y0()
-        Ku = np.array([u.shape[1] for u in self.plan_u])
-        y = np.empty((S, 7, n_eval))
-        kus = np.unique(Ku)
-        gis = [np.nonzero(Ku == ku)[0] for ku in kus]
-        # SequenceController(tf_u, tf_sim = interval): end_tau = tf_u / interval
-        outs = self._timed("truth_propagation", _rollouts,
-                           [(y0[gi], tf, self.consts[gi], (_ffi.CTRL_SEQUENCE, np.stack([self.plan_u[s] for s in gi]), int(ku),
-                                                           self.plan_tf[gi] / self.interval), n_eval, self.include_drag, self.include_J2,
-                             0.001) for ku, gi in zip(kus, gis)], self.device)
-        for gi, (yy, st, _) in zip(gis, outs):
-            self._check(st)
-            y[gi] = yy
+        # SequenceController(tf_u, tf_sim = interval): end_tau = tf_u / interval; one launch, tables of plan_K[s] columns
+        y, st, _ = self._timed("truth_propagation", propagate_batch, y0, tf, self.consts,
+                               (_ffi.CTRL_SEQUENCE, self._plan_U, self._plan_U.shape[2], self.plan_tf / self.interval), n_eval,
+                               self.include_drag, self.include_J2, 0.001, self.device, Kus=self.plan_K)
+        self._check(st)
         t = np.linspace(0, 1, n_eval)
         for i, (sat, sc) in enumerate(zip(self.sats, self.scales)):
             sat.update_state_vector(sc.redim_state(y[i][:, -1]))

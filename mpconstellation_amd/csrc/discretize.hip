@@ -25,7 +25,8 @@ constexpr int kMaxRkIters = 200000;   // attempts per interval before giving up 
 enum { LAYOUT_STAGE = 0, LAYOUT_REF = 1 };
 
 struct DiscArgs {
-    int S, K, Ku, flags;
+    int S, K, Ku, flags;                 // K, Ku: nodes / thrust-table columns of every satellite, or (Ks / Kus given) row lengths
+    const int32_t *Ks, *Kus;             // ragged batch: per-satellite node and table-column counts; nullptr: all K / Ku
     double max_step;
     const double *xbar, *ubar, *tf, *consts;
     double *stage;                       // LAYOUT_STAGE
@@ -40,7 +41,7 @@ __device__ __forceinline__ double group_sum(double v)
 
 struct RhsCtx {
     const double *us;
-    int Ku, flags, c;
+    int Ku, ldu, flags, c;
     double tf;
     SatConst cst;
     FohCache foh;        // the thrust table's interval in use (see foh3_cached)
@@ -51,7 +52,7 @@ __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], doubl
                                          double (&out)[7], int &err)
 {
     double u[3];
-    foh3_cached(ts, p.us, p.Ku, p.foh, u, err);
+    foh3_cached(ts, p.us, p.Ku, p.ldu, p.foh, u, err);
     const double rx = bcast8<7>(ys[0]), ry = bcast8<7>(ys[1]), rz = bcast8<7>(ys[2]);
     const double m = bcast8<7>(ys[6]);
     double G[3][3], gm[3];
@@ -136,7 +137,7 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const dou
 #pragma unroll
     for (int i = 0; i < 7; ++i) x[i] = bcast8<7>(y[i]);
     double u[3];
-    foh3_cached(t, p.us, p.Ku, p.foh, u, err);
+    foh3_cached(t, p.us, p.Ku, p.ldu, p.foh, u, err);
     const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);
     const double lam_p = (t - tau_k) / (tau_kp1 - tau_k);
     const double tf = p.tf, m = x[6];
@@ -218,29 +219,40 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
     const int grp = lane >> 3, c = lane & 7;
     double *rec = lds + grp * kRec;
 
-    const int Km1 = a.K - 1;
+    const int Km1 = a.K - 1;                        // slots per satellite in the output arrays
     const long total = (long)a.S * Km1;
     const long item0 = (long)blockIdx.x * 8;
     const long item = item0 + grp;
-    const bool valid = item < total;
-    const long it = valid ? item : total - 1;      // tail groups shadow the last item, write nothing
-    const int s = (int)(it / Km1), k = (int)(it % Km1);
+    const bool in_range = item < total;
+    const long it = in_range ? item : total - 1;      // tail groups shadow the last item, write nothing
+    const int s = (int)(it / Km1), kslot = (int)(it % Km1);
+    // ragged batch: this satellite's own node count; the slots past its last interval shadow that interval (their output
+    // lands in slots nobody reads)
+    int Ks = a.Ks ? a.Ks[s] : a.K;
+    const bool badk = Ks < 2 || Ks > a.K;
+    Ks = badk ? a.K : Ks;
+    const int Km1s = Ks - 1;
+    const bool valid = in_range && kslot < Km1s;
+    const int k = kslot < Km1s ? kslot : Km1s - 1;
 
     RhsCtx p;
     p.us = a.ubar + (size_t)s * 3 * a.Ku;
-    p.Ku = a.Ku; p.flags = a.flags & (MPCX_FLAG_DRAG | MPCX_FLAG_J2); p.c = c; p.foh.reset();
+    p.Ku = a.Kus ? a.Kus[s] : a.Ku; p.ldu = a.Ku;
+    const bool badku = p.Ku < 2 || p.Ku > a.Ku;
+    if (badku) p.Ku = a.Ku;
+    p.flags = a.flags & (MPCX_FLAG_DRAG | MPCX_FLAG_J2); p.c = c; p.foh.reset();
     const int n_uni = UNIFORM ? (a.flags >> 8) : 0;                 // integrator_steps
     p.tf = a.tf[s];
     p.cst.load(a.consts + (size_t)s * MPCX_NCONST);
     const double *xs = a.xbar + (size_t)s * 7 * a.K;
 
     // np.linspace(0, 1, K)[k], [k+1]
-    const double step = 1.0 / (double)Km1;
+    const double step = 1.0 / (double)Km1s;
     const double tau_k = (double)k * step + 0.0;
-    const double tau_kp1 = (k + 1 == Km1) ? 1.0 : (double)(k + 1) * step + 0.0;
+    const double tau_kp1 = (k + 1 == Km1s) ? 1.0 : (double)(k + 1) * step + 0.0;
     const double t_bound = tau_kp1;
     const double rtol = 1e-3, atol = 1e-6;
-    int err = 0;
+    int err = (badk || badku) ? MPCX_ST_BADK : 0;
 
     double y[7], f[7];
 #pragma unroll
@@ -523,8 +535,18 @@ extern "C" int mpcx_discretize_batch_dev(mpcx_ctx *ctx, int S, int K, int Ku, co
                                          void *stream)
 {
     if (!ctx) return MPCX_E_BADARG;
-    DiscArgs a{S, K, Ku, flags, max_step, xbar, ubar, tf, consts, nullptr, A, Bp, Bn, Sigma, xi, status};
+    DiscArgs a{S, K, Ku, flags, nullptr, nullptr, max_step, xbar, ubar, tf, consts, nullptr, A, Bp, Bn, Sigma, xi, status};
     return launch_discretize(ctx, LAYOUT_REF, a, (hipStream_t)stream);
+}
+
+extern "C" int mpcx_discretize_stages_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, int Ku, const int32_t *Kus,
+                                                 const double *xbar, const double *ubar, const double *tf,
+                                                 const double *consts, int flags, double max_step, double *stage,
+                                                 int32_t *status, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    DiscArgs a{S, K, Ku, flags, Ks, Kus, max_step, xbar, ubar, tf, consts, stage, nullptr, nullptr, nullptr, nullptr, nullptr, status};
+    return launch_discretize(ctx, LAYOUT_STAGE, a, (hipStream_t)stream);
 }
 
 extern "C" int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,
@@ -532,9 +554,7 @@ extern "C" int mpcx_discretize_stages_dev(mpcx_ctx *ctx, int S, int K, int Ku, c
                                           int flags, double max_step, double *stage, int32_t *status,
                                           void *stream)
 {
-    if (!ctx) return MPCX_E_BADARG;
-    DiscArgs a{S, K, Ku, flags, max_step, xbar, ubar, tf, consts, stage, nullptr, nullptr, nullptr, nullptr, nullptr, status};
-    return launch_discretize(ctx, LAYOUT_STAGE, a, (hipStream_t)stream);
+    return mpcx_discretize_stages_ragged_dev(ctx, S, K, nullptr, Ku, nullptr, xbar, ubar, tf, consts, flags, max_step, stage, status, stream);
 }
 
 extern "C" int mpcx_discretize_batch(mpcx_ctx *ctx, int S, int K, int Ku, const double *xbar,

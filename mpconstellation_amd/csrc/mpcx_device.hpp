@@ -50,11 +50,12 @@ __device__ __forceinline__ double py_floordiv(double a, double b)
 }
 
 // First-order hold of a (3,Ku) row-major table: linearize_discretize.py:294-315, control.py:104-126
-__device__ __forceinline__ void foh3(double tau, const double *__restrict__ u, int Ku, double (&out)[3],
+// (ld: row length of the table in memory, Ku <= ld of its columns in use -- they differ only in ragged batches)
+__device__ __forceinline__ void foh3(double tau, const double *__restrict__ u, int Ku, int ld, double (&out)[3],
                                      int &err)
 {
     if (tau == 1.0) {
-        out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1];
+        out[0] = u[Ku - 1]; out[1] = u[ld + Ku - 1]; out[2] = u[2 * ld + Ku - 1];
         return;
     }
     const double km1 = (double)(Ku - 1);
@@ -69,8 +70,8 @@ __device__ __forceinline__ void foh3(double tau, const double *__restrict__ u, i
     const double lam_n = (tau_kp1 - tau) / (tau_kp1 - tau_k);
     const double lam_p = (tau - tau_k) / (tau_kp1 - tau_k);
     out[0] = lam_n * u[k] + lam_p * u[k + 1];
-    out[1] = lam_n * u[Ku + k] + lam_p * u[Ku + k + 1];
-    out[2] = lam_n * u[2 * Ku + k] + lam_p * u[2 * Ku + k + 1];
+    out[1] = lam_n * u[ld + k] + lam_p * u[ld + k + 1];
+    out[2] = lam_n * u[2 * ld + k] + lam_p * u[2 * ld + k + 1];
 }
 
 // The same first-order hold with the interval in use kept in registers: the two table columns, the node index and the
@@ -85,12 +86,12 @@ struct FohCache {
     __device__ __forceinline__ void reset() { k = -1; tau_k = 2.0; tau_kp1 = -1.0; }
 };
 
-__device__ __forceinline__ void foh3_cached(double tau, const double *__restrict__ u, int Ku, FohCache &c, double (&out)[3],
+__device__ __forceinline__ void foh3_cached(double tau, const double *__restrict__ u, int Ku, int ld, FohCache &c, double (&out)[3],
                                             int &err)
 {
     if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {      // rare: everything but "same interval" is behind this branch
         if (tau == 1.0) {
-            out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1];
+            out[0] = u[Ku - 1]; out[1] = u[ld + Ku - 1]; out[2] = u[2 * ld + Ku - 1];
             return;
         }
         const double km1 = (double)(Ku - 1);
@@ -105,7 +106,7 @@ __device__ __forceinline__ void foh3_cached(double tau, const double *__restrict
             c.k = k;
             c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * Ku + k]; c.uk1[i] = u[i * Ku + k + 1]; }
+            for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * ld + k]; c.uk1[i] = u[i * ld + k + 1]; }
         }
     }
     const double lam_n = (c.tau_kp1 - tau) / (c.tau_kp1 - c.tau_k);

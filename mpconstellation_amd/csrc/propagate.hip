@@ -14,7 +14,8 @@
 namespace mpcx {
 
 struct PropArgs {
-    int S, n_eval, flags, ctrl_kind, Ku;
+    int S, n_eval, flags, ctrl_kind, Ku;     // n_eval, Ku: output points / table columns of every satellite, or row lengths
+    const int32_t *n_evals, *Kus;            // ragged batch: per-satellite counts (<= n_eval, <= Ku); nullptr: all the same
     double max_step;
     const double *y0, *tf, *consts;
     const double *ctrl_vec;   // CONSTANT: [S][3]; TANGENTIAL: [S] magnitudes; SEQUENCE: [S][3][Ku]
@@ -24,7 +25,7 @@ struct PropArgs {
 };
 
 struct Ctrl {
-    int kind, Ku;
+    int kind, Ku, ldu;        // ldu: row length of the thrust table in memory (Ku of its columns in use)
     double v[3], vn;          // vn = |v| (constant thrust)
     const double *useq;
     double end_tau, inv_end_tau;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
     // Everything else -- a new interval, an end point, tau == 1 -- is behind this one rarely taken branch: the right-hand
     // side is evaluated six times per step and every branch in it costs the in-order wave ~40 cycles.
     if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
-    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[2 * Ku - 1]; out[2] = u[3 * Ku - 1]; return; }
+    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[c.ldu + Ku - 1]; out[2] = u[2 * c.ldu + Ku - 1]; return; }
     const double km1 = (double)(Ku - 1);
     const double q = tau * km1;
     int k = (fabs(q - rint(q)) > 1e-9 * fmax(1.0, q)) ? (int)floor(q) : (int)py_floordiv(tau, 1.0 / km1);
@@ -78,7 +79,7 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
         c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
         c.id = 1.0 / (c.tau_kp1 - c.tau_k);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * Ku + k]; c.uk1[i] = u[i * Ku + k + 1]; }
+        for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * c.ldu + k]; c.uk1[i] = u[i * c.ldu + k + 1]; }
     }
     }
     const double lam_n = (c.tau_kp1 - tau) * c.id, lam_p = (tau - c.tau_k) * c.id;
@@ -166,13 +167,18 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     if (sat >= a.S) return;
     SatConst cst; cst.load(a.consts + (size_t)sat * MPCX_NCONST);
     const double tf = a.tf[sat];
-    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0;
+    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Kus ? a.Kus[sat] : a.Ku; c.ldu = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0;
     if (a.ctrl_kind == MPCX_CTRL_CONSTANT) { for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i]; }
     else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
     else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }
     c.vn = sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]);
     c.inv_end_tau = 1.0 / c.end_tau;
-    const int n_eval = a.n_eval;
+    const int ld = a.n_eval;                                     // row length of y_out
+    int n_eval = a.n_evals ? a.n_evals[sat] : a.n_eval;
+    if (n_eval < 1 || n_eval > ld || (a.ctrl_kind == MPCX_CTRL_SEQUENCE && (c.Ku < 2 || c.Ku > a.Ku))) {
+        a.status[sat] = MPCX_ST_BADK; a.nsteps[sat] = 0;
+        return;
+    }
     const double inv_gi = 1.0 / (cst.g0 * cst.isp);
     const double rtol = 1e-3, atol = 1e-6, t_bound = 1.0;
     int err = 0;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     const double estep = (n_eval > 1) ? 1.0 / (double)(n_eval - 1) : 0.0;
     int ei = 0, nsteps = 0;
     bool rejected = false;
-    double *yo = a.y_out + (size_t)sat * 7 * n_eval;
+    double *yo = a.y_out + (size_t)sat * 7 * ld;
     for (int iter = 0; iter < 4000000; ++iter) {
         if (t == t_bound) break;
         // scipy: min_step = 10 |nextafter(t, inf) - t| <= 10 ulp(1) = 2.3e-15 for t in [0, 1]; it only guards against
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
                         for (int j = 0; j < 7; ++j) q += kk[j] * RK_P[j][cc];
                         acc += q * pw[cc];
                     }
-                    yo[(size_t)i * n_eval + ei] = h * acc + y[i];
+                    yo[(size_t)i * ld + ei] = h * acc + y[i];
                 }
                 ++ei;
             }
@@ -308,14 +314,50 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     a.nsteps[sat] = nsteps;
 }
 
+// Discretizer.extract_uk (linearize_discretize.py:393-411) of a SequenceController played over its own horizon
+// (SequenceController(u, tf_u, tf_sim = tf_u), control.py:217-221: end_tau = 1) at the nodes linspace(0, 1, n_s): the
+// reference thrust of the next SCP iteration.  One lane per (satellite, output node).
+__global__ __launch_bounds__(256) void resample_sequence_kernel(int S, int Ku, const int32_t *Kus, const double *u, int n, const int32_t *ns,
+                                                                double *out, int32_t *status)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)S * n) return;
+    const int s = (int)(idx / n), i = (int)(idx - (long)s * n);
+    const int ku = Kus ? Kus[s] : Ku, nn = ns ? ns[s] : n;
+    double o[3] = {0.0, 0.0, 0.0};
+    if (ku < 2 || ku > Ku || nn < 1 || nn > n) { if (i == 0) status[s] = MPCX_ST_BADK; }
+    else if (i < nn) {
+        // np.linspace(0, 1, nn)[i]: i * step, the last point exactly 1
+        const double tau = (i == nn - 1 && nn > 1) ? 1.0 : (double)i * (1.0 / (double)(nn > 1 ? nn - 1 : 1)) + 0.0;
+        int err = 0;
+        foh3(tau, u + (size_t)s * 3 * Ku, ku, Ku, o, err);
+        if (err) atomicMax(&status[s], err);
+    }
+    for (int r = 0; r < 3; ++r) out[(size_t)s * 3 * n + (size_t)r * n + i] = o[r];      // (zeros past the satellite's last node)
+}
+
 }  // namespace mpcx
 
 using namespace mpcx;
 
-extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
-                                        const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
-                                        int Ku, const double *end_tau, double max_step, double *y_out,
-                                        int32_t *status, int32_t *nsteps, void *stream)
+extern "C" int mpcx_resample_sequence_dev(mpcx_ctx *ctx, int S, int Ku, const int32_t *Kus, const double *u, int n,
+                                          const int32_t *ns, double *u_out, int32_t *status, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || Ku < 2 || n < 1 || !u || !u_out || !status) return ctx_fail(ctx, MPCX_E_BADARG, "resample_sequence: need S>=1, Ku>=2, n>=1 and all arrays");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    MPCX_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * S, (hipStream_t)stream));
+    const long total = (long)S * n;
+    hipLaunchKernelGGL(resample_sequence_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, Ku, Kus, u, n, ns,
+                       u_out, status);
+    MPCX_HIP(ctx, hipGetLastError());
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                               const double *tf, const double *consts, int flags, int ctrl_kind,
+                                               const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                               double max_step, double *y_out, int32_t *status, int32_t *nsteps, void *stream)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || n_eval < 1 || !(max_step > 0.0)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1, max_step>0");
@@ -323,7 +365,7 @@ extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const 
     if (ctrl_kind == MPCX_CTRL_SEQUENCE && (Ku < 2 || !end_tau || !ctrl_vec)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: sequence needs Ku>=2, table and end_tau");
     if ((ctrl_kind == MPCX_CTRL_CONSTANT || ctrl_kind == MPCX_CTRL_TANGENTIAL) && !ctrl_vec) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: thrust parameters missing");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
-    PropArgs a{S, n_eval, flags, ctrl_kind, Ku, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
+    PropArgs a{S, n_eval, flags, ctrl_kind, Ku, n_evals, Kus, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
     const dim3 grid((S + 63) / 64), block(64);
     hipStream_t st = (hipStream_t)stream;
 #define MPCX_PROP_LAUNCH(KIND, FLAGS) hipLaunchKernelGGL((propagate_kernel<KIND, FLAGS>), grid, block, 0, st, a)
@@ -346,10 +388,19 @@ extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const 
     return MPCX_OK;
 }
 
-extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
-                                    const double *consts, int flags, int ctrl_kind, const double *ctrl_vec, int Ku,
-                                    const double *end_tau, double max_step, double *y_out, int32_t *status,
-                                    int32_t *nsteps)
+extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                                        const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
+                                        int Ku, const double *end_tau, double max_step, double *y_out,
+                                        int32_t *status, int32_t *nsteps, void *stream)
+{
+    return mpcx_propagate_batch_ragged_dev(ctx, S, n_eval, nullptr, y0, tf, consts, flags, ctrl_kind, ctrl_vec, Ku, nullptr, end_tau,
+                                           max_step, y_out, status, nsteps, stream);
+}
+
+extern "C" int mpcx_propagate_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                           const double *tf, const double *consts, int flags, int ctrl_kind,
+                                           const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                           double max_step, double *y_out, int32_t *status, int32_t *nsteps)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || n_eval < 1) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1");
@@ -362,12 +413,23 @@ extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const doub
     else if (ctrl_kind == MPCX_CTRL_SEQUENCE) nv = (size_t)S * 3 * Ku;
     double *dv = (nv && ctrl_vec) ? ar.upload(ctrl_vec, nv) : nullptr;
     double *de = (ctrl_kind == MPCX_CTRL_SEQUENCE && end_tau) ? ar.upload(end_tau, S) : nullptr;
+    int32_t *dne = n_evals ? ar.upload(n_evals, S) : nullptr, *dku = Kus ? ar.upload(Kus, S) : nullptr;
     double *dy = ar.alloc<double>((size_t)S * 7 * n_eval);
     int32_t *dst = ar.alloc<int32_t>(S), *dns = ar.alloc<int32_t>(S);
     if (ar.failed()) return ar.code();
-    int rc = mpcx_propagate_batch_dev(ctx, S, n_eval, dy0, dtf, dc, flags, ctrl_kind, dv, Ku, de, max_step, dy, dst,
-                                      dns, ctx->stream);
+    if (n_evals) MPCX_HIP(ctx, hipMemsetAsync(dy, 0, (size_t)S * 7 * n_eval * sizeof(double), ctx->stream));   // the unused columns
+    int rc = mpcx_propagate_batch_ragged_dev(ctx, S, n_eval, dne, dy0, dtf, dc, flags, ctrl_kind, dv, Ku, dku, de, max_step, dy,
+                                             dst, dns, ctx->stream);
     if (rc) return rc;
     ar.download(y_out, dy, (size_t)S * 7 * n_eval); ar.download(status, dst, S); ar.download(nsteps, dns, S);
     return ar.finish();
+}
+
+extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
+                                    const double *consts, int flags, int ctrl_kind, const double *ctrl_vec, int Ku,
+                                    const double *end_tau, double max_step, double *y_out, int32_t *status,
+                                    int32_t *nsteps)
+{
+    return mpcx_propagate_batch_ragged(ctx, S, n_eval, nullptr, y0, tf, consts, flags, ctrl_kind, ctrl_vec, Ku, nullptr, end_tau,
+                                       max_step, y_out, status, nsteps);
 }

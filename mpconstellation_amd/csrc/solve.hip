@@ -66,7 +66,8 @@ struct SolveOpts {
 };
 
 struct SolveArgs {
-    int S, K;
+    int S, K;                 // K: node count of every satellite, or (Ks given) the row length of the arrays
+    const int32_t *Ks;        // ragged batch: satellite s has Ks[s] <= K nodes in the first columns of its rows; nullptr: all K
     const double *stage, *xbar, *ubar, *tfbar, *consts, *r_des;
     SolveOpts o;
     double *X, *U, *NU, *tf_out, *kkt;
@@ -351,6 +352,7 @@ __device__ __forceinline__ void ustore(gf64 *ubase, int e, double v)
 
 struct Sat {
     int K, KP;
+    int ldk;                      // row length of xbar / ubar (= K unless the batch is ragged)
     cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
     gf64 *it, *dr, *nbs, *stT, *rbh;            // field-major [field][KP]: iterate, direction, Newton scalars, stage copy, r-hat
     gf64 *itg, *drg, *nb, *fac, *ch, *traj;     // globals; record-per-node arrays read by the recursion (one wave, one record)
@@ -382,7 +384,7 @@ struct Sat {
 __device__ __forceinline__ Sat uniform_view(const Sat &v)
 {
     Sat s = v;
-    s.K = __builtin_amdgcn_readfirstlane(v.K); s.KP = __builtin_amdgcn_readfirstlane(v.KP);
+    s.K = __builtin_amdgcn_readfirstlane(v.K); s.KP = __builtin_amdgcn_readfirstlane(v.KP); s.ldk = __builtin_amdgcn_readfirstlane(v.ldk);
     s.stage = wave_uniform(v.stage); s.xbar = wave_uniform(v.xbar); s.ubar = wave_uniform(v.ubar);
     s.it = wave_uniform(v.it); s.dr = wave_uniform(v.dr); s.nbs = wave_uniform(v.nbs); s.stT = wave_uniform(v.stT); s.rbh = wave_uniform(v.rbh);
     s.itg = wave_uniform(v.itg); s.drg = wave_uniform(v.drg); s.nb = wave_uniform(v.nb); s.fac = wave_uniform(v.fac);
@@ -468,9 +470,9 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
             if (has_prev && dyn) POST(srmin, zrmin, g_rmin);
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * K + k]);
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * s.ldk + k]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - s.ubar[(size_t)i * K + k]) + 2.0 * u[i] * zu;
+        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - s.ubar[(size_t)i * s.ldk + k]) + 2.0 * u[i] * zu;
         if (has_prev) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrmax;
@@ -673,9 +675,9 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         {
             double bs[6], xb[7], ub[3];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; xb[i] = s.xbar[(size_t)i * K + k]; }
+            for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; xb[i] = s.xbar[(size_t)i * s.ldk + k]; }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; ub[i] = s.ubar[(size_t)i * K + k]; }
+            for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; ub[i] = s.ubar[(size_t)i * s.ldk + k]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
             const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
@@ -2121,12 +2123,20 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     //  out-of-bounds satellite)
     int sat = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     if ((unsigned)sat >= (unsigned)a.S) sat = (int)blockIdx.x;
-    const int K = a.K;
+    const int Kmax = a.K;
+    const int K = a.Ks ? a.Ks[sat] : Kmax;        // (wave-uniform: one satellite per workgroup)
+    if (K < 3 || K > Kmax) {                      // ragged batch with a node count the solver cannot take
+        if (lane == 0) {
+            a.status[sat] = MPCX_ST_BADK; a.iters[sat] = 0; a.kkt[sat] = 0.0;
+            if (a.nreg) { a.nreg[2 * sat] = 0; a.nreg[2 * sat + 1] = -1; }
+        }
+        return;
+    }
     Sat s;
-    s.K = K;
-    s.stage = (cgf64 *)a.stage + (size_t)sat * (K - 1) * MPCX_STAGE_DOUBLES;
-    s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * K;
-    s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * K;
+    s.K = K; s.ldk = Kmax;
+    s.stage = (cgf64 *)a.stage + (size_t)sat * (Kmax - 1) * MPCX_STAGE_DOUBLES;
+    s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * Kmax;
+    s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
     const int KP = padded_nodes(K);
     s.KP = KP;
     gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
@@ -2154,11 +2164,11 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     // ---- problem constants (constraint terms) and the initial iterate ----
     if (lane == 0) {
         double xK[7];
-        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
+        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * Kmax + K - 1];
         build_terminal(xK, a.consts[(size_t)sat * MPCX_NCONST + MPCX_C_MU], a.r_des[sat], o, sd);
         sd.tfbar = a.tfbar[sat];
         double x0[3];
-        for (int i = 0; i < 3; ++i) x0[i] = s.xbar[(size_t)i * K];
+        for (int i = 0; i < 3; ++i) x0[i] = s.xbar[(size_t)i * Kmax];
         sd.infeas = structural_violation(x0, K, sd);
 #ifdef MPCX_PHASE_TIMING
         for (int i = 0; i < 16; ++i) sd.fpt[i] = 0;
@@ -2166,8 +2176,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     }
     __syncthreads();
     if (sd.infeas > 0.0) {      // empty constraint set: the reference trajectory goes back unchanged, no iteration is spent
-        for (int e = lane; e < 7 * K; e += 64) { a.X[(size_t)sat * 7 * K + e] = s.xbar[e]; a.NU[(size_t)sat * 7 * K + e] = 0.0; }
-        for (int e = lane; e < 3 * K; e += 64) a.U[(size_t)sat * 3 * K + e] = s.ubar[e];
+        for (int e = lane; e < 7 * Kmax; e += 64) { a.X[(size_t)sat * 7 * Kmax + e] = s.xbar[e]; a.NU[(size_t)sat * 7 * Kmax + e] = 0.0; }
+        for (int e = lane; e < 3 * Kmax; e += 64) a.U[(size_t)sat * 3 * Kmax + e] = s.ubar[e];
         if (lane == 0) {
             if (!sd.fixed_tf) a.tf_out[sat] = sd.tfbar; else a.tf_out[sat] = 0.0;      // (fixed tf: the slot returns g_s)
             a.status[sat] = MPCX_ST_INFEASIBLE; a.iters[sat] = 0; a.kkt[sat] = sd.infeas;
@@ -2195,8 +2205,8 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     }
     for (int k = lane; k < K; k += 64) {
         double x[7], u[3];
-        for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * K + k];
-        for (int i = 0; i < 3; ++i) u[i] = s.ubar[(size_t)i * K + k];
+        for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * s.ldk + k];
+        for (int i = 0; i < 3; ++i) u[i] = s.ubar[(size_t)i * s.ldk + k];
         const double rn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         const auto rb = s.rbn(k);
         for (int i = 0; i < 3; ++i) rb[i] = x[i] / rn;           // optimizer.py:129-130
@@ -2215,7 +2225,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     if (lane == 0) {
         for (int i = 0; i < GL_N; ++i) { s.itg[i] = 0.0; s.drg[i] = 0.0; }
         double xK[7];
-        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * K + K - 1];
+        for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * Kmax + K - 1];
         for (int j = 0; j < sd.nT; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * xK[i];
@@ -2322,7 +2332,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
 #if defined(MPCX_ITER_LOG) && defined(MPCX_LOG_IT)
                     // diagnostic build only: the border system of one chosen iteration into this satellite's NU block
                     if (iter == MPCX_LOG_IT && pass == 0 && lane == 0) {
-                        double *lg = a.NU + (size_t)sat * 7 * K; int n = 0;
+                        double *lg = a.NU + (size_t)sat * 7 * Kmax; int n = 0;
                         for (int j = 0; j < NBD; ++j) lg[n++] = sd.sol[j];
                         for (int j = 0; j < NTERM; ++j) lg[n++] = sd.tw[j];
                         for (int j = 0; j < NTERM; ++j) lg[n++] = sd.twin[j];
@@ -2353,7 +2363,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         if (have_dir && delta_w > 0.0) { dw_last = delta_w; if (n_reg++ == 0) first_reg = iter; }
         if (!have_dir) {
 #ifdef MPCX_ITER_LOG
-            if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = -1.0; lg[3] = delta_w; lg[4] = (double)fail_mask; }
+            if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * Kmax + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = -1.0; lg[3] = delta_w; lg[4] = (double)fail_mask; }
 #endif
             status = MPCX_ST_NUMERIC; break;
         }
@@ -2374,7 +2384,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
 #ifdef MPCX_ITER_LOG
             // diagnostic build only: the first trial's margins into this satellite's U block
-            if (ls == 0 && lane == 0 && 3 * iter + 2 < 3 * K) { double *lg = a.U + (size_t)sat * 3 * K + 3 * iter; lg[0] = alpha; lg[1] = sqrt(rt.sq) / rn0; lg[2] = rt.prod_min / (kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc)); }
+            if (ls == 0 && lane == 0 && 3 * iter + 2 < 3 * K) { double *lg = a.U + (size_t)sat * 3 * Kmax + 3 * iter; lg[0] = alpha; lg[1] = sqrt(rt.sq) / rn0; lg[2] = rt.prod_min / (kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc)); }
 #endif
             if (dec && cen) { have_trial = true; break; }
             alpha *= 0.5;
@@ -2386,7 +2396,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         }
 #ifdef MPCX_ITER_LOG
         // diagnostic build only: iteration log (mu, E0, accepted step, regularisation) into this satellite's X block
-        if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * K + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
+        if (lane == 0 && 5 * iter + 4 < 7 * K) { double *lg = a.X + (size_t)sat * 7 * Kmax + 5 * iter; lg[0] = mu; lg[1] = E0; lg[2] = alpha; lg[3] = delta_w; lg[4] = (double)fail_mask; }
 #endif
         n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
@@ -2400,15 +2410,19 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         const auto p = s.itn(k);
         for (int i = 0; i < 7; ++i) {
 #ifndef MPCX_ITER_LOG
-            a.X[(size_t)sat * 7 * K + (size_t)i * K + k] = p[I_X + i];
+            a.X[(size_t)sat * 7 * Kmax + (size_t)i * Kmax + k] = p[I_X + i];
 #endif
 #if !(defined(MPCX_ITER_LOG) && defined(MPCX_LOG_IT))
-            a.NU[(size_t)sat * 7 * K + (size_t)i * K + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
+            a.NU[(size_t)sat * 7 * Kmax + (size_t)i * Kmax + k] = (k <= K - 2) ? p[I_NU + i] : 0.0;
 #endif
         }
 #ifndef MPCX_ITER_LOG
-        for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * K + (size_t)i * K + k] = p[I_U + i];
+        for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * Kmax + (size_t)i * Kmax + k] = p[I_U + i];
 #endif
+    }
+    for (int k = K + lane; k < Kmax; k += 64) {          // ragged batch: the unused columns of this satellite's rows
+        for (int i = 0; i < 7; ++i) { a.X[(size_t)sat * 7 * Kmax + (size_t)i * Kmax + k] = 0.0; a.NU[(size_t)sat * 7 * Kmax + (size_t)i * Kmax + k] = 0.0; }
+        for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * Kmax + (size_t)i * Kmax + k] = 0.0;
     }
     if (lane == 0) {
         a.tf_out[sat] = sd.fixed_tf ? r0.g_tf : s.itg[G_TF];
@@ -2418,7 +2432,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         if (a.nreg) { a.nreg[2 * sat] = n_reg; a.nreg[2 * sat + 1] = first_reg; }
 #ifdef MPCX_PHASE_TIMING
         // diagnostic build only: cycle sums per phase into the NU block of this satellite (never shipped)
-        double *dbg = a.NU + (size_t)sat * 7 * K;
+        double *dbg = a.NU + (size_t)sat * 7 * Kmax;
         for (int i = 0; i < 12; ++i) { dbg[2 * i] = (double)pt_[i]; dbg[2 * i + 1] = (double)pc_[i]; }
         for (int i = 0; i < 16; ++i) dbg[24 + i] = (double)sd.fpt[i];
 #endif
@@ -2531,18 +2545,18 @@ extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
     return (size_t)S * ws_doubles(K) * sizeof(double);
 }
 
-extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *stage, const double *xbar,
-                                    const double *ubar, const double *tf, const double *consts,
-                                    const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
-                                    double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
-                                    void *workspace, void *stream)
+extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *stage, const double *xbar,
+                                           const double *ubar, const double *tf, const double *consts,
+                                           const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
+                                           double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                           void *workspace, void *stream)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "solve: need S>=1, K>=3 and options");
     if (!workspace) return ctx_fail(ctx, MPCX_E_BADARG, "solve: workspace of mpcx_solve_workspace_bytes(S,K) required");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
     SolveArgs a;
-    a.S = S; a.K = K; a.stage = stage; a.xbar = xbar; a.ubar = ubar; a.tfbar = tf; a.consts = consts; a.r_des = r_des;
+    a.S = S; a.K = K; a.Ks = Ks; a.stage = stage; a.xbar = xbar; a.ubar = ubar; a.tfbar = tf; a.consts = consts; a.r_des = r_des;
     a.o = to_dev_opts(opts);
     a.X = X; a.U = U; a.NU = NU; a.tf_out = tf_out; a.kkt = kkt; a.status = status; a.iters = iters;
     a.ws = (double *)workspace; a.ws_stride = ws_doubles(K);
@@ -2584,11 +2598,21 @@ extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *s
     return MPCX_OK;
 }
 
-extern "C" int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
-                                       const double *tf, const double *consts, const double *r_des, int flags,
-                                       double max_step, const mpcx_solve_opts *opts, double *X, double *U,
-                                       double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
-                                       void *workspace, void *stream)
+extern "C" int mpcx_solve_batch_dev(mpcx_ctx *ctx, int S, int K, const double *stage, const double *xbar,
+                                    const double *ubar, const double *tf, const double *consts,
+                                    const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
+                                    double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                    void *workspace, void *stream)
+{
+    return mpcx_solve_batch_ragged_dev(ctx, S, K, nullptr, stage, xbar, ubar, tf, consts, r_des, opts, X, U, NU, tf_out, status,
+                                       iters, kkt, workspace, stream);
+}
+
+extern "C" int mpcx_mpc_step_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *xbar, const double *ubar,
+                                              const double *tf, const double *consts, const double *r_des, int flags,
+                                              double max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                                              double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                              void *workspace, void *stream)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (!workspace) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_step: workspace of mpcx_mpc_step_workspace_bytes(S,K) required");
@@ -2597,14 +2621,25 @@ extern "C" int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double
     const size_t nstage = (size_t)S * (K - 1) * MPCX_STAGE_DOUBLES;
     int32_t *dstat = (int32_t *)(stage + nstage);
     double *sws = stage + nstage + ((size_t)S + 1) / 2 + 1;
-    int rc = mpcx_discretize_stages_dev(ctx, S, K, K, xbar, ubar, tf, consts, flags, max_step, stage, dstat, stream);
+    // (a ragged batch's thrust tables have as many columns as the satellite has nodes)
+    int rc = mpcx_discretize_stages_ragged_dev(ctx, S, K, Ks, K, Ks, xbar, ubar, tf, consts, flags, max_step, stage, dstat, stream);
     if (rc) return rc;
-    rc = mpcx_solve_batch_dev(ctx, S, K, stage, xbar, ubar, tf, consts, r_des, opts, X, U, NU, tf_out, status, iters,
-                              kkt, sws, stream);
+    rc = mpcx_solve_batch_ragged_dev(ctx, S, K, Ks, stage, xbar, ubar, tf, consts, r_des, opts, X, U, NU, tf_out, status, iters,
+                                     kkt, sws, stream);
     if (rc) return rc;
     merge_status_kernel_launch(S, dstat, status, (hipStream_t)stream);
     MPCX_HIP(ctx, hipGetLastError());
     return MPCX_OK;
+}
+
+extern "C" int mpcx_mpc_step_batch_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                                       const double *tf, const double *consts, const double *r_des, int flags,
+                                       double max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                                       double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                       void *workspace, void *stream)
+{
+    return mpcx_mpc_step_batch_ragged_dev(ctx, S, K, nullptr, xbar, ubar, tf, consts, r_des, flags, max_step, opts, X, U, NU,
+                                          tf_out, status, iters, kkt, workspace, stream);
 }
 
 extern "C" size_t mpcx_mpc_step_workspace_bytes(int S, int K)
@@ -2613,10 +2648,10 @@ extern "C" size_t mpcx_mpc_step_workspace_bytes(int S, int K)
            mpcx_solve_workspace_bytes(S, K);
 }
 
-extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
-                                   const double *tf, const double *consts, const double *r_des, int flags,
-                                   double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
-                                   double *tf_out, int32_t *status, int32_t *iters, double *kkt)
+extern "C" int mpcx_mpc_step_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *xbar, const double *ubar,
+                                          const double *tf, const double *consts, const double *r_des, int flags,
+                                          double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
+                                          double *tf_out, int32_t *status, int32_t *iters, double *kkt)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_step: need S>=1, K>=3 and options");
@@ -2626,17 +2661,27 @@ extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xb
     DeviceArena ar(ctx);
     double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
     double *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    int32_t *dKs = Ks ? ar.upload(Ks, S) : nullptr;
     double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K);
     const bool fixed_tf = (opts->flags & MPCX_SOLVE_FIXED_TF) != 0;          // tf_out is an input too (include/mpcx.h)
     double *dNU = ar.alloc<double>((size_t)S * 7 * K), *dtfo = fixed_tf ? ar.upload(tf_out, S) : ar.alloc<double>(S), *dk = ar.alloc<double>(S);
     int32_t *dst = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S);
     if (ar.failed()) return ar.code();
-    int rc = mpcx_mpc_step_batch_dev(ctx, S, K, dx, du, dtf, dc, drd, flags, max_step, opts, dX, dU, dNU, dtfo, dst,
-                                     dit, dk, ws, ctx->stream);
+    int rc = mpcx_mpc_step_batch_ragged_dev(ctx, S, K, dKs, dx, du, dtf, dc, drd, flags, max_step, opts, dX, dU, dNU, dtfo, dst,
+                                            dit, dk, ws, ctx->stream);
     if (rc) return rc;
     ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
     ar.download(tf_out, dtfo, S); ar.download(status, dst, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
     return ar.finish();
+}
+
+extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *ubar,
+                                   const double *tf, const double *consts, const double *r_des, int flags,
+                                   double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
+                                   double *tf_out, int32_t *status, int32_t *iters, double *kkt)
+{
+    return mpcx_mpc_step_batch_ragged(ctx, S, K, nullptr, xbar, ubar, tf, consts, r_des, flags, max_step, opts, X, U, NU, tf_out,
+                                      status, iters, kkt);
 }
 
 extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,

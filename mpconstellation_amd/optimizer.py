@@ -82,9 +82,12 @@ def _tf_io(S, fixed_tf):
 
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, **solver):
+                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
+    Ks (S,) int: a ragged batch -- satellite s has Ks[s] <= K nodes in the first columns of its rows (what the reference's
+    second SCP iteration poses: int(base_res * tf_u) nodes per satellite, control.py:227); result columns past a
+    satellite's count are zero.
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
     returns the results in page-locked buffers that the next call of the same shape overwrites."""
     solver = _solver_flags(solver, linear_vt, fixed_tf)
@@ -103,10 +106,17 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     dflags = _ffi.FLAG_J2 if include_J2 else 0
     if uniform_steps:                         # Discretizer.use_uniform_steps with integrator_steps = uniform_steps
         dflags |= _ffi.FLAG_UNIFORM_STEPS | (int(uniform_steps) << 8)
-    rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
-                                 _ffi.dptr(r_des), dflags, float(max_step), C.byref(opts),
-                                 _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
-                                 _ffi.iptr(iters), _ffi.dptr(kkt))
+    if Ks is None:
+        rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
+                                     _ffi.dptr(r_des), dflags, float(max_step), C.byref(opts),
+                                     _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
+                                     _ffi.iptr(iters), _ffi.dptr(kkt))
+    else:
+        Ks = np.ascontiguousarray(np.broadcast_to(np.asarray(Ks), (S,)), dtype=np.int32)
+        rc = lib.mpcx_mpc_step_batch_ragged(ctx, S, K, _ffi.iptr(Ks), _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf),
+                                            _ffi.dptr(consts), _ffi.dptr(r_des), dflags, float(max_step), C.byref(opts),
+                                            _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
+                                            _ffi.iptr(iters), _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
     reg = _regularised(lib, ctx, S) if regularised else None
     return SolveResult(X, U, NU, tfo, status, iters, kkt, regularised=reg) if held is None else \

@@ -146,28 +146,35 @@ def test_rejected_arguments(golden_dir):
 
 def test_config3_full_size_scp_loop():
     """BASELINE configs[3] at full size through the bench harness's device-resident path: 4096 satellites, K = 100,
-    two SCP iterations with the nonlinear re-rollout under the optimised sequence between them (control.py:166,183-227;
-    the benchmark re-samples the rollout at K nodes, bench.py).  Properties over all satellites after the second
-    iteration, and three satellites against the same chain built from the CPU oracle."""
+    two SCP iterations with the nonlinear re-rollout under the optimised sequence between them, re-sampled as the
+    reference does at int(base_res * tf_u) nodes per satellite (control.py:166,183-227, simulator.py:38) -- the second
+    iteration is one ragged launch.  Properties over all satellites after the second iteration, and three satellites
+    against the same chain built from the CPU oracle."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import torch
     import bench
-    run = bench.Runner("S4096_K100_scp2", 0, 1, 0)
+    run = bench.Runner("S4096_K100_scp2", 0, 1, 0, n_variants=1)
     run.step()
     torch.cuda.synchronize()
     status, iters, kkt = run.solver_stats()
     S, K = run.S, run.K
     assert (status == 0).all() and kkt.max() <= 1e-8 and iters.max() <= 40
     X = run.d_X.cpu().numpy(); U = run.d_U.cpu().numpy(); NU = run.d_NU.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
-    assert (run.d_pst.cpu().numpy() == 0).all()                                              # the re-rollouts succeeded
+    Kn = run.d_Kn.cpu().numpy()
+    assert (run.d_pst.cpu().numpy() == 0).all() and (run.d_rst.cpu().numpy() == 0).all()    # re-rollout and resampling succeeded
+    assert Kn.min() >= 80 and Kn.max() <= 99 and len(np.unique(Kn)) > 3                       # a genuinely ragged batch
     h = run.host
     assert np.abs(X[:, :, 0] - h["xbar"][:, :, 0]).max() == 0.0
     assert np.linalg.norm(U, axis=1).max() <= 5 + 1e-6 and (np.abs(NU) <= 1e-6).all()
-    rn = np.linalg.norm(X[:, :3, :], axis=1)
-    assert np.abs(rn[:, -1] - h["r_des"]).max() <= 0.01 + 1e-6
+    last = Kn - 1
+    col = np.arange(K)[None, :]
+    assert not X[np.broadcast_to((col >= Kn[:, None])[:, None, :], X.shape)].any()            # columns past a satellite's nodes: zero
+    XK = X[np.arange(S), :, last]                                                             # (S,7): each satellite's terminal node
+    rK = np.linalg.norm(XK[:, :3], axis=1)
+    assert np.abs(rK - h["r_des"]).max() <= 0.01 + 1e-6
     assert (tfo > 0).all() and (tfo <= 5 + 1e-6).all()
-    hK = np.cross(X[:, :3, -1], X[:, 3:6, -1])
-    assert np.abs(np.linalg.norm(hK, axis=1) / rn[:, -1] - np.sqrt(h["consts"][:, 0] / h["r_des"])).max() < 1e-7
+    hK = np.cross(XK[:, :3], XK[:, 3:6])
+    assert np.abs(np.linalg.norm(hK, axis=1) / rK - np.sqrt(h["consts"][:, 0] / h["r_des"])).max() < 1e-7
     # the second iteration's reference is the rollout under the first one's plan: shorter flight time than the first guess
     assert (tfo < 1.0).all()
     for s in (0, 1777, 4095):
@@ -180,8 +187,11 @@ def test_config3_full_size_scp_loop():
             assert r["status"] == 0
             if it == 0:
                 ctrl = O.make_ctrl(3, useq=np.ascontiguousarray(r["U"]), end_tau=1.0)
-                x = O.propagate(h["xbar"][s][:, 0], r["tf"], cst, ctrl, K)[0]; u = r["U"]; tf = r["tf"]
-        assert np.abs(X[s] - r["X"]).max() < 5e-6 and abs(tfo[s] - r["tf"]) < 5e-6
+                kn = int(K * r["tf"])                                  # base_res = K (tf_bar = 1): control.py:227, simulator.py:38
+                x = O.propagate(h["xbar"][s][:, 0], r["tf"], cst, ctrl, kn)[0]
+                u = O.extract_uk(x, np.linspace(0, 1, kn), ctrl); tf = r["tf"]
+        assert Kn[s] == kn
+        assert np.abs(X[s][:, :kn] - r["X"]).max() < 5e-6 and abs(tfo[s] - r["tf"]) < 5e-6
 
 
 def test_config4_every_rank_block():

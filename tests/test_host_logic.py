@@ -220,3 +220,21 @@ def test_shared_tf_root_reports_a_missing_bracket():
     calls = []
     t, ev = shared_tf_root(lambda t: (calls.append(t), 1.0)[1], 5.0, 1.0, max_bracket=6)
     assert not ev.converged and len(calls) == len(ev) <= 8
+
+
+def test_ragged_foh_resampling_matches_the_scalar_reference_formula():
+    """ConstellationMPC's extract_uk for a whole ragged batch (foh_resample_ragged) against SequenceController.u_FOH
+    (control.py:104-126, Python float floor division), satellite by satellite, bit for bit."""
+    from mpconstellation_amd.constellation_mpc import foh_resample_ragged, foh_resample
+    from mpconstellation_amd.control import SequenceController
+    rng = np.random.default_rng(0)
+    S, Kmax = 40, 37
+    Ku = rng.integers(2, Kmax + 1, S); n = rng.integers(1, 60, S)
+    u = rng.standard_normal((S, 3, Kmax))
+    out = foh_resample_ragged(u, Ku, n)
+    assert out.shape == (S, 3, n.max())
+    for s in range(S):
+        f = SequenceController(u=u[s][:, :Ku[s]], tf_u=1.3, tf_sim=1.3).get_u_func()
+        ref = np.column_stack([f(None, tq) for tq in np.linspace(0, 1, n[s])])
+        assert np.array_equal(ref, out[s][:, :n[s]]) and not out[s][:, n[s]:].any()
+    assert np.array_equal(foh_resample(u, 29), foh_resample_ragged(u, np.full(S, Kmax), np.full(S, 29)))

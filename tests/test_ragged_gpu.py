@@ -1,0 +1,115 @@
+"""Ragged batches (include/mpcx.h, mpcx_*_ragged): satellites with different node counts in one launch -- what the
+reference's second SCP iteration poses for a constellation (control.py:227: the re-rollout of satellite s is sampled at
+int(base_res * tf_u[s]) nodes, simulator.py:38).  Every satellite of a ragged launch must get, bit for bit, what it
+gets when it is solved / propagated alone with its own rectangular arrays."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["tan_K20_tf2", "tan_K30_tf1", "tan_K60_tf2", "const_K30_tf1", "zero_K20_tf1"]
+
+
+def padded(golden_dir):
+    ds = [np.load(os.path.join(golden_dir, f"disc_{n}.npz")) for n in CASES]
+    Ks = np.array([d["x"].shape[1] for d in ds], dtype=np.int32)
+    Kmax = int(Ks.max()); S = len(ds)
+    x = np.zeros((S, 7, Kmax)); u = np.zeros((S, 3, Kmax))
+    for s, d in enumerate(ds):
+        x[s, :, :Ks[s]] = d["x"]; u[s, :, :Ks[s]] = d["u"]
+    tf = np.array([float(d["tf"]) for d in ds]); cst = np.stack([d["const"] for d in ds])
+    r_des = np.array([np.linalg.norm(d["x"][:3, -1]) for d in ds])
+    return ds, Ks, x, u, tf, cst, r_des
+
+
+def test_ragged_fused_step_equals_rectangular_solves(golden_dir):
+    from mpconstellation_amd import mpc_step_batch
+    ds, Ks, x, u, tf, cst, r_des = padded(golden_dir)
+    res = mpc_step_batch(x, u, tf, cst, r_des, Ks=Ks, regularised=True)
+    assert (res.status == 0).all()
+    for s, d in enumerate(ds):
+        k = Ks[s]
+        one = mpc_step_batch(d["x"][None], d["u"][None], [tf[s]], cst[s:s + 1], [r_des[s]], regularised=True)
+        assert one.status[0] == 0 and one.iters[0] == res.iters[s] and one.n_regularised[0] == res.n_regularised[s]
+        assert np.array_equal(res.X[s][:, :k], one.X[0]) and np.array_equal(res.U[s][:, :k], one.U[0])
+        assert np.array_equal(res.NU[s][:, :k], one.NU[0]) and res.tf[s] == one.tf[0] and res.kkt[s] == one.kkt[0]
+        assert not res.X[s][:, k:].any() and not res.U[s][:, k:].any() and not res.NU[s][:, k:].any()
+    # the order of the satellites in the ragged batch does not matter either
+    perm = np.array([3, 0, 4, 2, 1])
+    shuf = mpc_step_batch(x[perm], u[perm], tf[perm], cst[perm], r_des[perm], Ks=Ks[perm])
+    assert np.array_equal(shuf.X, res.X[perm]) and np.array_equal(shuf.tf, res.tf[perm])
+
+
+def test_ragged_node_counts_out_of_range(golden_dir):
+    """a satellite whose count the solver cannot take (< 3 or > K) reports MPCX_ST_BADK; its neighbours are solved"""
+    from mpconstellation_amd import mpc_step_batch
+    ds, Ks, x, u, tf, cst, r_des = padded(golden_dir)
+    ref = mpc_step_batch(x, u, tf, cst, r_des, Ks=Ks)
+    for bad in (2, 0, -5, int(Ks.max()) + 1):
+        k2 = Ks.copy(); k2[1] = bad
+        res = mpc_step_batch(x, u, tf, cst, r_des, Ks=k2)
+        assert res.status[1] == 9 and (np.delete(res.status, 1) == 0).all()
+        assert np.array_equal(np.delete(res.X, 1, axis=0), np.delete(ref.X, 1, axis=0))
+
+
+def test_ragged_propagation_equals_rectangular_calls(golden_dir):
+    """Simulator.get_trajectory_ODE sampled at a different number of points per satellite, with thrust tables of
+    different lengths (the playback of ragged plans), against one call per satellite."""
+    from mpconstellation_amd import _ffi
+    from mpconstellation_amd.simulator import propagate_batch
+    ds, Ks, x, u, tf, cst, r_des = padded(golden_dir)
+    S = len(ds)
+    y0 = x[:, :, 0].copy()
+    n_eval = np.array([17, 40, 1, 33, 25], dtype=np.int32)
+    end_tau = np.array([1.0, 0.8, 1.0, 0.5, 1.0])
+    y, st, ns = propagate_batch(y0, tf, cst, (_ffi.CTRL_SEQUENCE, u, u.shape[2], end_tau), n_eval, True, True, 1e-3, Kus=Ks)
+    assert (st == 0).all() and y.shape == (S, 7, 40)
+    for s in range(S):
+        k = Ks[s]
+        y1, st1, ns1 = propagate_batch(y0[s:s + 1], tf[s:s + 1], cst[s:s + 1], (_ffi.CTRL_SEQUENCE, u[s:s + 1, :, :k].copy(), int(k), end_tau[s:s + 1]),
+                                       int(n_eval[s]), True, True, 1e-3)
+        assert st1[0] == 0 and ns1[0] == ns[s]
+        assert np.array_equal(y[s][:, :n_eval[s]], y1[0]) and not y[s][:, n_eval[s]:].any()
+    # tangential law, ragged sampling only
+    y, st, _ = propagate_batch(y0, tf, cst, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), n_eval)
+    for s in range(S):
+        y1, _, _ = propagate_batch(y0[s:s + 1], tf[s:s + 1], cst[s:s + 1], (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), int(n_eval[s]))
+        assert np.array_equal(y[s][:, :n_eval[s]], y1[0])
+    bad = n_eval.copy(); bad[2] = 0
+    _, st, _ = propagate_batch(y0, tf, cst, (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), bad)
+    assert st[2] == 9 and (np.delete(st, 2) == 0).all()
+
+
+def test_resample_sequence_on_device_equals_extract_uk(golden_dir):
+    """mpcx_resample_sequence_dev = Discretizer.extract_uk of SequenceController(u, tf_u, tf_sim = tf_u) at
+    linspace(0, 1, n_s) (linearize_discretize.py:393-411, control.py:104-131), for ragged tables and node counts, against
+    the host evaluation of the reference's formula (mpconstellation_amd.control.SequenceController)."""
+    import torch
+    from mpconstellation_amd import _ffi
+    from mpconstellation_amd.control import SequenceController
+    rng = np.random.default_rng(3)
+    S, Ku, n = 37, 41, 64
+    Kus = rng.integers(2, Ku + 1, S).astype(np.int32); ns = rng.integers(1, n + 1, S).astype(np.int32)
+    u = rng.standard_normal((S, 3, Ku))
+    dev = torch.device("cuda", 0)
+    d_u = torch.tensor(u, dtype=torch.float64, device=dev); d_out = torch.empty((S, 3, n), dtype=torch.float64, device=dev)
+    d_k = torch.tensor(Kus, device=dev); d_n = torch.tensor(ns, device=dev); d_st = torch.empty(S, dtype=torch.int32, device=dev)
+    lib, ctx = _ffi.load(), _ffi.context(0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _ffi.check(lib.mpcx_resample_sequence_dev(ctx, S, Ku, p(d_k), p(d_u), n, p(d_n), p(d_out), p(d_st), st), ctx, "resample")
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert (d_st.cpu().numpy() == 0).all()
+    for s in range(S):
+        f = SequenceController(u=u[s][:, :Kus[s]], tf_u=0.93, tf_sim=0.93).get_u_func()
+        ref = np.column_stack([f(None, tq) for tq in np.linspace(0, 1, ns[s])])
+        assert np.abs(out[s][:, :ns[s]] - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max()) and not out[s][:, ns[s]:].any()
+    # rectangular call (NULL counts)
+    _ffi.check(lib.mpcx_resample_sequence_dev(ctx, S, Ku, None, p(d_u), n, None, p(d_out), p(d_st), st), ctx, "resample")
+    torch.cuda.synchronize()
+    f = SequenceController(u=u[5], tf_u=1, tf_sim=1).get_u_func()
+    assert np.abs(d_out.cpu().numpy()[5] - np.column_stack([f(None, tq) for tq in np.linspace(0, 1, n)])).max() <= 1e-15 * np.abs(u[5]).max()
