@@ -104,9 +104,14 @@ class ConstellationMPC:
         self.include_drag, self.include_J2 = include_drag, include_J2
         self.device = device
         self.strict = strict                  # raise instead of warning when a solve does not converge (control.py mirror)
-        self.sim_data, self.sim_time = {}, {}
+        # per-satellite unit factors as vectors: the whole constellation is (re)dimensionalised in one array expression
+        # (satellite_scale.py:46-100: r / r0, v / v0, m / m0 and back)
+        self._f = np.array([[sc._r0, sc._v0, sc._m0] for sc in self.scales]).reshape(len(self.sats), 3)
+        self._seg_y, self._seg_t, self._sim_cache = [], [], None       # flown segments (S,7,n) / (n,), and the dict view of them
         self.last_status = None
-        self.plan_u, self.plan_tf, self.plan_x, self.plan_nu, self.plan_K = None, None, None, None, None
+        self.plan_tf, self.plan_K = None, None
+        self._plan = None                                               # (X, U, NU) of the last plan, rows of length Kmax
+        self._plan_lists = None
         # wall-clock seconds spent inside the batched device calls (host staging included), accumulated over the updates
         self.timing = {"rollouts": 0.0, "discretize_solve": 0.0, "truth_propagation": 0.0}
 
@@ -117,12 +122,55 @@ class ConstellationMPC:
         return out
 
     def _y0(self):
-        return np.stack([sc.normalize_state(s.get_state_vector()) for sc, s in zip(self.scales, self.sats)])
+        """normalised states of all satellites (SatelliteScale.normalize_state of each, in one expression)"""
+        pos = np.array([s.position for s in self.sats], dtype=np.float64).reshape(-1, 3)
+        vel = np.array([s.velocity for s in self.sats], dtype=np.float64).reshape(-1, 3)
+        m = np.array([s.mass for s in self.sats], dtype=np.float64)
+        f = self._f
+        return np.column_stack([pos / f[:, 0:1], vel / f[:, 1:2], m / f[:, 2]])
+
+    # the reference keeps sim_data / sim_time as dicts id -> array (simulator.py:18-19); built on demand from the batched
+    # segments (one concatenation for the constellation instead of one per satellite and segment)
+    def _sim_dicts(self):
+        if self._sim_cache is None:
+            if not self._seg_y:
+                self._sim_cache = ({}, {})
+            else:
+                Y = np.concatenate(self._seg_y, axis=2); T = np.concatenate(self._seg_t)
+                self._sim_cache = ({sat.id: Y[i] for i, sat in enumerate(self.sats)}, {sat.id: T for sat in self.sats})
+        return self._sim_cache
+
+    @property
+    def sim_data(self):
+        return self._sim_dicts()[0]
+
+    @property
+    def sim_time(self):
+        return self._sim_dicts()[1]
+
+    # the plan per satellite, trimmed to its own node count: lists of views, built on demand
+    def _plan_views(self):
+        if self._plan_lists is None and self._plan is not None:
+            Kp = self.plan_K
+            self._plan_lists = tuple([a[s][:, :Kp[s]] for s in range(len(self.sats))] for a in self._plan)
+        return self._plan_lists or (None, None, None)
+
+    @property
+    def plan_x(self):
+        return self._plan_views()[0]
+
+    @property
+    def plan_u(self):
+        return self._plan_views()[1]
+
+    @property
+    def plan_nu(self):
+        return self._plan_views()[2]
 
     # ---- OptimalController.update for every satellite ----
-    def update(self):
+    def update(self, y0=None):
         S = len(self.sats)
-        y0 = self._y0()
+        y0 = self._y0() if y0 is None else y0
         K = int(self.base_res * self.horizon)
         x, st, _ = self._timed("rollouts", propagate_batch, y0, self.horizon, self.consts,
                                (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, False, False, 0.001, self.device)
@@ -157,33 +205,31 @@ class ConstellationMPC:
             Ks = Kn
         Kp = np.full(S, res.X.shape[2]) if Ks is None else Ks
         self.plan_K = Kp.astype(np.int32)
-        self._plan_U = res.U                                               # (S,3,Kmax): the table the segment is flown with
-        self.plan_u = [res.U[s][:, :Kp[s]] for s in range(S)]
-        self.plan_x = [res.X[s][:, :Kp[s]] for s in range(S)]
-        self.plan_nu = [res.NU[s][:, :Kp[s]] for s in range(S)]
+        self._plan = (res.X, res.U, res.NU)                                # rows of length Kmax; U is the table the segment is flown with
+        self._plan_lists = None
         self.plan_tf = tf_u.copy()
         if self.horizon - self.interval > 0.1:                               # control.py:234-235
             self.horizon -= self.interval
 
     # ---- Simulator.run_segment for every satellite: plan, fly tf under the truth model, update the states ----
     def run_segment(self, tf=1):
-        self.update()
-        n_eval = int(self.sim_base_res * tf)
         y0 = self._y0()
+        self.update(y0)
+        n_eval = int(self.sim_base_res * tf)
+        U = self._plan[1]
         # SequenceController(tf_u, tf_sim = interval): end_tau = tf_u / interval; one launch, tables of plan_K[s] columns
         y, st, _ = self._timed("truth_propagation", propagate_batch, y0, tf, self.consts,
-                               (_ffi.CTRL_SEQUENCE, self._plan_U, self._plan_U.shape[2], self.plan_tf / self.interval), n_eval,
+                               (_ffi.CTRL_SEQUENCE, U, U.shape[2], self.plan_tf / self.interval), n_eval,
                                self.include_drag, self.include_J2, 0.001, self.device, Kus=self.plan_K)
         self._check(st)
         t = np.linspace(0, 1, n_eval)
-        for i, (sat, sc) in enumerate(zip(self.sats, self.scales)):
-            sat.update_state_vector(sc.redim_state(y[i][:, -1]))
-            if sat.id in self.sim_data:
-                time = t + self.sim_time[sat.id][-1] * tf + 0.0000001       # simulator.py:69-76
-                self.sim_data[sat.id] = np.concatenate([self.sim_data[sat.id], y[i]], axis=1)
-                self.sim_time[sat.id] = np.concatenate([self.sim_time[sat.id], time])
-            else:
-                self.sim_data[sat.id] = y[i]; self.sim_time[sat.id] = t.copy()
+        f = self._f
+        end = np.column_stack([y[:, 0:3, -1] * f[:, 0:1], y[:, 3:6, -1] * f[:, 1:2], y[:, 6, -1] * f[:, 2]])     # redim_state
+        for i, sat in enumerate(self.sats):
+            sat.update_state_vector(end[i])
+        if self._seg_t:
+            t = t + self._seg_t[-1][-1] * tf + 0.0000001                  # simulator.py:69-76
+        self._seg_y.append(y); self._seg_t.append(t); self._sim_cache = None
 
     def run_segments(self, tf=1, num_segments=1):
         for _ in range(num_segments):
