@@ -37,6 +37,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->prev_iters = nullptr; c->order = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
     c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
     c->copier = nullptr;
+    c->counter = nullptr; c->n_slots = prop.multiProcessorCount * 8;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -57,6 +58,7 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
     if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->nreg) (void)hipFree(ctx->nreg);
+    if (ctx->counter) (void)hipFree(ctx->counter);
     pool_free(ctx->pool_dev); pool_free(ctx->pool_host);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     delete ctx->copier;

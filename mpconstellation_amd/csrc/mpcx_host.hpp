@@ -127,6 +127,8 @@ struct mpcx_ctx {
     // regularisation counts of the last solve ([S][2] int32, include/mpcx.h: mpcx_solve_regularised)
     int32_t *nreg;
     int nreg_cap, nreg_S;
+    int32_t *counter;         // work-queue counter of the solver's persistent workgroups
+    int n_slots;              // single-wave workgroups of solve_kernel the device holds at once (compute units x 8)
     StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
     HostCopier *copier;                // worker threads of the pageable <-> page-locked copies (created on first use)
     std::vector<hipEvent_t> events;    // one per download of a host-pointer call: its copy-out starts when ITS transfer is done

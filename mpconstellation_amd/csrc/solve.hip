@@ -52,7 +52,10 @@ enum { F_A = 256, F_BPM = 320, F_D = 341, FLAT_N = 384 };
 // channel vectors per node: 8 channels x (p 7, qu 3) then the rhs record (gx 7, gu 3, rho 7, aff 7)
 enum { C_P = 0, C_QU = 56, C_RHS = 80, R_GX = 0, R_GU = 7, R_RHO = 10, R_AFF = 17, RHS_N = 24, CH_N = 104 };
 // stored trajectory of one channel at one node
-enum { T_X = 0, T_U = 7, T_NU = 10, T_LAM = 17, TR_N = 24 };
+// (the multiplier part of a channel's trajectory is not stored: lam_k = D_k nu_k + rho_k -- sweep_forward -- is linear in
+//  nu, so combine_channels forms it from the combined nu, D_k of the Newton record and the right-hand side's rho_k)
+enum { T_X = 0, T_U = 7, T_NU = 10, TR_N = 17, T_LAM = TR_N, DIR_N = 24 };
+constexpr int RHS_LD = RHS_N + 1, CMB_LD = 33;   // LDS strides of newton_blocks' rhs staging and combine_channels' transposition (bank-conflict free)
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
@@ -73,6 +76,7 @@ struct SolveArgs {
     double *X, *U, *NU, *tf_out, *kkt;
     int32_t *status, *iters;
     const int32_t *order;     // workgroup b solves satellite order[b]; nullptr = index order
+    int32_t *counter;         // work queue of the persistent workgroups: next position of the launch order (zeroed per launch)
     int32_t *nreg;            // [S][2]: iterations whose direction needed delta_w > 0, and the first of them (-1: none)
     double *ws;
     size_t ws_stride;
@@ -395,6 +399,34 @@ __device__ __forceinline__ Sat uniform_view(const Sat &v)
     return s;
 }
 
+// Directions of the eliminated slack / multiplier pairs by back-substitution from the direction of the primal variables
+// ("Linear solve").  They are not stored: finish_direction needs them once for the fraction-to-the-boundary
+// step, every trial evaluation of the line search recomputes them from the iterate it reads anyway -- 41 field-major
+// arrays less to write and to read back per iteration, against a handful of reciprocals per node.
+// One inequality g + s = 0 with slack s, multiplier z: ds = -(g + s) - dg, dz = mu / s + (z / s) (g + s + dg) - z.
+struct PairDir { double ds, dz; };
+__device__ __forceinline__ PairDir pair_dir(double sv, double zv, double g, double dg, double mu)
+{
+    const double is = rcp_pos(sv), sig = zv * is, zh = mu * is + sig * (g + sv);
+    return PairDir{-(g + sv) - dg, zh + sig * dg - zv};
+}
+// One component of the L1 pair nu - t <= 0, -nu - t <= 0 (t eliminated: optimizer.py:579-585): dt and the two pairs
+struct L1Dir { double dt, dstp, dztp, dstn, dztn; };
+__device__ __forceinline__ L1Dir l1_dir(double nu, double tt, double stp, double ztp, double stn, double ztn, double dnu, double mu, double w_nu)
+{
+    const double g1 = nu - tt, g2 = -nu - tt;
+    const double ip = rcp_pos(stp), in = rcp_pos(stn);
+    const double s1 = ztp * ip, s2 = ztn * in;
+    const double zh1 = mu * ip + s1 * (g1 + stp), zh2 = mu * in + s2 * (g2 + stn);
+    const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
+    L1Dir o;
+    o.dt = (-gt - bb * dnu) * rcp_pos(aa);
+    const double dg1 = dnu - o.dt, dg2 = -dnu - o.dt;
+    o.dstp = -(g1 + stp) - dg1; o.dztp = zh1 + s1 * dg1 - ztp;
+    o.dstn = -(g2 + stn) - dg2; o.dztn = zh2 + s2 * dg2 - ztn;
+    return o;
+}
+
 // iterate + a * direction for one field, branch-free: both loads always issue (so they can all be in flight
 // together); at a == 0 the direction value, which may be stale, is replaced by 0.
 __device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64> &d, int off, double a, bool z)
@@ -450,17 +482,36 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
         const bool has_prev = (k >= 1), dyn = (k <= K - 2);
         // ---- chunk 0 (both halves, accounted by half 0): states, thrust, ball slacks, objective gradient ----
         double x[7], u[3], gx[7], gu[3], un[3];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) x[i] = TRIAL(p, d, I_X + i);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = TRIAL(p, d, I_U + i);
-        double su = TRIAL(p, d, I_SU), zu = TRIAL(p, d, I_ZU), srmax = TRIAL(p, d, I_SRMAX), zrmax = TRIAL(p, d, I_ZRMAX);
-        double srmin = TRIAL(p, d, I_SRMIN), zrmin = TRIAL(p, d, I_ZRMIN);
+        double su, zu, srmax, zrmax, srmin, zrmin;
         const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
         const auto rb = s.rbn(k);
         const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+        {
+            double x0[7], dx[7], u0[3], du[3], bs[6];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { x0[i] = p[I_X + i]; dx[i] = d[I_X + i]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { u0[i] = p[I_U + i]; du[i] = d[I_U + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) un[i] = TRIAL(pn, dn, I_U + i);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { dx[i] = z ? 0.0 : dx[i]; x[i] = fma(a, dx[i], x0[i]); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { du[i] = z ? 0.0 : du[i]; u[i] = fma(a, du[i], u0[i]); }
+            // the ball pairs' directions (pairs a node does not own keep their placeholder values)
+            PairDir du_ = pair_dir(bs[0], bs[1], u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2] - b_u,
+                                   2.0 * (u0[0] * du[0] + u0[1] * du[1] + u0[2] * du[2]), mu);
+            PairDir dmax = pair_dir(bs[2], bs[3], x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2] - b_rmax,
+                                    2.0 * (x0[0] * dx[0] + x0[1] * dx[1] + x0[2] * dx[2]), mu);
+            PairDir dmin = pair_dir(bs[4], bs[5], -(rb0 * x0[0] + rb1 * x0[1] + rb2 * x0[2]) - b_rmin,
+                                    -(rb0 * dx[0] + rb1 * dx[1] + rb2 * dx[2]), mu);
+            const bool on_max = !z && has_prev, on_min = !z && has_prev && dyn;
+            su = fma(a, z ? 0.0 : du_.ds, bs[0]); zu = fma(a, z ? 0.0 : du_.dz, bs[1]);
+            srmax = fma(a, on_max ? dmax.ds : 0.0, bs[2]); zrmax = fma(a, on_max ? dmax.dz : 0.0, bs[3]);
+            srmin = fma(a, on_min ? dmin.ds : 0.0, bs[4]); zrmin = fma(a, on_min ? dmin.dz : 0.0, bs[5]);
+        }
         const double g_u = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
         const double g_rmax = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax;
         const double g_rmin = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
@@ -521,9 +572,14 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { bn[j] = Bn[i * 3 + j]; bp[j] = Bp[i * 3 + j]; bm[j] = Bm[i * 3 + j]; }
                 const double sg = Sg[i], xv = xi[i];
-                const double nu = TRIAL(p, d, I_NU + i), tt = TRIAL(p, d, I_T + i), lam = TRIAL(p, d, I_LAM + i);
-                double stp = TRIAL(p, d, I_STP + i), ztp = TRIAL(p, d, I_ZTP + i);
-                double stn = TRIAL(p, d, I_STN + i), ztn = TRIAL(p, d, I_ZTN + i);
+                const double nu0 = p[I_NU + i], dnu_ = d[I_NU + i], tt0 = p[I_T + i], lam = TRIAL(p, d, I_LAM + i);
+                const double stp0 = p[I_STP + i], ztp0 = p[I_ZTP + i], stn0 = p[I_STN + i], ztn0 = p[I_ZTN + i];
+                const double dnu = z ? 0.0 : dnu_;
+                const L1Dir ld = l1_dir(nu0, tt0, stp0, ztp0, stn0, ztn0, dnu, mu, w_nu);
+                const bool lon = !z && dyn;                                   // (the terminal node has no virtual control)
+                const double nu = fma(a, dnu, nu0), tt = fma(a, lon ? ld.dt : 0.0, tt0);
+                double stp = fma(a, lon ? ld.dstp : 0.0, stp0), ztp = fma(a, lon ? ld.dztp : 0.0, ztp0);
+                double stn = fma(a, lon ? ld.dstn : 0.0, stn0), ztn = fma(a, lon ? ld.dztn : 0.0, ztn0);
                 if (WRITE && dyn) { POST(stp, ztp, nu - tt); POST(stn, ztn, -nu - tt); }
                 const double xn = TRIAL(pn, dn, I_X + i);
                 const double lmv = TRIAL(pm, dm, I_LAM + i);
@@ -653,6 +709,10 @@ __device__ double scaled_error(const ResAcc &r, int K, int nT, int fixed_tf, dou
 // right-hand-side records are assembled there and the 32 records of a round go out as contiguous, coalesced blocks: written straight from the node
 // lanes they were 8-byte stores scattered over 32 cache lines per instruction (measured: the 40 stores per node that the
 // compact Hessian form removed were 6 % of the launch at S = 4096).
+// KEEP_NS: also keep the node's gradient / rho / D scalars in the field-major Newton scalars -- only reduced_residual (the
+// refinement passes of a stiff iteration) reads them: the driver runs newton_blocks<true> once more when it finds that the
+// iteration refines (rare), the plain iteration does not write them.
+template <bool KEEP_NS>
 __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *stg, double mu, double delta_w, int lane)
 {
     const int K = s.K;
@@ -666,7 +726,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         const auto p = s.itn(k), ns = s.nsn(k);
         const auto rb = s.rbn(k);
         double *nb = stg + NODE_OF(lane) * NB_N;
-        double *rhs = stg + 32 * NB_N + NODE_OF(lane) * RHS_N;
+        double *rhs = stg + 32 * NB_N + NODE_OF(lane) * RHS_LD;      // (odd stride: the 32 node lanes hit different banks)
         const bool dyn = (k <= K - 2), inner = (k >= 1 && k <= K - 2);
         // ---- chunk 0: objective, thrust ball, radius balls ----
         // (chunk 0 is computed by both halves and stored by half 0)
@@ -739,10 +799,12 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
 #pragma unroll
                 for (int i = 0; i < 9; ++i) nb[N_WU + i] = Wu[i];
                 if (!inner) { nb[N_SX + SX_EX] = 0.0; nb[N_SX + SX_A] = 0.0; nb[N_SX + SX_A + 1] = 0.0; nb[N_SX + SX_A + 2] = 0.0; }
+                if (KEEP_NS) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
+                    for (int i = 0; i < 7; ++i) ns[NS_GX + i] = gx[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
+                    for (int i = 0; i < 3; ++i) ns[NS_GU + i] = gu[i];
+                }
                 // right-hand-side record of the iteration's first solve (= the Newton blocks; the zero direction carries
                 // no multipliers): x_0 is fixed (no row), the terminal node's gradient is written with its Hessians below
 #pragma unroll
@@ -782,9 +844,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
                 const double ek = ns[NS_E + i];
                 const double rho = (zh1 - zh2) - (bb * ia) * gt;
                 if (valid) {
-                    nb[N_D + i] = dd; ns[NS_D + i] = dd;
-                    ns[NS_AA + i] = aa; ns[NS_BB + i] = bb; ns[NS_GT + i] = gt;
-                    ns[NS_RHO + i] = rho;
+                    nb[N_D + i] = dd;
+                    if (KEEP_NS) { ns[NS_D + i] = dd; ns[NS_RHO + i] = rho; }
                 }
                 if (iv < 7) { rhs[R_RHO + i] = dyn ? rho : 0.0; rhs[R_AFF + i] = dyn ? -ek : 0.0; }
             }
@@ -866,7 +927,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
           // ... and the right-hand-side records (24 contiguous doubles inside each node's channel record)
           const int nr = ((K - k0 < 32) ? K - k0 : 32) * RHS_N;
           gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
-          for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[32 * NB_N + e]; }
+          for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[32 * NB_N + kl * RHS_LD + i]; }
       }
       __syncthreads();
     }
@@ -951,10 +1012,10 @@ struct Scratch {   // LDS working set of the recursion (and, between recursions,
     double Quy[21];
     double Quu[9];
     double zero;                   // constant 0 (addend of the tasks that have none)
-    double stage_pad[32 * (NB_N + RHS_N) - 1129 > 0 ? 32 * (NB_N + RHS_N) - 1129 : 1];   // newton_blocks stages 32 Newton + 32 rhs records here
+    double stage_pad[32 * (NB_N + RHS_LD) - 1129 > 0 ? 32 * (NB_N + RHS_LD) - 1129 : 1];   // newton_blocks stages 32 Newton + 32 rhs records here
 };
 
-static_assert(sizeof(Scratch) >= 32 * (NB_N + RHS_N) * sizeof(double), "newton_blocks stages 32 Newton and right-hand-side records in the recursion's scratch");
+static_assert(sizeof(Scratch) >= 32 * (NB_N + RHS_LD) * sizeof(double) && sizeof(Scratch) >= TR_N * CMB_LD * sizeof(double), "newton_blocks stages 32 Newton and right-hand-side records in the recursion's scratch");
 
 template <int N>
 __device__ __forceinline__ double dotN(const double *a, int sa, const double *b, int sb)
@@ -1403,13 +1464,17 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
 // so a node costs one barrier (the buffer swap).
 struct SweepPre { double v[6]; };
 
+// (PT: the backward sweep of a refinement pass reads Pt; the forward sweep does not, and outside refinement the
+//  factorisation does not even write it -- its 49 doubles, three of the record's 12.5 cache lines, are not fetched then)
+template <bool PT>
 __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
     const int K = s.K;
     cgf64 *fac = s.fac + (size_t)k * FAC_N;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pre.v[q] = fac[lane + 64 * q];
-    pre.v[3] = fac[(lane + 192 < FAC_N) ? lane + 192 : FAC_N - 1];
+    for (int q = 0; q < 2; ++q) pre.v[q] = fac[lane + 64 * q];
+    pre.v[2] = fac[(PT || lane + 128 < F_PT) ? lane + 128 : F_PT - 1];
+    pre.v[3] = PT ? fac[(lane + 192 < FAC_N) ? lane + 192 : FAC_N - 1] : 0.0;
     // A: head of stage record k; Bpm: B_kp of record k-1; D: Newton record k (what a node lacks is zeroed when stashed)
     cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
     cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
@@ -1436,14 +1501,14 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
     const bool act = (c >= c0 && c < c1) && r < 7;
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
-    sweep_fetch_mats(s, K - 1, lane, pre);
+    sweep_fetch_mats<true>(s, K - 1, lane, pre);
     sweep_stash_mats(w.flat[(K - 1) & 1], K, K - 1, lane, pre);
     ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
     double pnext = 0.0;
     __syncthreads();
     for (int k = K - 1; k >= 0; --k) {
         const double *f = w.flat[k & 1];
-        if (k >= 1) { sweep_fetch_mats(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
+        if (k >= 1) { sweep_fetch_mats<true>(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
         const bool dyn = (k <= K - 2);
         double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
@@ -1490,7 +1555,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     const bool act = (c >= c0 && c < c1) && r < 7;
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
-    sweep_fetch_mats(s, 0, lane, pre);
+    sweep_fetch_mats<false>(s, 0, lane, pre);
     sweep_stash_mats(w.flat[0], K, 0, lane, pre);
     ChanIn cur = chan_inputs(s, sd, 0, c, r, act);
     ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
@@ -1510,7 +1575,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     for (int k = 0; k < K; ++k) {
         const double *f = w.flat[k & 1];
         FT_DECL
-        if (k + 1 < K) { sweep_fetch_mats(s, k + 1, lane, pre); nraw = chan_fetch(s, k + 1, c, rr, r3); load_pq(k + 1, qun, pnn, sgn); }
+        if (k + 1 < K) { sweep_fetch_mats<false>(s, k + 1, lane, pre); nraw = chan_fetch(s, k + 1, c, rr, r3); load_pq(k + 1, qun, pnn, sgn); }
         const bool dyn = (k <= K - 2);
         FT_MARK(10)
         double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
@@ -1545,7 +1610,6 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
             ustore(s.ws, act ? tb + T_X + r : sink_t, x);
             ustore(s.ws, (act && r < 3) ? tb + T_U + r3 : sink_t, u);
             ustore(s.ws, ad ? tb + T_NU + r : sink_t, nu);
-            ustore(s.ws, ad ? tb + T_LAM + r : sink_t, lam);
             if (act && k == K - 1) sd.xK[c][r] = x;
             siglam += ad ? sgc * lam : 0.0;
             y = ad ? yh + nu : y;
@@ -1597,14 +1661,15 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
                 cgf64 *tr = traj + (size_t)(k0 + kl) * NCH * TR_N + i;
                 double acc = tr[0];
 #pragma unroll
-                for (int j = 0; j < NBD; ++j) acc += sol[j] * tr[(1 + j) * TR_N];
-                v[q] = acc; slot[q] = (e < n) ? i * 32 + kl : -1;
+                for (int j = 0; j < NBD; ++j)
+                    acc += sol[j] * tr[(1 + j) * TR_N];
+                v[q] = acc; slot[q] = (e < n) ? i * CMB_LD + kl : -1;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
         __syncthreads();
-        for (int e = lane; e < TR_N * 32; e += 64) {
+        for (int e = lane; e < DIR_N * 32; e += 64) {
             const int i = e >> 5, kl = e & 31, k = k0 + kl;
             const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
             const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
@@ -1612,7 +1677,11 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
             // starting value: -lam for the multiplier part of the first solve, the current direction when refining
             const double cur = first ? it[dst] : dr[dst];
             const double base = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
-            if (act) dr[dst] = base + stg[e];
+            // multiplier part: D_k nu_k + rho_k from the combined nu
+            const int kc = (kl < nk) ? k : k0, j = (i >= T_LAM) ? i - T_LAM : 0;
+            const double Dj = s.nb[(size_t)kc * NB_N + N_D + j], rj = s.ch[(size_t)kc * CH_N + C_RHS + R_RHO + j];
+            const double val = (i >= T_LAM) ? fma(Dj, stg[(T_NU + j) * CMB_LD + kl], rj) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
+            if (act) dr[dst] = base + val;
         }
         __syncthreads();
     }
@@ -1938,20 +2007,23 @@ __device__ __forceinline__ void first_rhs_scalars(const SatData &sd, double &gtf
     }
 }
 
-// dt, ds, dz by back-substitution ("Linear solve") and the fraction-to-the-boundary step.
+// The fraction-to-the-boundary step of the direction and the finite check on it.  The directions of the eliminated pairs
+// (dt, ds, dz by back-substitution: pair_dir, l1_dir) are formed here only to be measured against their variables; they are
+// not stored -- every trial evaluation forms them again (eval_residual).  The handful of terminal / tf pairs live in the
+// global part of the direction record, as before.
 __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane, bool &finite)
 {
     const int K = s.K;
     double amax = 1.0, bad = 0.0;
 #define CHK(v) { if (!(fabs(v) < 1e300)) bad = 1.0; }
-    const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin;
+    const double b_u = sd.b_u, b_rmax = sd.b_rmax, b_rmin = sd.b_rmin, w_nu = sd.w_nu;
 #define LIM(v, dv) { const double v_ = (v), d_ = (dv); if (d_ < 0.0) amax = fmin(amax, -tau * v_ / d_); }
     const int half = HALF_OF(lane);
     const bool h0 = (half == 0);
     for (int k = NODE_OF(lane); k < K; k += 32) {
-        const auto p = s.itn(k), d = s.drn(k), ns = s.nsn(k);
+        const auto p = s.itn(k), d = s.drn(k);
         const auto rb = s.rbn(k);
-        // chunk 0 (both halves compute, half 0 stores; the step limit and the finite flag are idempotent): the ball pairs
+        // chunk 0 (both halves compute; the step limit and the finite flag are idempotent): the ball pairs
         double x[7], dx[7];
         {
             double u[3], du[3], bs[6];
@@ -1966,36 +2038,20 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
 #pragma unroll
             for (int i = 0; i < 3; ++i) CHK(du[i]);
             const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
-            double o[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             {
-                const double su = bs[0], zu = bs[1];
-                const double g = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u;
-                const double isu = rcp_pos(su), sig = zu * isu, zh = mu * isu + sig * (g + su);
-                const double dg = 2.0 * (u[0] * du[0] + u[1] * du[1] + u[2] * du[2]);
-                o[0] = -(g + su) - dg; o[1] = zh + sig * dg - zu;
-                LIM(su, o[0]); LIM(zu, o[1]);
+                const PairDir q = pair_dir(bs[0], bs[1], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u,
+                                           2.0 * (u[0] * du[0] + u[1] * du[1] + u[2] * du[2]), mu);
+                LIM(bs[0], q.ds); LIM(bs[1], q.dz);
             }
             if (k >= 1) {
-                const double srmax = bs[2], zrmax = bs[3];
-                const double g = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax;
-                const double isr = rcp_pos(srmax), sig = zrmax * isr, zh = mu * isr + sig * (g + srmax);
-                const double dg = 2.0 * (x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2]);
-                o[2] = -(g + srmax) - dg; o[3] = zh + sig * dg - zrmax;
-                LIM(srmax, o[2]); LIM(zrmax, o[3]);
+                const PairDir q = pair_dir(bs[2], bs[3], x[0] * x[0] + x[1] * x[1] + x[2] * x[2] - b_rmax,
+                                           2.0 * (x[0] * dx[0] + x[1] * dx[1] + x[2] * dx[2]), mu);
+                LIM(bs[2], q.ds); LIM(bs[3], q.dz);
             }
             if (k >= 1 && k <= K - 2) {
-                const double srmin = bs[4], zrmin = bs[5];
-                const double g = -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin;
-                const double isr = rcp_pos(srmin), sig = zrmin * isr, zh = mu * isr + sig * (g + srmin);
-                const double dg = -(rb0 * dx[0] + rb1 * dx[1] + rb2 * dx[2]);
-                o[4] = -(g + srmin) - dg; o[5] = zh + sig * dg - zrmin;
-                LIM(srmin, o[4]); LIM(zrmin, o[5]);
-            }
-            // pairs a node does not own keep the zero the direction record was reset to
-            if (h0) {
-                d[I_SU] = o[0]; d[I_ZU] = o[1];
-                if (k >= 1) { d[I_SRMAX] = o[2]; d[I_ZRMAX] = o[3]; }
-                if (k >= 1 && k <= K - 2) { d[I_SRMIN] = o[4]; d[I_ZRMIN] = o[5]; }
+                const PairDir q = pair_dir(bs[4], bs[5], -(rb0 * x[0] + rb1 * x[1] + rb2 * x[2]) - b_rmin,
+                                           -(rb0 * dx[0] + rb1 * dx[1] + rb2 * dx[2]), mu);
+                LIM(bs[4], q.ds); LIM(bs[5], q.dz);
             }
         }
         CHUNK_END
@@ -2009,22 +2065,11 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
                 const int i = (iv < 7) ? iv : 6;
                 const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
                 const double stn = p[I_STN + i], ztn = p[I_ZTN + i], dnu = d[I_NU + i], dlam = d[I_LAM + i];
-                const double gt = ns[NS_GT + i], bb = ns[NS_BB + i], aa = ns[NS_AA + i];
-                const double dt = (-gt - bb * dnu) * rcp_pos(aa);
-                if (valid) { CHK(dnu); CHK(dlam); CHK(dt); }
-                const double g1 = nu - tt, g2 = -nu - tt;
-                const double ip = rcp_pos(stp), in = rcp_pos(stn);
-                const double s1 = ztp * ip, s2 = ztn * in;
-                const double zh1 = mu * ip + s1 * (g1 + stp), zh2 = mu * in + s2 * (g2 + stn);
-                const double dg1 = dnu - dt, dg2 = -dnu - dt;
-                const double dstp = -(g1 + stp) - dg1, dztp = zh1 + s1 * dg1 - ztp;
-                const double dstn = -(g2 + stn) - dg2, dztn = zh2 + s2 * dg2 - ztn;
+                const L1Dir q = l1_dir(nu, tt, stp, ztp, stn, ztn, dnu, mu, w_nu);
                 if (valid) {
-                    LIM(stp, dstp); LIM(ztp, dztp);
-                    LIM(stn, dstn); LIM(ztn, dztn);
-                    d[I_T + i] = dt;
-                    d[I_STP + i] = dstp; d[I_ZTP + i] = dztp;
-                    d[I_STN + i] = dstn; d[I_ZTN + i] = dztn;
+                    CHK(dnu); CHK(dlam); CHK(q.dt);
+                    LIM(stp, q.dstp); LIM(ztp, q.dztp);
+                    LIM(stn, q.dstn); LIM(ztn, q.dztn);
                 }
                 CHUNK_END
             }
@@ -2100,7 +2145,8 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 }
 
 #ifdef MPCX_PHASE_TIMING
-#define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, pt0_ = 0; unsigned pc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, pt0_ = 0; unsigned pc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; \
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
 #define PT_BEGIN pt0_ = __builtin_amdgcn_s_memtime();
 #define PT_END(i) { pt_[i] += __builtin_amdgcn_s_memtime() - pt0_; pc_[i]++; }
 #else
@@ -2112,17 +2158,10 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 2     // waves per SIMD the register allocation is bounded for (256 registers; 3 was measured slower)
 #endif
-__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
+// One satellite from the problem constants to its results; `slot` selects the workspace (see solve_kernel).
+__device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sat, const int slot, SatData &sd, Scratch &w, const int lane)
 {
     PT_DECL
-    __shared__ SatData sd;
-    __shared__ Scratch w;
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= a.S) return;
-    // (an entry outside [0, S) can only come from a caller that broke the same-stream rule of include/mpcx.h: never an
-    //  out-of-bounds satellite)
-    int sat = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if ((unsigned)sat >= (unsigned)a.S) sat = (int)blockIdx.x;
     const int Kmax = a.K;
     const int K = a.Ks ? a.Ks[sat] : Kmax;        // (wave-uniform: one satellite per workgroup)
     if (K < 3 || K > Kmax) {                      // ragged batch with a node count the solver cannot take
@@ -2139,7 +2178,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
     s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
     const int KP = padded_nodes(K);
     s.KP = KP;
-    gf64 *ws = (gf64 *)a.ws + (size_t)sat * a.ws_stride;
+    gf64 *ws = (gf64 *)a.ws + (size_t)slot * a.ws_stride;
     s.ws = ws;
     s.it = ws; ws += (size_t)KP * IT_N;
     s.dr = ws; ws += (size_t)KP * IT_N;
@@ -2288,7 +2327,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         // the last value that worked (1e-4 the first time), growing by 8 (by 100 until some value has worked), up to 1e40
         while (!have_dir && delta_w <= kDwMax) {
             PT_BEGIN
-            newton_blocks(s, sd, (double *)&w, mu, delta_w, lane);
+            newton_blocks<false>(s, sd, (double *)&w, mu, delta_w, lane);
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
             first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
@@ -2297,6 +2336,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
             double twmax = sd.sigmax;
             for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
             const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
+            if (passes > 1) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);      // (the scalars reduced_residual reads)
             PT_BEGIN
             bool ok = riccati_factor(s, sd, w, lane, true, passes > 1);   // factorisation + backward sweep of all 8 channels
             PT_END(2)
@@ -2435,7 +2475,35 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         double *dbg = a.NU + (size_t)sat * 7 * Kmax;
         for (int i = 0; i < 12; ++i) { dbg[2 * i] = (double)pt_[i]; dbg[2 * i + 1] = (double)pc_[i]; }
         for (int i = 0; i < 16; ++i) dbg[24 + i] = (double)sd.fpt[i];
+        // calibration: the satellite's life in s_memrealtime ticks (constant 100 MHz) and in s_memtime ticks
+        dbg[40] = (double)(__builtin_amdgcn_s_memrealtime() - rt0_); dbg[41] = (double)(__builtin_amdgcn_s_memtime() - mt0_);
 #endif
+    }
+}
+
+// Persistent workgroups: the launch has as many single-wave workgroups as the device holds at once (or S, if fewer), each
+// takes satellites off a counter until none is left, in launch order (longest first when the previous solve's iteration
+// counts are known).  A workgroup keeps ONE workspace slot for all its satellites: the solver's working set is
+// slots x 206 KB whatever the batch size (8192 satellites: 0.44 GB instead of 1.8 GB), and a slot's lines are rewritten
+// by the next satellite while they are still cached instead of being written back as dead data.
+__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
+{
+    __shared__ SatData sd;
+    __shared__ Scratch w;
+    __shared__ int next_item;
+    const int lane = threadIdx.x;
+    for (;;) {
+        if (lane == 0) next_item = atomicAdd(a.counter, 1);
+        __syncthreads();
+        const int b = __builtin_amdgcn_readfirstlane(next_item);
+        __syncthreads();
+        if (b >= a.S) return;
+        // (an entry outside [0, S) can only come from a caller that broke the same-stream rule of include/mpcx.h: never an
+        //  out-of-bounds satellite)
+        int sat = a.order ? a.order[b] : b;
+        if ((unsigned)sat >= (unsigned)a.S) sat = b;
+        solve_satellite(a, sat, (int)blockIdx.x, sd, w, lane);
+        __syncthreads();
     }
 }
 
@@ -2589,7 +2657,11 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
             a.order = ctx->order;
         }
     }
-    hipLaunchKernelGGL(solve_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, a);
+    if (!ctx->counter) MPCX_HIP(ctx, hipMalloc((void **)&ctx->counter, sizeof(int32_t)));
+    MPCX_HIP(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(int32_t), (hipStream_t)stream));
+    a.counter = ctx->counter;
+    const int slots = S < ctx->n_slots ? S : ctx->n_slots;
+    hipLaunchKernelGGL(solve_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, a);
     MPCX_HIP(ctx, hipGetLastError());
     if (adaptive) {
         MPCX_HIP(ctx, hipMemcpyAsync(ctx->prev_iters, iters, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));

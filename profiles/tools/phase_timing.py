@@ -14,13 +14,18 @@ d = np.load(os.path.join(G, "disc_tan_K30_tf1.npz"))
 x, u, tf, cst = d["x"], d["u"], float(d["tf"]), d["const"]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rep = lambda a: np.repeat(a[None], S, axis=0)
-r = solve_batch(rep(d["A"]), rep(d["Bp"]), rep(d["Bn"]), rep(d["Sigma"]), rep(d["xi"]), rep(x), rep(u), [tf] * S, rep(cst),
-                [np.linalg.norm(x[:3, -1])] * S)
+import time
+args = (rep(d["A"]), rep(d["Bp"]), rep(d["Bn"]), rep(d["Sigma"]), rep(d["xi"]), rep(x), rep(u), [tf] * S, rep(cst), [np.linalg.norm(x[:3, -1])] * S)
+r = solve_batch(*args)
+t0 = time.perf_counter(); r = solve_batch(*args); wall = time.perf_counter() - t0
+print(f"S {S}: host-pointer solve_batch wall {wall*1e3:.3f} ms (copies of {S*30*17*8/1e6:.1f} MB results included)")
 names = ["eval_res(E0,Emu,r0)", "newton_blocks", "riccati_factor", "sweep_bwd 8ch", "sweep_fwd 8ch+border", "reduced_residual",
          "ch0 bwd+fwd", "border_solve+comb fwd", "finish_direction", "apply_step", "line-search evals", "-"]
 t = r.NU[0].ravel()[:24].reshape(12, 2)
 tot = t[:, 0].sum()
-print("iters", r.iters[0], "status", r.status[0], "total cycles(100MHz ticks?)", tot)
+rt, mt = r.NU[0].ravel()[40:42]
+print("iters", r.iters[0], "status", r.status[0], "total s_memtime ticks in phases", tot,
+      f"| satellite 0 lived {rt/100:.1f} us (s_memrealtime, 100 MHz) = {mt:.0f} s_memtime ticks -> s_memtime at {mt/(rt/100):.1f} MHz")
 for n, (cyc, cnt) in zip(names, t):
     if cnt: print(f"{n:28s} {cyc/tot*100:6.2f}%  calls {int(cnt):5d}  per call {cyc/cnt:10.0f}")
 fn = ["fetch issue", "P1-3 Bh,WxBp,LDL,subst + bwd sweep of k+1", "(mark only)", "P4 Pt,G,Minv", "P5", "P6", "P7-9 inv3,P_k,Kg", "(mark only)", "sweep inputs", "stash+sync",
