@@ -164,19 +164,32 @@ def measure(runner, steps, warmup, world):
 
 
 def measured_traffic(workload, kernel="solve_kernel"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)."""
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/rNN/
+    pmc_traffic.json) -- a counter measurement of an earlier run on another box, echoed here; it is reported only when
+    the kernel sources are byte for byte the ones that were profiled (the profile records their hashes), with its origin."""
+    import hashlib
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
-        w = json.load(open(f)).get("workloads", {}).get(workload, {}).get(kernel)
-        if w: return w["hbm_bytes_per_launch"]
-    return None
+        prof = json.load(open(f))
+        w = prof.get("workloads", {}).get(workload, {}).get(kernel)
+        if not w: continue
+        src = os.path.relpath(f, ROOT)
+        want = prof.get("kernel_source_sha256")
+        if not want:
+            return None, f"{src}: no source hashes recorded (profile of an earlier round), not reported"
+        for name, h in want.items():
+            if hashlib.sha256(open(os.path.join(ROOT, "mpconstellation_amd", "csrc", name), "rb").read()).hexdigest() != h:
+                return None, f"{src}: {name} changed since it was profiled, not reported"
+        return w["hbm_bytes_per_launch"], f"{src} (same kernel sources, counters of that profiling run)"
+    return None, "no committed profile holds this workload"
 
 
 def roofline(workload, S, K, solve_ms, iters):
     B = algorithmic_bytes(K)
     achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
     flops = FLOP_PER_NODE_ITER * K * float(iters.sum())   # of the last solve_kernel launch on this rank
+    traffic, traffic_source = measured_traffic(workload)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(workload), "kernel": "mpcx::solve_kernel", "kernel_ms": solve_ms,
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": "mpcx::solve_kernel", "kernel_ms": solve_ms,
             "algorithmic_bytes_per_satellite": B,
             "note": "algorithmic bytes = 8(27K+7)+8 + 1680(K-1) per satellite-MPC-step (SURVEY 8d, two-kernel form) x satellites per "
                     "launch; duration = HIP events around solve_kernel on its launch stream; traffic = FETCH_SIZE+WRITE_SIZE of "

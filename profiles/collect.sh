@@ -5,19 +5,20 @@
 #   3. two passes of 8 SQ counters each: instruction mix / fp64 operation counts, and wait / active cycles
 # Raw output goes to gpurun_out/prof/<round>/ ; profiles/summarize.py turns it into the committed summaries.
 set -e
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for W in S4096_K30 S64_K30 S4096_K100_scp2; do
+for W in S4096_K30 S64_K30 S4096_K100_scp2 S8192_K30; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W/stats" -o stats -- \
     python3 "$REPO/bench.py" --workload $W --steps 8 --warmup 2 --no-also --no-cpu-baseline > "$OUT/$W.bench.log" 2>&1
   echo "stats $W done"
 done
 SQ_A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"
 SQ_B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F64"
-for W in S4096_K30 S64_K30; do
+# (K = 100: the configuration BASELINE.json calls the HBM-bound regime)
+for W in S4096_K30 S64_K30 S4096_K100_scp2; do
   for C in FETCH_SIZE WRITE_SIZE SQ_A SQ_B; do
     case $C in SQ_A) LIST=$SQ_A;; SQ_B) LIST=$SQ_B;; *) LIST=$C;; esac
     rocprofv3 --kernel-trace --pmc $LIST --output-format csv -d "$OUT/$W/$C" -o pmc -- \

@@ -48,6 +48,11 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
             f_kb, w_kb = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
             traffic["workloads"][w][short] = {"fetch_KB": f_kb, "write_KB": w_kb, "hbm_bytes_per_launch": (f_kb + w_kb) * 1024.0}
 if traffic["workloads"]:
+    import hashlib
+    # the kernel sources these counters belong to: bench.py reports the traffic only for exactly this code
+    traffic["kernel_source_sha256"] = {f: hashlib.sha256(open(os.path.join(root, "..", "mpconstellation_amd", "csrc", f), "rb").read()).hexdigest()
+                                       for f in ("solve.hip", "discretize.hip", "mpcx_device.hpp")}
+    traffic["round"] = rnd
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 # SQ passes: per kernel, counter values summed over the rows of one dispatch, averaged over dispatches
