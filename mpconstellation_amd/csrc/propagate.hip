@@ -5,8 +5,8 @@
 // (simulator.py:116-161) under one of the reference's thrust laws (control.py:8-143).  Samples come
 // from the RK45 dense-output interpolant exactly as scipy produces them.
 //
-// One lane per satellite: the 7-state system and its 7 RK stages live in registers; satellites of a
-// wave take their own adaptive step sequences under predicate.  It is a setup / SCP re-linearisation
+// Four lanes per satellite: the 7-state system and its 7 RK stages live in the registers of a quad (Ctrl below);
+// satellites of a wave take their own adaptive step sequences under predicate.  It is a setup / SCP re-linearisation
 // kernel (7 x ~1000 steps per satellite), not bandwidth relevant.
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
@@ -24,21 +24,26 @@ struct PropArgs {
     int32_t *status, *nsteps;
 };
 
+// Four lanes per satellite (a quad): lane c < 3 owns position and velocity component c, every lane carries the mass; lane 3
+// mirrors lane 2 and is left out of the sums.  What the right-hand side needs across components travels by quad_perm DPP
+// moves: |r|^2, |h|^2, |u|^2 and the error norms as quad sums, the cross products through the two rotations of the triple.
+// One lane per satellite (rounds 1-2) was bound by the issue rate of its ~810 instructions per RK45 step (the whole
+// 7-state system and its stage combinations in one lane); a lane of the quad issues ~500.
 struct Ctrl {
     int kind, Ku, ldu;        // ldu: row length of the thrust table in memory (Ku of its columns in use)
-    double v[3], vn;          // vn = |v| (constant thrust)
-    const double *useq;
+    double vc, vn;            // constant thrust: this lane's component and |v|; tangential: vc = magnitude
+    const double *useq;       // sequence: this lane's ROW of the table
     double end_tau, inv_end_tau;
     // first-order hold: the interval in use (an RK45 step is at most max_step = 1e-3 long against intervals of 1/(Ku-1):
     // the six stages of a step and many steps in a row read the same two table columns -- kept in registers)
     int kc;
-    double uk[3], uk1[3], tau_k, tau_kp1, id;
+    double uk, uk1, tau_k, tau_kp1, id;
 };
 
 // 1/d and 1/sqrt(d) for d > 0 well inside the normal range: hardware seed + two Newton steps (half an ulp, measured:
 // profiles/tools/rcp_accuracy.hip) instead of the IEEE division / square-root sequences (scaling, fix-up: ~3x the
-// instructions).  The rollout is ~1000 sequential RK45 steps x 6 right-hand sides of one lane: its time is the number
-// of instructions of the right-hand side.
+// instructions).  The rollout is ~1000 sequential RK45 steps x 6 right-hand sides: its time is the number of
+// instructions of the right-hand side.
 __device__ __forceinline__ double rcp_fast(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -54,10 +59,18 @@ __device__ __forceinline__ double rsq_fast(double d)
     return r;
 }
 
-// First-order hold of a (3,Ku) table at tau in [0,1] (control.py:104-126), same node index as foh3: k = int(tau // dtau) is
-// the floor of the exact quotient (Python's float floor division goes through an exact fmod); floor(tau * (Ku-1)) is
-// that number unless the product sits within rounding of an integer, and only then the exact routine is needed.
-__device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3], int &err)
+// quad exchange: sum over the four lanes (bitwise identical on all of them: both steps add the same two operands), the two
+// rotations of the (0,1,2) triple (lane 3 keeps its own value), and the value of lane 2
+__device__ __forceinline__ double quad_sum(double v) { v += dpp64<0xB1>(v); v += dpp64<0x4E>(v); return v; }
+__device__ __forceinline__ double rot1(double v) { return dpp64<0xC9>(v); }     // quad_perm [1,2,0,3]: lane c <- lane (c+1) mod 3
+__device__ __forceinline__ double rot2(double v) { return dpp64<0xD2>(v); }     // quad_perm [2,0,1,3]: lane c <- lane (c+2) mod 3
+__device__ __forceinline__ double lane2(double v) { return dpp64<0xAA>(v); }    // quad_perm [2,2,2,2]
+
+// First-order hold of this lane's row of a (3,Ku) table at tau in [0,1] (control.py:104-126), same node index as foh3:
+// k = int(tau // dtau) is the floor of the exact quotient (Python's float floor division goes through an exact fmod);
+// floor(tau * (Ku-1)) is that number unless the product sits within rounding of an integer, and only then the exact routine
+// is needed.
+__device__ __forceinline__ double foh_cached(double tau, Ctrl &c, int &err)
 {
     const int Ku = c.Ku;
     const double *__restrict__ u = c.useq;
@@ -65,54 +78,54 @@ __device__ __forceinline__ void foh3_cached(double tau, Ctrl &c, double (&out)[3
     // Everything else -- a new interval, an end point, tau == 1 -- is behind this one rarely taken branch: the right-hand
     // side is evaluated six times per step and every branch in it costs the in-order wave ~40 cycles.
     if (!(tau > c.tau_k + 1e-12 && tau < c.tau_kp1 - 1e-12)) {
-    if (tau == 1.0) { out[0] = u[Ku - 1]; out[1] = u[c.ldu + Ku - 1]; out[2] = u[2 * c.ldu + Ku - 1]; return; }
+    if (tau == 1.0) return u[Ku - 1];
     const double km1 = (double)(Ku - 1);
     const double q = tau * km1;
     int k = (fabs(q - rint(q)) > 1e-9 * fmax(1.0, q)) ? (int)floor(q) : (int)py_floordiv(tau, 1.0 / km1);
     if (k < 0 || k + 1 >= Ku) {          // the reference raises IndexError here
         err = MPCX_ST_FOH;
         k = k < 0 ? 0 : Ku - 2;
-        if (Ku < 2) { out[0] = out[1] = out[2] = 0.0; return; }
+        if (Ku < 2) return 0.0;
     }
     if (k != c.kc) {
         c.kc = k;
         c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
         c.id = 1.0 / (c.tau_kp1 - c.tau_k);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * c.ldu + k]; c.uk1[i] = u[i * c.ldu + k + 1]; }
+        c.uk = u[k]; c.uk1 = u[k + 1];
     }
     }
     const double lam_n = (c.tau_kp1 - tau) * c.id, lam_p = (tau - c.tau_k) * c.id;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
+    return lam_n * c.uk + lam_p * c.uk1;
 }
 
-// Simulator.satellite_dynamics (simulator.py:116-161) under the controller's thrust law (control.py), times tf -- the
-// same quantities as dynamics_unscaled / ctrl_eval (which the discretizer keeps using, division for division as numpy
-// evaluates them), arranged around one reciprocal each of |r|, |h|, m instead of a division per component: results
-// differ from those forms by rounding only (a few ulp per evaluation; rollouts agree with the reference's to 1e-12,
-// the accepted step sequence is the same -- max_step clips every step).  inv_gi = 1 / (g0 Isp).
+// Simulator.satellite_dynamics (simulator.py:116-161) under the controller's thrust law (control.py), times tf, for the
+// component this lane owns (r, v: its position / velocity component, m: the mass; on: lane < 3) -- the same quantities as
+// dynamics_unscaled / ctrl_eval (which the discretizer keeps using, division for division as numpy evaluates them),
+// arranged around one reciprocal each of |r|, |h|, m instead of a division per component: results differ from those forms
+// by rounding only (rollouts agree with the reference's to 1e-12, the accepted step sequence is the same -- max_step
+// clips every step).  inv_gi = 1 / (g0 Isp).
 template <int KIND, int FLAGS>
-__device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double inv_gi, double tf, double tau,
-                                         const double (&y)[7], double (&yd)[7], int &err)
+__device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double inv_gi, double tf, double tau, int comp, bool on,
+                                         double r, double v, double m, double &dr, double &dv, double &dm, int &err)
 {
     constexpr int flags = FLAGS;
-    const double r2 = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+    const double r2 = quad_sum(on ? r * r : 0.0);
     const double irn = rsq_fast(r2), irn2 = irn * irn;
-    const double m = y[6];
     if (m <= 0.0) err = MPCX_ST_MASS;
     const double im = rcp_fast(m > 0.0 ? m : 1.0);
-    double u[3], un;
+    double u, un;
     if (KIND == MPCX_CTRL_CONSTANT) {
-        u[0] = c.v[0]; u[1] = c.v[1]; u[2] = c.v[2];
-        un = c.vn;
-    } else if (KIND == MPCX_CTRL_TANGENTIAL) {            // control.py:66-84: u = mag * h_hat x r_hat = mag (h x r) / (|h| |r|)
-        const double h[3] = {y[1] * y[5] - y[2] * y[4], y[2] * y[3] - y[0] * y[5], y[0] * y[4] - y[1] * y[3]};
-        const double ihn = rsq_fast(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
-        const double k = c.v[0] * (ihn * irn);
-        u[0] = k * (h[1] * y[2] - h[2] * y[1]); u[1] = k * (h[2] * y[0] - h[0] * y[2]); u[2] = k * (h[0] * y[1] - h[1] * y[0]);
-        un = fabs(c.v[0]);                                   // |h_hat x r_hat| = 1 (h is normal to r)
-    } else if (KIND == MPCX_CTRL_SEQUENCE) {                          // control.py:132-142
+        u = c.vc; un = c.vn;
+    } else if (KIND == MPCX_CTRL_TANGENTIAL) {
+        // control.py:66-84: u = mag * t_hat, t_hat = h_hat x r_hat with h = r x v.  (r x v) x r = v |r|^2 - r (r.v) is that
+        // direction without a cross product (h is normal to r, so |h x r| = |h| |r|): one quad sum for r.v, one for the
+        // norm, no rotations of the triple
+        const double rv = quad_sum(on ? r * v : 0.0);
+        const double w = v * r2 - r * rv;
+        const double iwn = rsq_fast(quad_sum(on ? w * w : 0.0));
+        u = c.vc * (w * iwn);
+        un = fabs(c.vc);
+    } else if (KIND == MPCX_CTRL_SEQUENCE) {                  // control.py:132-142
         // tau / end_tau: reciprocal, product and one correction step (the quotient as the division sequence rounds it).
         // Past end_tau the thrust is zero: no branch, the table is read at the middle of the interval in use (always a
         // valid argument) and the result discarded.
@@ -120,42 +133,27 @@ __device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double in
         double tn = tau * c.inv_end_tau;
         tn = fma(fma(-tn, c.end_tau, tau), c.inv_end_tau, tn);
         tn = live ? tn : ((c.kc >= 0) ? 0.5 * (c.tau_k + c.tau_kp1) : 0.5);
-        foh3_cached(tn, c, u, err);
-        const double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        const double uf = foh_cached(tn, c, err);
+        const double uu = quad_sum(on ? uf * uf : 0.0);
         un = live ? uu * rsq_fast(fmax(uu, 1e-300)) : 0.0;    // |u| (0 for u = 0)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = live ? u[i] : 0.0;
-    } else { u[0] = u[1] = u[2] = 0.0; un = 0.0; }
+        u = live ? uf : 0.0;
+    } else { u = 0.0; un = 0.0; }
     const double kg = -cst.mu * (irn2 * irn);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        yd[i] = y[3 + i];
-        yd[3 + i] = kg * y[i] + u[i] * im;
-    }
+    dr = v;
+    dv = kg * r + u * im;
     if (flags & MPCX_FLAG_DRAG) {                            // simulator.py:150-153
-        const double vn = sqrt(y[3] * y[3] + y[4] * y[4] + y[5] * y[5]);
+        const double vn = sqrt(quad_sum(on ? v * v : 0.0));
         const double coef = -0.5 * kCd * cst.s * im * (kRho500 / cst.rho) * vn;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) yd[3 + i] += coef * y[3 + i];
+        dv += coef * v;
     }
     if (flags & MPCX_FLAG_J2) {                              // simulator.py:154-158
-        const double q2 = (y[2] * y[2]) * irn2;
+        const double rz = lane2(r);
+        const double q2 = (rz * rz) * irn2;
         const double coef = 1.5 * cst.j2 * cst.mu * (cst.re * cst.re) * (irn2 * irn2 * irn);
-        yd[3] += coef * ((5.0 * q2 - 1.0) * y[0]);
-        yd[4] += coef * ((5.0 * q2 - 1.0) * y[1]);
-        yd[5] += coef * ((5.0 * q2 - 3.0) * y[2]);
+        dv += coef * ((5.0 * q2 - (comp == 2 ? 3.0 : 1.0)) * r);
     }
-    yd[6] = -un * inv_gi;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) yd[i] = tf * yd[i];
-}
-
-__device__ __forceinline__ double rms7(const double (&v)[7])
-{
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) s += v[i] * v[i];
-    return sqrt(s) / sqrt(7.0);
+    dm = -un * inv_gi;
+    dr = tf * dr; dv = tf * dv; dm = tf * dm;
 }
 
 // One instantiation per thrust law and truth-model flag set (both are launch constants): the right-hand side appears
@@ -163,46 +161,48 @@ __device__ __forceinline__ double rms7(const double (&v)[7])
 template <int KIND, int FLAGS>
 __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
 {
-    const int sat = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sat >= a.S) return;
+    const int sat = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int lane4 = threadIdx.x & 3;
+    if (sat >= a.S) return;                                      // (quad-uniform: the exchanges never leave a quad)
+    const bool on = lane4 < 3;
+    const int comp = on ? lane4 : 2;                             // lane 3 mirrors lane 2 and is left out of sums and stores
     SatConst cst; cst.load(a.consts + (size_t)sat * MPCX_NCONST);
     const double tf = a.tf[sat];
-    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Kus ? a.Kus[sat] : a.Ku; c.ldu = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.v[0] = c.v[1] = c.v[2] = 0.0; c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0;
-    if (a.ctrl_kind == MPCX_CTRL_CONSTANT) { for (int i = 0; i < 3; ++i) c.v[i] = a.ctrl_vec[(size_t)sat * 3 + i]; }
-    else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.v[0] = a.ctrl_vec[sat];
-    else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku; c.end_tau = a.end_tau[sat]; }
-    c.vn = sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]);
+    Ctrl c; c.kind = a.ctrl_kind; c.Ku = a.Kus ? a.Kus[sat] : a.Ku; c.ldu = a.Ku; c.useq = nullptr; c.end_tau = 1.0; c.vc = 0.0; c.vn = 0.0;
+    c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0; c.uk = c.uk1 = 0.0; c.id = 0.0;
+    if (a.ctrl_kind == MPCX_CTRL_CONSTANT) {
+        const double *v3 = a.ctrl_vec + (size_t)sat * 3;
+        c.vc = v3[comp]; c.vn = sqrt(v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2]);
+    } else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.vc = a.ctrl_vec[sat];
+    else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku + (size_t)comp * a.Ku; c.end_tau = a.end_tau[sat]; }
     c.inv_end_tau = 1.0 / c.end_tau;
     const int ld = a.n_eval;                                     // row length of y_out
     int n_eval = a.n_evals ? a.n_evals[sat] : a.n_eval;
     if (n_eval < 1 || n_eval > ld || (a.ctrl_kind == MPCX_CTRL_SEQUENCE && (c.Ku < 2 || c.Ku > a.Ku))) {
-        a.status[sat] = MPCX_ST_BADK; a.nsteps[sat] = 0;
+        if (lane4 == 0) { a.status[sat] = MPCX_ST_BADK; a.nsteps[sat] = 0; }
         return;
     }
     const double inv_gi = 1.0 / (cst.g0 * cst.isp);
     const double rtol = 1e-3, atol = 1e-6, t_bound = 1.0;
     int err = 0;
-    double y[7], f[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) y[i] = a.y0[(size_t)sat * 7 + i];
+    // rms over the 7 components of the system from this lane's three (the mass is counted by lane 0)
+    auto rms7 = [&](double pr, double pv, double pm) {
+        return sqrt(quad_sum((on ? pr * pr + pv * pv : 0.0) + (lane4 == 0 ? pm * pm : 0.0))) / sqrt(7.0);
+    };
+    double yr = a.y0[(size_t)sat * 7 + comp], yv = a.y0[(size_t)sat * 7 + 3 + comp], ym = a.y0[(size_t)sat * 7 + 6];
+    double fr, fv, fm;
     double t = 0.0;
-    prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t, y, f, err);
+    prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t, comp, on, yr, yv, ym, fr, fv, fm, err);
     // select_initial_step (scipy common.py:68-134)
     double h_abs;
     {
-        double sc[7], a0[7], a1[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { sc[i] = atol + fabs(y[i]) * rtol; a0[i] = y[i] / sc[i]; a1[i] = f[i] / sc[i]; }
-        const double d0 = rms7(a0), d1 = rms7(a1);
+        const double scr = atol + fabs(yr) * rtol, scv = atol + fabs(yv) * rtol, scm = atol + fabs(ym) * rtol;
+        const double d0 = rms7(yr / scr, yv / scv, ym / scm), d1 = rms7(fr / scr, fv / scv, fm / scm);
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         h0 = fmin(h0, 1.0);
-        double y1[7], f1[7], dd[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h0, y1, f1, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) dd[i] = (f1[i] - f[i]) / sc[i];
-        const double d2 = rms7(dd) / h0;
+        double f1r, f1v, f1m;
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h0, comp, on, yr + h0 * fr, yv + h0 * fv, ym + h0 * fm, f1r, f1v, f1m, err);
+        const double d2 = rms7((f1r - fr) / scr, (f1v - fv) / scv, (f1m - fm) / scm) / h0;
         const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(1.0, a.max_step));
     }
@@ -224,48 +224,38 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         if (t_new - t_bound > 0.0) t_new = t_bound;
         h = t_new - t;
         const double h_try = fabs(h);
-        double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[1] * h, yt, K1, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[2][0] + K1[i] * RK_A[2][1]) * h;
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[2] * h, yt, K2, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[3][0] + K1[i] * RK_A[3][1] + K2[i] * RK_A[3][2]) * h;
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[3] * h, yt, K3, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-            yt[i] = y[i] + (f[i] * RK_A[4][0] + K1[i] * RK_A[4][1] + K2[i] * RK_A[4][2] + K3[i] * RK_A[4][3]) * h;
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[4] * h, yt, K4, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-            yt[i] = y[i] + (f[i] * RK_A[5][0] + K1[i] * RK_A[5][1] + K2[i] * RK_A[5][2] + K3[i] * RK_A[5][3] +
-                            K4[i] * RK_A[5][4]) * h;
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[5] * h, yt, K5, err);
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-            yn[i] = y[i] + h * (f[i] * RK_B[0] + K1[i] * RK_B[1] + K2[i] * RK_B[2] + K3[i] * RK_B[3] + K4[i] * RK_B[4] +
-                                K5[i] * RK_B[5]);
-        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h, yn, K6, err);
-        double eh[7], ssq = 0.0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const double e = f[i] * RK_E[0] + K1[i] * RK_E[1] + K2[i] * RK_E[2] + K3[i] * RK_E[3] + K4[i] * RK_E[4] +
-                             K5[i] * RK_E[5] + K6[i] * RK_E[6];
-            eh[i] = e * h; ssq += eh[i] * eh[i];
-        }
+        // the six stages, each of this lane's three components with the arithmetic of the one-lane form
+        double Kr[6], Kv[6], Km[6];
+#define MPCX_STAGE(S, EXPR_R, EXPR_V, EXPR_M)                                                                            \
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + RK_C[S] * h, comp, on, yr + (EXPR_R) * h, yv + (EXPR_V) * h, ym + (EXPR_M) * h, \
+                              Kr[S - 1], Kv[S - 1], Km[S - 1], err);
+        MPCX_STAGE(1, fr * RK_A[1][0], fv * RK_A[1][0], fm * RK_A[1][0])
+        MPCX_STAGE(2, fr * RK_A[2][0] + Kr[0] * RK_A[2][1], fv * RK_A[2][0] + Kv[0] * RK_A[2][1], fm * RK_A[2][0] + Km[0] * RK_A[2][1])
+        MPCX_STAGE(3, fr * RK_A[3][0] + Kr[0] * RK_A[3][1] + Kr[1] * RK_A[3][2], fv * RK_A[3][0] + Kv[0] * RK_A[3][1] + Kv[1] * RK_A[3][2],
+                   fm * RK_A[3][0] + Km[0] * RK_A[3][1] + Km[1] * RK_A[3][2])
+        MPCX_STAGE(4, fr * RK_A[4][0] + Kr[0] * RK_A[4][1] + Kr[1] * RK_A[4][2] + Kr[2] * RK_A[4][3],
+                   fv * RK_A[4][0] + Kv[0] * RK_A[4][1] + Kv[1] * RK_A[4][2] + Kv[2] * RK_A[4][3],
+                   fm * RK_A[4][0] + Km[0] * RK_A[4][1] + Km[1] * RK_A[4][2] + Km[2] * RK_A[4][3])
+        MPCX_STAGE(5, fr * RK_A[5][0] + Kr[0] * RK_A[5][1] + Kr[1] * RK_A[5][2] + Kr[2] * RK_A[5][3] + Kr[3] * RK_A[5][4],
+                   fv * RK_A[5][0] + Kv[0] * RK_A[5][1] + Kv[1] * RK_A[5][2] + Kv[2] * RK_A[5][3] + Kv[3] * RK_A[5][4],
+                   fm * RK_A[5][0] + Km[0] * RK_A[5][1] + Km[1] * RK_A[5][2] + Km[2] * RK_A[5][3] + Km[3] * RK_A[5][4])
+#undef MPCX_STAGE
+        const double ynr = yr + h * (fr * RK_B[0] + Kr[0] * RK_B[1] + Kr[1] * RK_B[2] + Kr[2] * RK_B[3] + Kr[3] * RK_B[4] + Kr[4] * RK_B[5]);
+        const double ynv = yv + h * (fv * RK_B[0] + Kv[0] * RK_B[1] + Kv[1] * RK_B[2] + Kv[2] * RK_B[3] + Kv[3] * RK_B[4] + Kv[4] * RK_B[5]);
+        const double ynm = ym + h * (fm * RK_B[0] + Km[0] * RK_B[1] + Km[1] * RK_B[2] + Km[2] * RK_B[3] + Km[3] * RK_B[4] + Km[4] * RK_B[5]);
+        prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t + h, comp, on, ynr, ynv, ynm, Kr[5], Kv[5], Km[5], err);
+        const double ehr = (fr * RK_E[0] + Kr[0] * RK_E[1] + Kr[1] * RK_E[2] + Kr[2] * RK_E[3] + Kr[3] * RK_E[4] + Kr[4] * RK_E[5] + Kr[5] * RK_E[6]) * h;
+        const double ehv = (fv * RK_E[0] + Kv[0] * RK_E[1] + Kv[1] * RK_E[2] + Kv[2] * RK_E[3] + Kv[3] * RK_E[4] + Kv[4] * RK_E[5] + Kv[5] * RK_E[6]) * h;
+        const double ehm = (fm * RK_E[0] + Km[0] * RK_E[1] + Km[1] * RK_E[2] + Km[2] * RK_E[3] + Km[3] * RK_E[4] + Km[4] * RK_E[5] + Km[5] * RK_E[6]) * h;
+        const double ssq = quad_sum((on ? ehr * ehr + ehv * ehv : 0.0) + (lane4 == 0 ? ehm * ehm : 0.0));
         // scipy's error norm divides each component by atol + max(|y|, |y_new|) rtol >= atol.  If even the bound
         // rms(e h) / atol is below 0.4 the exact norm is below 0.5 (and below 1) whatever it is, which is all the
         // controller asks of it when the step was max_step long (see below): no divisions, no square roots then.
         const bool surely_small = (ssq < 7.0 * (0.4 * atol) * (0.4 * atol)) && h_try >= a.max_step;
         double en = 0.25;
-        if (!surely_small) {
-            double ev[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) ev[i] = eh[i] / (atol + fmax(fabs(y[i]), fabs(yn[i])) * rtol);
-            en = rms7(ev);
-        }
+        if (!surely_small)
+            en = rms7(ehr / (atol + fmax(fabs(yr), fabs(ynr)) * rtol), ehv / (atol + fmax(fabs(yv), fabs(ynv)) * rtol),
+                      ehm / (atol + fmax(fabs(ym), fabs(ynm)) * rtol));
         if (en < 1.0) {
             // scipy: factor = min(MAX_FACTOR, SAFETY * en^-0.2) (1 if the step before was rejected), h_abs = h_try * factor,
             // then h_abs is clipped to max_step at the top of the next step.  When this step already was max_step long
@@ -283,12 +273,10 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
                 const double te = (ei == n_eval - 1 && n_eval > 1) ? 1.0 : (double)ei * estep + 0.0;
                 if (te > t_new) break;
                 const double x = (te - t) / h;
-                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const double kk[7] = {f[i], K1[i], K2[i], K3[i], K4[i], K5[i], K6[i]};
+                const double pw[4] = {x, x * x, (x * x) * x, ((x * x) * x) * x};
+                auto dense = [&](double f0, const double (&K)[6], double y0) {
+                    const double kk[7] = {f0, K[0], K[1], K[2], K[3], K[4], K[5]};
                     double acc = 0.0;
-                    const double pw[4] = {p1, p2, p3, p4};
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         double q = 0.0;
@@ -296,13 +284,15 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
                         for (int j = 0; j < 7; ++j) q += kk[j] * RK_P[j][cc];
                         acc += q * pw[cc];
                     }
-                    yo[(size_t)i * ld + ei] = h * acc + y[i];
-                }
+                    return h * acc + y0;
+                };
+                const double orr = dense(fr, Kr, yr), ov = dense(fv, Kv, yv), om = dense(fm, Km, ym);
+                if (on) { yo[(size_t)comp * ld + ei] = orr; yo[(size_t)(3 + comp) * ld + ei] = ov; }
+                if (lane4 == 0) yo[(size_t)6 * ld + ei] = om;
                 ++ei;
             }
             t = t_new;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) { y[i] = yn[i]; f[i] = K6[i]; }
+            yr = ynr; yv = ynv; ym = ynm; fr = Kr[5]; fv = Kv[5]; fm = Km[5];
             ++nsteps;
         } else {
             h_abs = h_try * fmax(RK_MIN_FACTOR, RK_SAFETY * pow(en, -0.2));
@@ -310,8 +300,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         }
     }
     if (t != t_bound && err == 0) err = MPCX_ST_STEP;
-    a.status[sat] = err;
-    a.nsteps[sat] = nsteps;
+    if (lane4 == 0) { a.status[sat] = err; a.nsteps[sat] = nsteps; }
 }
 
 // Discretizer.extract_uk (linearize_discretize.py:393-411) of a SequenceController played over its own horizon
@@ -366,7 +355,7 @@ extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval,
     if ((ctrl_kind == MPCX_CTRL_CONSTANT || ctrl_kind == MPCX_CTRL_TANGENTIAL) && !ctrl_vec) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: thrust parameters missing");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
     PropArgs a{S, n_eval, flags, ctrl_kind, Ku, n_evals, Kus, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
-    const dim3 grid((S + 63) / 64), block(64);
+    const dim3 grid((S + 15) / 16), block(64);            // 16 satellites (quads) per wave
     hipStream_t st = (hipStream_t)stream;
 #define MPCX_PROP_LAUNCH(KIND, FLAGS) hipLaunchKernelGGL((propagate_kernel<KIND, FLAGS>), grid, block, 0, st, a)
 #define MPCX_PROP_FLAGS(KIND)                                                                                         \
