@@ -142,6 +142,14 @@ typedef struct {
  * points read tf_out as an input too in this mode. */
 #define MPCX_SOLVE_FIXED_TF 4
 
+/* ONE final time for all S satellites of the call: the NLP of a reference Optimizer that holds several satellites
+ * (optimizer.py:287: a single tf Var; its trust-region term :311,322 and the dynamics' Sigma_k tf :336 for every satellite,
+ * the range constraint :588 once), solved as one problem -- one barrier parameter, one step length, one convergence test,
+ * the tf row of every Newton system assembled across the satellites -- in a single cooperative launch with one workgroup per
+ * satellite.  tf_out[s] is the same for every s (get_solved_tf ignores s, :199-203); status, iters, kkt are the launch's.
+ * S is limited to the workgroups the device holds at once (2048 on MI355X); no ragged batches. */
+#define MPCX_SOLVE_SHARED_TF 8
+
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 size_t mpcx_solve_workspace_bytes(int S, int K);
 size_t mpcx_mpc_step_workspace_bytes(int S, int K);

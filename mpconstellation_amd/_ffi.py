@@ -182,7 +182,7 @@ def iptr(a):
 
 
 SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
-SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF = 1, 2, 4          # mpcx_solve_opts.flags (include/mpcx.h)
+SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF = 1, 2, 4, 8          # mpcx_solve_opts.flags (include/mpcx.h)
 
 
 def check_solver_keywords(solver):

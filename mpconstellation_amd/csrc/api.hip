@@ -38,6 +38,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
     c->copier = nullptr;
     c->counter = nullptr; c->n_slots = prop.multiProcessorCount * 8;
+    c->red = nullptr; c->red_cap = 0; c->coop_max = 0;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -59,6 +60,7 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->nreg) (void)hipFree(ctx->nreg);
     if (ctx->counter) (void)hipFree(ctx->counter);
+    if (ctx->red) (void)hipFree(ctx->red);
     pool_free(ctx->pool_dev); pool_free(ctx->pool_host);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     delete ctx->copier;

@@ -65,7 +65,8 @@ constexpr int kFbN = 8;
 struct SolveOpts {
     double min_mass, u_max, r_min, r_max, eps_r, eps_vr, eps_vn, eps_vt, tf_max, w_nu, w_tr, tol, acc_tol;
     int max_iter, acc_iter, n_refine, linvt;    // linvt: the linearised tangential pair (optimizer.py:471-489) instead of the quartic
-    int fixed_tf, pad;                          // fixed_tf: tf is held at the value passed in tf_out (MPCX_SOLVE_FIXED_TF)
+    int fixed_tf, shared_tf;                    // fixed_tf: tf is held at the value passed in tf_out (MPCX_SOLVE_FIXED_TF);
+                                                // shared_tf: ONE tf for all satellites of the launch (MPCX_SOLVE_SHARED_TF)
 };
 
 struct SolveArgs {
@@ -76,6 +77,9 @@ struct SolveArgs {
     double *X, *U, *NU, *tf_out, *kkt;
     int32_t *status, *iters;
     const int32_t *order;     // workgroup b solves satellite order[b]; nullptr = index order
+    // shared-tf launches (solve_shared_kernel): per-block reduction slots [2][S][GR_N], arrival counter, abort flag
+    double *red;
+    int32_t *arrive, *abort_flag;
     int32_t *counter;         // work queue of the persistent workgroups: next position of the launch order (zeroed per launch)
     int32_t *nreg;            // [S][2]: iterations whose direction needed delta_w > 0, and the first of them (-1: none)
     double *ws;
@@ -97,6 +101,8 @@ struct SatData {
     double aT[8][7], bT[8];
     int nT, linvt;           // terminal inequality rows (6, or 8 with the linearised tangential pair); convex variant flag
     int fixed_tf;            // tf is a constant of the problem: no range constraint, no stationarity row, dtf = 0
+    int shared;              // tf is ONE variable shared by the satellites of the launch: its row is assembled across workgroups
+    double tS, rS;           // shared tf: this satellite's share of the tf pivot (local Schur complement) and of its right-hand side
     double w_vt, gh_vt, zeta_vt;   // convex variant: weight, gradient coefficient and border unknown of the tangential pair
     double b_u, b_rmax, b_rmin, b_rfmax, b_tf[2], vt_des, w_tr, w_nu, tfbar;
     // Newton-step globals
@@ -244,7 +250,7 @@ __device__ __noinline__ void build_terminal(const double *xK, double mu_grav, do
     double gRbar = 0.0, gNbar = 0.0;
     for (int i = 0; i < 6; ++i) { gRbar += gR[i] * xK[i]; gNbar += gN[i] * xK[i]; }
     for (int i = 0; i < 8; ++i) { sd.bT[i] = 0.0; for (int j = 0; j < 7; ++j) sd.aT[i][j] = 0.0; }
-    sd.linvt = o.linvt; sd.nT = o.linvt ? 8 : 6; sd.fixed_tf = o.fixed_tf;
+    sd.linvt = o.linvt; sd.nT = o.linvt ? 8 : 6; sd.fixed_tf = o.fixed_tf | o.shared_tf; sd.shared = o.shared_tf;
     sd.w_vt = 0.0; sd.gh_vt = 0.0; sd.zeta_vt = 0.0;
     for (int j = 0; j < 3; ++j) sd.aT[0][j] = -rh[j];
     sd.bT[0] = relax(-(r_des - o.eps_r));
@@ -694,6 +700,14 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
 __device__ __forceinline__ int n_ineq(int K, int nT, int fixed_tf) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + (fixed_tf ? 0 : 2); }
 
 // ipopt's scaled optimality error E_mu from one residual evaluation: max_i |s_i z_i - mu| = max(pmax - mu, mu - pmin)
+__device__ double scaled_error_n(const ResAcc &r, int nz, int nl, double mu)
+{
+    const double smax = 100.0;
+    const double sdl = fmax(smax, (r.zsum + r.lsum) / (double)(nz + nl)) / smax;
+    const double sc = fmax(smax, r.zsum / (double)nz) / smax;
+    const double comp = fmax(r.prod_max - mu, mu - r.prod_min);
+    return fmax(fmax(r.dual_max / sdl, r.prim_max), comp / sc);
+}
 __device__ double scaled_error(const ResAcc &r, int K, int nT, int fixed_tf, double mu)
 {
     const double smax = 100.0;
@@ -945,7 +959,11 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         full += sd.gam * sd.avt[i] * sd.avt[j];
         sd.WxKsoft[lane] = soft; sd.WxK[lane] = full;
     }
-    if (lane == 0 && sd.fixed_tf) { sd.Wtf = 1.0; sd.gtf = 0.0; sd.sigmax = sigmax; }
+    if (lane == 0 && sd.shared) {
+        // this satellite's share of the tf row: the trust-region term w_tr (tf - tf_bar)^2 (optimizer.py:311,322); the 1 of
+        // the objective, the range constraint's barrier terms and delta_w belong to the launch as a whole (solve_satellite)
+        sd.Wtf = 2.0 * sd.w_tr; sd.gtf = 2.0 * sd.w_tr * (s.itg[G_TF] - sd.tfbar); sd.sigmax = sigmax;
+    } else if (lane == 0 && sd.fixed_tf) { sd.Wtf = 1.0; sd.gtf = 0.0; sd.sigmax = sigmax; }
     else if (lane == 0) {
         const double tf = s.itg[G_TF];
         double W = 2.0 * sd.w_tr + delta_w, g = 1.0 + 2.0 * sd.w_tr * (tf - sd.tfbar);
@@ -1841,6 +1859,222 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
     __syncthreads();
 }
 
+
+// ---- launch-wide reductions of the shared-tf mode (solve_shared_kernel: every workgroup resident, cooperative launch) ----
+// A reduction is also the barrier between two phases of the lock-step iteration: every workgroup publishes GR_N values,
+// waits until all S have arrived, and folds the S contributions in a fixed order (same result on every workgroup, the
+// same from run to run).  Slots alternate between two rings: a workgroup can be at most one phase ahead of the slowest.
+constexpr int GR_SUM = 6, GR_MAX = 3, GR_MIN = 3, GR_N = GR_SUM + GR_MAX + GR_MIN;
+constexpr long kSpinMax = 20000000;        // ~ seconds: a workgroup that never arrives aborts the launch instead of hanging it
+struct GridSync {
+    double *red;
+    int32_t *arrive, *abort_flag;
+    int S, blk, phase;
+    bool aborted;
+};
+
+__device__ __noinline__ void grid_reduce(GridSync &g, double (&v)[GR_N], int lane)
+{
+    double *slot = g.red + ((size_t)(g.phase & 1) * g.S + g.blk) * GR_N;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < GR_N; ++j) __hip_atomic_store(slot + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) {
+        __hip_atomic_fetch_add(g.arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = (g.phase + 1) * g.S;
+        long spins = 0;
+        while (__hip_atomic_load(g.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (++spins > kSpinMax) { __hip_atomic_store(g.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __syncthreads();
+    __threadfence();
+    if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) g.aborted = true;
+    const double *base = g.red + (size_t)(g.phase & 1) * g.S * GR_N;
+#pragma unroll
+    for (int j = 0; j < GR_N; ++j) {
+        double acc = (j < GR_SUM) ? 0.0 : (j < GR_SUM + GR_MAX ? -1e300 : 1e300);
+        for (int b = lane; b < g.S; b += 64) {
+            const double x = __hip_atomic_load(base + (size_t)b * GR_N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc = (j < GR_SUM) ? acc + x : (j < GR_SUM + GR_MAX ? fmax(acc, x) : fmin(acc, x));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double x = __shfl_xor(acc, o, 64);
+            acc = (j < GR_SUM) ? acc + x : (j < GR_SUM + GR_MAX ? fmax(acc, x) : fmin(acc, x));
+        }
+        v[j] = acc;
+    }
+    ++g.phase;
+    __syncthreads();
+}
+__device__ __forceinline__ void gr_clear(double (&v)[GR_N])
+{
+#pragma unroll
+    for (int j = 0; j < GR_N; ++j) v[j] = (j < GR_SUM) ? 0.0 : (j < GR_SUM + GR_MAX ? -1e300 : 1e300);
+}
+
+// The border of a satellite whose tf is shared by the launch.  Same matrix as border_factor builds, the dtf row carrying
+// only this satellite's share of the tf row (W_tf = 2 w_tr, its -Sigma.lambda terms): the six constraint-type pivots are
+// eliminated here, the seventh -- the Schur complement of dtf -- is this satellite's ADDEND to the launch's tf pivot
+// (sd.tS) and is neither tested nor inverted.  Returns false if a constraint pivot has the wrong sign.
+__device__ __noinline__ bool border_factor_shared(SatData &sd, int lane)
+{
+    if (lane < NBD * NBD) {
+        const int p = lane / NBD, q = lane - NBD * p;
+        const int c = border_channel(q);
+        double v;
+        if (p < NBD - 1) {
+            const double *a = (p == 0) ? sd.avt : sd.ta[p - 1];
+            v = 0.0;
+#pragma unroll
+            for (int l = 0; l < 7; ++l) v += a[l] * sd.xK[c][l];
+        } else v = (q == NBD - 1 ? sd.Wtf : 0.0) - sd.siglam[c];
+        sd.Mb[p][q] = v; sd.Sb[p][q] = v;
+    }
+    __syncthreads();
+    double S[NBD][NBD];
+#pragma unroll
+    for (int p = 0; p < NBD; ++p)
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) S[p][q] = sd.Mb[p][q];
+#pragma unroll
+    for (int p = 0; p < NBD - 1; ++p) {
+        bool eq;
+        const double iw = border_iw(sd, p, eq);
+        const bool on = iw > 0.0;
+        if (eq) continue;
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) if (!on && q != p) { S[p][q] = 0.0; S[q][p] = 0.0; }
+        S[p][p] = on ? S[p][p] - iw : -1.0;
+    }
+    bool ok = true;
+    double rd[NBD];
+#pragma unroll
+    for (int p = 0; p < NBD - 1; ++p) {
+        const double d = S[p][p];
+        if (!(d < 0.0)) ok = false;
+        rd[p] = 1.0 / d;
+#pragma unroll
+        for (int i = p + 1; i < NBD; ++i) {
+            const double m = S[i][p] * rd[p];
+#pragma unroll
+            for (int j = p + 1; j < NBD; ++j) S[i][j] -= m * S[p][j];
+            S[i][p] = m;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < NBD - 1; ++p) {
+            sd.Mb[p][p] = rd[p];
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) sd.Mb[i][p] = S[i][p];
+        }
+        sd.tS = S[NBD - 1][NBD - 1];
+    }
+    __syncthreads();
+    return ok;
+}
+
+// Solve with the shared tf: forward substitution here, dtf = (sum of the satellites' right-hand-side shares + the launch's
+// own part r_glob) / (sum of their pivot shares + W_glob) across the launch, back substitution here; then one step of
+// iterative refinement of the whole bordered system, its tf row again summed across the launch.  `fail`: this satellite
+// cannot contribute (breakdown upstream).  Returns false -- on every workgroup alike -- if any satellite failed or the
+// launch's tf pivot is not positive (wrong inertia: regularise).
+__device__ __noinline__ bool border_solve_shared(SatData &sd, GridSync &g, double gtf_share, double rvt_rhs, const double *gex,
+                                                 double W_glob, double r_glob, bool fail, int lane)
+{
+    double rb[NBD], v[NBD], x[NBD];
+#pragma unroll
+    for (int p = 0; p < NBD - 1; ++p) {
+        const double *a = (p == 0) ? sd.avt : sd.ta[p - 1];
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) acc += a[l] * sd.xK[0][l];
+        rb[p] = -acc;
+    }
+    rb[0] += rvt_rhs;
+    double iw[NBD - 1];
+    bool eqr[NBD - 1];
+#pragma unroll
+    for (int p = 0; p < NBD - 1; ++p) {
+        iw[p] = border_iw(sd, p, eqr[p]);
+        if (p >= 1) rb[p] = (iw[p] > 0.0) ? rb[p] - gex[p - 1] * iw[p] : 0.0;
+        else if (!eqr[0] && !(iw[0] > 0.0)) rb[0] = 0.0;
+    }
+    rb[NBD - 1] = -gtf_share + sd.siglam[0];
+    auto forward = [&](double (&w)[NBD]) {
+#pragma unroll
+        for (int p = 0; p < NBD - 1; ++p)
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) w[i] -= sd.Mb[i][p] * w[p];
+    };
+    auto backward = [&](double (&w)[NBD], double dtf) {      // w: forward-substituted; on return the solution
+        w[NBD - 1] = dtf;
+#pragma unroll
+        for (int p = NBD - 2; p >= 0; --p) {
+            double acc = w[p] * sd.Mb[p][p];
+#pragma unroll
+            for (int i = p + 1; i < NBD; ++i) acc -= sd.Mb[i][p] * w[i];
+            w[p] = acc;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) v[p] = rb[p];
+    forward(v);
+    double gr[GR_N];
+    gr_clear(gr);
+    gr[0] = fail ? 0.0 : sd.tS; gr[1] = fail ? 0.0 : v[NBD - 1]; gr[2] = fail ? 1.0 : 0.0;
+    grid_reduce(g, gr, lane);
+    const double D = gr[0] + W_glob;
+    if (g.aborted || gr[2] > 0.0 || !(D > 0.0)) return false;
+    const double dtf = (gr[1] + r_glob) / D;
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) x[p] = v[p];
+    backward(x, dtf);
+    // refinement: r = rb - S x with S rebuilt from the kept matrix (zeta rows in their 1/wex form, decoupled ones as -1);
+    // the tf row's residual is summed across the launch together with the launch's own part r_glob - W_glob dtf
+    double r[NBD];
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) {
+        double acc = rb[p];
+#pragma unroll
+        for (int q = 0; q < NBD; ++q) {
+            double sv = sd.Sb[p][q];
+            const int pc = p < NBD - 1 ? p : 0, qc = q < NBD - 1 ? q : 0;
+            const bool zp = p < NBD - 1 && !eqr[pc], zq = q < NBD - 1 && !eqr[qc];
+            const bool offp = zp && !(iw[pc] > 0.0), offq = zq && !(iw[qc] > 0.0);
+            if (p == q && zp) sv = offp ? -1.0 : sv - iw[pc];
+            else if (offp || offq) sv = 0.0;
+            acc -= sv * x[q];
+        }
+        r[p] = acc;
+    }
+    forward(r);
+    gr_clear(gr);
+    gr[1] = r[NBD - 1];
+    grid_reduce(g, gr, lane);
+    if (g.aborted) return false;
+    const double ddtf = (gr[1] + (r_glob - W_glob * dtf)) / D;
+    backward(r, ddtf);
+#pragma unroll
+    for (int p = 0; p < NBD; ++p) x[p] += r[p];
+    __syncthreads();
+    if (lane == 0) {
+        sd.sol[0] = x[NBD - 1];
+#pragma unroll
+        for (int p = 0; p < NBD - 1; ++p) sd.sol[1 + p] = x[p];
+    }
+    __syncthreads();
+    return true;
+}
+
 // Residual of the reduced KKT system at the current direction -> rhs record of channel 0
 // ("Linear solve").  Stage-parallel.  Returns gtf_rhs, rvt_rhs and gex[] = wex * (residual of the zeta rows).
 // The border unknowns zeta_t of the stiff terminal terms are part of the direction being refined (sd.zeta): the x_K row
@@ -2158,8 +2392,40 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 2     // waves per SIMD the register allocation is bounded for (256 registers; 3 was measured slower)
 #endif
+
+// Shared tf: one residual evaluation of the whole launch from the satellites' own (grid_reduce) plus the rows and pairs
+// that belong to the launch: tf's stationarity row 1 + sum_s g_s - z_0 + z_1 and the two sides of its range constraint
+// (optimizer.py:588) with slacks gs and multipliers gz.
+__device__ __forceinline__ void shared_fold(GridSync &g, ResAcc &r, double tf, const double (&b_tf)[2], const double (&gs)[2], const double (&gz)[2],
+                                            double mu, int lane)
+{
+    double v[GR_N];
+    gr_clear(v);
+    v[0] = r.sq; v[1] = r.zsum; v[2] = r.lsum; v[3] = r.prod_sum; v[4] = r.g_tf;
+    v[GR_SUM] = r.dual_max; v[GR_SUM + 1] = r.prim_max; v[GR_SUM + 2] = r.prod_max;
+    v[GR_SUM + GR_MAX] = r.prod_min;
+    grid_reduce(g, v, lane);
+    r.sq = v[0]; r.zsum = v[1]; r.lsum = v[2]; r.prod_sum = v[3]; r.g_tf = v[4];
+    r.dual_max = v[GR_SUM]; r.prim_max = v[GR_SUM + 1]; r.prod_max = v[GR_SUM + 2]; r.prod_min = v[GR_SUM + GR_MAX];
+    const double gtf = 1.0 + r.g_tf - gz[0] + gz[1];
+    r.dual_max = fmax(r.dual_max, fabs(gtf)); r.sq += gtf * gtf;
+    const double gv[2] = {-tf - b_tf[0], tf - b_tf[1]};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double pr = gv[j] + gs[j], sz = gs[j] * gz[j], q = sz - mu;
+        r.prim_max = fmax(r.prim_max, fabs(pr)); r.sq += pr * pr + q * q;
+        r.zsum += fabs(gz[j]); r.prod_min = fmin(r.prod_min, sz); r.prod_max = fmax(r.prod_max, sz); r.prod_sum += sz;
+    }
+}
+
 // One satellite from the problem constants to its results; `slot` selects the workspace (see solve_kernel).
-__device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sat, const int slot, SatData &sd, Scratch &w, const int lane)
+// SHARED (solve_shared_kernel): the satellites of the launch share ONE final time (several satellites in one reference
+// Optimizer, optimizer.py:287,311,322,336).  Every workgroup runs this same iteration in lock step: barrier parameter, step
+// length, line-search decisions, regularisation and the convergence test come from launch-wide reductions (grid_reduce),
+// the tf row of the Newton system is assembled across the launch (border_solve_shared), and the launch-wide variables --
+// tf's range-constraint slacks and multipliers -- are carried identically by every workgroup (gs, gz below).
+template <bool SHARED>
+__device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sat, const int slot, SatData &sd, Scratch &w, const int lane, GridSync *gsync = nullptr)
 {
     PT_DECL
     const int Kmax = a.K;
@@ -2214,12 +2480,22 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
     }
     __syncthreads();
+    double gr[GR_N];                // (shared tf: operands / results of the launch-wide reductions)
+    if (SHARED) {
+        // the launch is ONE problem: empty if any satellite's constraint set is, or tf's own range (which build_terminal
+        // leaves out of the per-satellite check when tf is not that satellite's variable)
+        gr_clear(gr);
+        gr[GR_SUM] = fmax(sd.infeas, -(sd.b_tf[0] + sd.b_tf[1]));
+        grid_reduce(*gsync, gr, lane);
+        if (lane == 0) sd.infeas = gsync->aborted ? 1.0 : gr[GR_SUM];
+        __syncthreads();
+    }
     if (sd.infeas > 0.0) {      // empty constraint set: the reference trajectory goes back unchanged, no iteration is spent
         for (int e = lane; e < 7 * Kmax; e += 64) { a.X[(size_t)sat * 7 * Kmax + e] = s.xbar[e]; a.NU[(size_t)sat * 7 * Kmax + e] = 0.0; }
         for (int e = lane; e < 3 * Kmax; e += 64) a.U[(size_t)sat * 3 * Kmax + e] = s.ubar[e];
         if (lane == 0) {
-            if (!sd.fixed_tf) a.tf_out[sat] = sd.tfbar; else a.tf_out[sat] = 0.0;      // (fixed tf: the slot returns g_s)
-            a.status[sat] = MPCX_ST_INFEASIBLE; a.iters[sat] = 0; a.kkt[sat] = sd.infeas;
+            if (!sd.fixed_tf || SHARED) a.tf_out[sat] = sd.tfbar; else a.tf_out[sat] = 0.0;      // (fixed tf: the slot returns g_s)
+            a.status[sat] = (SHARED && gsync->aborted) ? MPCX_ST_NUMERIC : MPCX_ST_INFEASIBLE; a.iters[sat] = 0; a.kkt[sat] = sd.infeas;
             if (a.nreg) { a.nreg[2 * sat] = 0; a.nreg[2 * sat + 1] = -1; }
         }
         return;
@@ -2272,7 +2548,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         }
         const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
         s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = kMuInit / s.itg[G_SRF];
-        const double tf = sd.fixed_tf ? a.tf_out[sat] : sd.tfbar;      // (fixed: the value to hold comes in through tf_out)
+        const double tf = (sd.fixed_tf && !SHARED) ? a.tf_out[sat] : sd.tfbar;      // (fixed: the value to hold comes in through tf_out)
         s.itg[G_TF] = tf;
         s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = kMuInit / s.itg[G_STF];
         s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = kMuInit / s.itg[G_STF + 1];
@@ -2280,7 +2556,17 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     __syncthreads();
 
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
-    const int nzc = n_ineq(K, sd.nT, sd.fixed_tf);
+    // (shared tf: the counts of the whole launch -- S satellites without their own tf rows plus tf's two range inequalities)
+    const int nzc = SHARED ? a.S * n_ineq(K, sd.nT, 1) + 2 : n_ineq(K, sd.nT, sd.fixed_tf);
+    const int nlc = (SHARED ? a.S : 1) * (7 * (K - 1) + (sd.nT == 6 ? 1 : 0));
+    // shared tf: slacks / multipliers of 0 <= tf <= tf_max, their trial values, and the launch's part of the tf row
+    double gs[2] = {0.0, 0.0}, gz[2] = {0.0, 0.0}, gst[2] = {0.0, 0.0}, gzt[2] = {0.0, 0.0}, gds[2] = {0.0, 0.0}, gdz[2] = {0.0, 0.0};
+    if (SHARED) {
+        const double tf = sd.tfbar;
+        gs[0] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); gz[0] = kMuInit / gs[0];
+        gs[1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); gz[1] = kMuInit / gs[1];
+    }
+    const double b_tf2[2] = {sd.b_tf[0], sd.b_tf[1]};
     int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0, n_reg = 0, first_reg = -1;
     // second safeguard of the adaptive barrier rule (the first is the kMuErr bound below): after kFbN consecutive accepted
     // steps shorter than kFbAlpha -- the iterate is jammed against its bounds -- mu is lifted to kFbBoost * mean(s z) and
@@ -2295,9 +2581,11 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     PT_BEGIN
     eval_residual<false>(s, sd, 0.0, 0.0, 0.0, lane, r0);
     PT_END(0)
+    if (SHARED) shared_fold(*gsync, r0, sd.tfbar, b_tf2, gs, gz, 0.0, lane);
     for (int iter = 0;; ++iter) {
         it_count = iter;
-        E0 = scaled_error(r0, K, sd.nT, sd.fixed_tf, 0.0);
+        E0 = scaled_error_n(r0, nzc, nlc, 0.0);
+        if (SHARED && gsync->aborted) { status = MPCX_ST_NUMERIC; break; }
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
         n_acc = (E0 <= o.acc_tol) ? n_acc + 1 : 0;
@@ -2313,7 +2601,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         if (!mono) mu = fmax(fmax(kSigma * mu_cur, o.tol / 10.0), kMuErr * E0);
         else {
             // mu moves on only when the barrier problem is solved to E_mu <= 10 mu: mu <- max(tol/10, min(0.2 mu, mu^1.5))
-            for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error(r0, K, sd.nT, sd.fixed_tf, mu) <= 10.0 * mu; ++lv)
+            for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error_n(r0, nzc, nlc, mu) <= 10.0 * mu; ++lv)
                 mu = fmax(o.tol / 10.0, fmin(0.2 * mu, mu * sqrt(mu)));
         }
         // Newton direction, with Hessian regularisation retries on breakdown
@@ -2331,6 +2619,61 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
             first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
+            if (SHARED) {
+                // ---- the same direction computation in lock step with the other satellites of the launch ----
+                GridSync &g = *gsync;
+                if (g.aborted) break;
+                // the launch's own part of the tf row: the 1 of the objective, the barrier terms of 0 <= tf <= tf_max, delta_w
+                double W_glob = delta_w, g_glob = 1.0, sig_tf = 0.0;
+                const double tfc = s.itg[G_TF];
+                const double gvv[2] = {-tfc - sd.b_tf[0], tfc - sd.b_tf[1]};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double sig = gz[j] / gs[j], zh = mu / gs[j] + sig * (gvv[j] + gs[j]);
+                    W_glob += sig; g_glob += (j == 0 ? -zh : zh); sig_tf = fmax(sig_tf, sig);
+                }
+                double twmax = fmax(sd.sigmax, sig_tf);
+                for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
+                gr_clear(gr); gr[GR_SUM] = twmax;
+                grid_reduce(g, gr, lane);                         // every satellite refines, or none
+                const int passes = 1 + ((delta_w == 0.0 && gr[GR_SUM] > kRefineTw) ? o.n_refine : 0);
+                if (passes > 1) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);
+                bool okl = riccati_factor(s, sd, w, lane, true, passes > 1);     // (a local breakdown is reported through the border's reduction)
+                bool ok = true;
+                for (int pass = 0; pass < passes && ok; ++pass) {
+                    if (okl && pass > 0) { reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gex); sweep_backward(s, sd, w, 0, 1, lane); }
+                    if (okl) {
+                        sweep_forward(s, sd, w, 0, (pass == 0) ? NCH : 1, lane);
+                        if (pass == 0) okl = border_factor_shared(sd, lane);
+                    }
+                    const double dtf_cur = (pass == 0) ? 0.0 : s.drg[G_TF];
+                    ok = border_solve_shared(sd, g, gtf_rhs, rvt_rhs, gex, W_glob, -(g_glob + W_glob * dtf_cur), !okl, lane);
+                    if (!ok) break;
+                    combine_channels(s, sd, (double *)&w, lane, pass == 0);
+                }
+                if (ok) {
+                    bool fin = true;
+                    alpha = finish_direction(s, sd, mu, tau, lane, fin);
+                    const double dtf = s.drg[G_TF];
+                    const double dgv[2] = {-dtf, dtf};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {       // the range constraint's pairs: direction and fraction to the boundary
+                        const PairDir q = pair_dir(gs[j], gz[j], gvv[j], dgv[j], mu);
+                        gds[j] = q.ds; gdz[j] = q.dz;
+                        if (q.ds < 0.0) alpha = fmin(alpha, -tau * gs[j] / q.ds);
+                        if (q.dz < 0.0) alpha = fmin(alpha, -tau * gz[j] / q.dz);
+                    }
+                    gr_clear(gr); gr[0] = fin ? 0.0 : 1.0; gr[GR_SUM + GR_MAX] = alpha;
+                    grid_reduce(g, gr, lane);                     // one step length for the whole launch
+                    alpha = gr[GR_SUM + GR_MAX];
+                    ok = (gr[0] == 0.0) && !g.aborted;
+                }
+                if (ok) have_dir = true;
+                else if (g.aborted) break;
+                else if (delta_w == 0.0) delta_w = (dw_last == 0.0) ? kDwFirst : fmax(kDwMin, dw_last / 3.0);
+                else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
+                continue;
+            }
             // iterative refinement only once a barrier weight (terminal rank-1 terms, stage balls and planes, the tf
             // bounds) is stiff enough to cost digits
             double twmax = sd.sigmax;
@@ -2414,12 +2757,25 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         // left in the second iterate buffer
         const double mu_clip = fmax(mu, mu_cur);
         ResAcc rt;
+        // shared tf: the trial values of the range constraint's pairs (slack reset and multiplier safeguard like every
+        // other pair), then the launch's residual from the satellites' (a reduction: every workgroup decides alike)
+        auto shared_trial = [&]() {
+            const double tft = s.itg[G_TF] + alpha * s.drg[G_TF];
+            const double gvt[2] = {-tft - sd.b_tf[0], tft - sd.b_tf[1]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                gst[j] = fmax(gs[j] + alpha * gds[j], -gvt[j]);
+                gzt[j] = fmin(gz[j] + alpha * gdz[j], kKappaSigma * (mu_clip * rcp_pos(gst[j])));
+            }
+            shared_fold(*gsync, rt, tft, b_tf2, gst, gzt, mu, lane);
+        };
         bool have_trial = false;
         for (int ls = 0; ls < 30; ++ls) {
             if (0.5 * alpha < kAlphaFloor) break;      // a rejection could not shorten the step any more: take it
             PT_BEGIN
             eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
             PT_END(10)
+            if (SHARED) shared_trial();
             const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
             const bool cen = rt.prod_min >= kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc);
 #ifdef MPCX_ITER_LOG
@@ -2433,6 +2789,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             PT_BEGIN
             eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
             PT_END(9)
+            if (SHARED) shared_trial();
         }
 #ifdef MPCX_ITER_LOG
         // diagnostic build only: iteration log (mu, E0, accepted step, regularisation) into this satellite's X block
@@ -2441,6 +2798,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
         { gf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
+        if (SHARED) { gs[0] = gst[0]; gs[1] = gst[1]; gz[0] = gzt[0]; gz[1] = gzt[1]; }
         r0 = rt;
         r0.sq = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;
     }
@@ -2465,7 +2823,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         for (int i = 0; i < 3; ++i) a.U[(size_t)sat * 3 * Kmax + (size_t)i * Kmax + k] = 0.0;
     }
     if (lane == 0) {
-        a.tf_out[sat] = sd.fixed_tf ? r0.g_tf : s.itg[G_TF];
+        a.tf_out[sat] = (sd.fixed_tf && !SHARED) ? r0.g_tf : s.itg[G_TF];
         a.status[sat] = status;
         a.iters[sat] = it_count;
         a.kkt[sat] = E0;
@@ -2486,10 +2844,16 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 // counts are known).  A workgroup keeps ONE workspace slot for all its satellites: the solver's working set is
 // slots x 206 KB whatever the batch size (8192 satellites: 0.44 GB instead of 1.8 GB), and a slot's lines are rewritten
 // by the next satellite while they are still cached instead of being written back as dead data.
+// The two kernels' LDS working set: ONE pair of module-scope objects, so that it sits at the same LDS address in both and
+// the out-of-line phase functions (which take it by reference) keep addressing it with compile-time offsets -- with a
+// pair per kernel the addresses reach them as run-time pointers (measured: solve_kernel 6.85 -> 8.4 ms at S4096).
+__shared__ SatData g_sd;
+__shared__ Scratch g_w;
+
 __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
 {
-    __shared__ SatData sd;
-    __shared__ Scratch w;
+    SatData &sd = g_sd;
+    Scratch &w = g_w;
     __shared__ int next_item;
     const int lane = threadIdx.x;
     for (;;) {
@@ -2502,9 +2866,19 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
         //  out-of-bounds satellite)
         int sat = a.order ? a.order[b] : b;
         if ((unsigned)sat >= (unsigned)a.S) sat = b;
-        solve_satellite(a, sat, (int)blockIdx.x, sd, w, lane);
+        solve_satellite<false>(a, sat, (int)blockIdx.x, sd, w, lane);
         __syncthreads();
     }
+}
+
+// Shared final time: one workgroup per satellite, all resident (cooperative launch), one lock-step iteration.
+__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_shared_kernel(SolveArgs a)
+{
+    SatData &sd = g_sd;
+    Scratch &w = g_w;
+    const int lane = threadIdx.x;
+    GridSync g{a.red, a.arrive, a.abort_flag, a.S, (int)blockIdx.x, 0, false};
+    solve_satellite<true>(a, (int)blockIdx.x, (int)blockIdx.x, sd, w, lane, &g);
 }
 
 }  // namespace mpcx
@@ -2518,7 +2892,7 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
     d.eps_vr = o->eps_vr; d.eps_vn = o->eps_vn; d.eps_vt = o->eps_vt; d.tf_max = o->tf_max; d.w_nu = o->w_nu; d.w_tr = o->w_tr;
     d.tol = o->tol; d.acc_tol = o->acceptable_tol; d.max_iter = o->max_iter; d.acc_iter = o->acceptable_iter;
     d.n_refine = o->n_refine; d.linvt = (o->flags & MPCX_SOLVE_LINEAR_VT) ? 1 : 0;
-    d.fixed_tf = (o->flags & MPCX_SOLVE_FIXED_TF) ? 1 : 0; d.pad = 0;
+    d.fixed_tf = (o->flags & MPCX_SOLVE_FIXED_TF) ? 1 : 0; d.shared_tf = (o->flags & MPCX_SOLVE_SHARED_TF) ? 1 : 0;
     return d;
 }
 
@@ -2656,6 +3030,34 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
             hipLaunchKernelGGL(launch_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, ctx->prev_iters, ctx->order);
             a.order = ctx->order;
         }
+    }
+    if (opts->flags & MPCX_SOLVE_SHARED_TF) {
+        // one final time for the whole batch: a cooperative launch, one workgroup per satellite, all of them resident
+        if (Ks) return ctx_fail(ctx, MPCX_E_BADARG, "solve: MPCX_SOLVE_SHARED_TF needs the same node count for every satellite (no ragged batch)");
+        if (opts->flags & MPCX_SOLVE_FIXED_TF) return ctx_fail(ctx, MPCX_E_BADARG, "solve: MPCX_SOLVE_SHARED_TF and MPCX_SOLVE_FIXED_TF exclude each other");
+        if (ctx->coop_max == 0) {
+            int coop = 0, per_cu = 0;
+            MPCX_HIP(ctx, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device));
+            MPCX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_shared_kernel, 64, 0));
+            ctx->coop_max = coop ? per_cu * (ctx->n_slots / 8) : -1;
+        }
+        if (ctx->coop_max < 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: the device does not support cooperative launches (MPCX_SOLVE_SHARED_TF)");
+        if (S > ctx->coop_max) return ctx_fail(ctx, MPCX_E_BADARG, "solve: MPCX_SOLVE_SHARED_TF takes at most as many satellites as the device holds workgroups at once");
+        if (ctx->red_cap < S) {
+            if (ctx->red) (void)hipFree(ctx->red);
+            ctx->red = nullptr; ctx->red_cap = 0;
+            MPCX_HIP(ctx, hipMalloc((void **)&ctx->red, ((size_t)2 * S * GR_N + 2) * sizeof(double)));
+            ctx->red_cap = S;
+        }
+        a.red = ctx->red;
+        a.arrive = (int32_t *)(ctx->red + (size_t)2 * ctx->red_cap * GR_N);
+        a.abort_flag = a.arrive + 1;
+        a.counter = nullptr; a.order = nullptr;
+        MPCX_HIP(ctx, hipMemsetAsync(a.arrive, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
+        void *kargs[] = {(void *)&a};
+        MPCX_HIP(ctx, hipLaunchCooperativeKernel((const void *)solve_shared_kernel, dim3(S), dim3(64), kargs, 0, (hipStream_t)stream));
+        ctx->order_valid = 0;
+        return MPCX_OK;
     }
     if (!ctx->counter) MPCX_HIP(ctx, hipMalloc((void **)&ctx->counter, sizeof(int32_t)));
     MPCX_HIP(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(int32_t), (hipStream_t)stream));

@@ -44,11 +44,14 @@ def constraint_terms_batch(xbar, consts, r_des, options=None, device=0, linear_v
     return aT, bT, sc
 
 
-def _solver_flags(solver, linear_vt, fixed_tf=None):
+def _solver_flags(solver, linear_vt, fixed_tf=None, shared_tf=False):
     """linear_vt: the linearised tangential pair the reference keeps commented out (optimizer.py:471-489, 575-576;
     tolerance options['eps_vt']) instead of the exact equality it enables (:577) -- MPCX_SOLVE_LINEAR_VT.
-    fixed_tf: hold every satellite's final time at the given value(s) -- MPCX_SOLVE_FIXED_TF."""
+    fixed_tf: hold every satellite's final time at the given value(s) -- MPCX_SOLVE_FIXED_TF.
+    shared_tf: ONE final time for the whole batch, solved as one problem on the device -- MPCX_SOLVE_SHARED_TF."""
     solver = dict(solver)
+    if shared_tf:
+        solver["flags"] = int(solver.get("flags", 0)) | _ffi.SOLVE_SHARED_TF
     if linear_vt:
         solver["flags"] = int(solver.get("flags", 0)) | _ffi.SOLVE_LINEAR_VT
     if fixed_tf is not None:
@@ -82,7 +85,8 @@ def _tf_io(S, fixed_tf):
 
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
-                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, **solver):
+                   linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, shared_tf=False,
+                   **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Ks (S,) int: a ragged batch -- satellite s has Ks[s] <= K nodes in the first columns of its rows (what the reference's
@@ -90,7 +94,7 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     satellite's count are zero.
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
     returns the results in page-locked buffers that the next call of the same shape overwrites."""
-    solver = _solver_flags(solver, linear_vt, fixed_tf)
+    solver = _solver_flags(solver, linear_vt, fixed_tf, shared_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     if xbar.shape[1] != 7 or ubar.shape != (S, 3, K):
@@ -124,9 +128,9 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
 
 
 def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, fixed_tf=None,
-                regularised=False, **solver):
+                regularised=False, shared_tf=False, **solver):
     """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""
-    solver = _solver_flags(solver, linear_vt, fixed_tf)
+    solver = _solver_flags(solver, linear_vt, fixed_tf, shared_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
     arrs = [_ffi.as_f64(a) for a in (A, Bp, Bn, Sigma, xi)]
@@ -208,17 +212,29 @@ def shared_tf_root(G, tf_max, tf0, gtol=1e-7, xtol=2e-8, max_bracket=40):
     return t, ev
 
 
-def solve_shared_tf(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, **solver):
+def solve_shared_tf(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, monolithic=True,
+                    **solver):
     """S satellites that share ONE final time, as in a reference Optimizer holding several satellites
-    (optimizer.py:287,311,322,336).  Given tf the NLP separates into the S per-satellite problems the device solves in one
-    batch (MPCX_SOLVE_FIXED_TF); what remains is the scalar row 1 + sum_s g_s(tf) = 0 (or tf on its bound), solved here.
-    Returns (SolveResult of the final inner solve, SharedTfSearch: the (tf, G(tf)) evaluations and whether a root was
-    found).  An inner solve that ends with a numeric breakdown raises; one whose constraint set is empty
-    (MPCX_ST_INFEASIBLE: it is empty at every tf) ends the search at once, its result is returned with the status set and
-    the search marked not converged; one that stops at max_iter is used as it is and recorded in the search's message --
-    the reference never raises from solve_OPT (optimizer.py:603 ignores ipopt's status)."""
+    (optimizer.py:287,311,322,336).
+    monolithic (default): one device solve of the whole NLP (MPCX_SOLVE_SHARED_TF: one interior-point iteration for all
+    satellites, the tf row assembled across them in a cooperative launch).
+    monolithic=False: the decomposition of rounds 1-2 -- given tf the NLP separates into the S per-satellite problems the
+    device solves in one batch (MPCX_SOLVE_FIXED_TF); what remains is the scalar row 1 + sum_s g_s(tf) = 0 (or tf on its
+    bound), solved here by a bracketing secant (8-35 batched inner solves).  Kept as an independent cross-check.
+    Returns (SolveResult, SharedTfSearch: the (tf, G(tf)) evaluations of the decomposition -- empty for the monolithic
+    solve -- and whether a solution was found).  In the decomposition an inner solve that ends with a numeric breakdown
+    raises; one whose constraint set is empty (MPCX_ST_INFEASIBLE: it is empty at every tf) ends the search at once, its
+    result is returned with the status set and the search marked not converged; one that stops at max_iter is used as it
+    is and recorded in the search's message -- the reference never raises from solve_OPT (optimizer.py:603 ignores
+    ipopt's status)."""
     opts = {**DEFAULT_OPTIONS, **(options or {})}
     S = np.asarray(xbar).shape[0]
+    if monolithic:
+        r = solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options, device, linear_vt, shared_tf=True, **solver)
+        ev = SharedTfSearch()
+        ev.converged = bool(np.isin(r.status, (0, 7)).all())
+        ev.message = "monolithic device solve" + ("" if ev.converged else f": status {sorted(set(int(c) for c in r.status))}")
+        return r, ev
 
     class _Infeasible(Exception):
         pass

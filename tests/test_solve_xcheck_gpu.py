@@ -100,22 +100,62 @@ def shared_inputs(golden_dir, case):
 
 
 @pytest.mark.parametrize("case", ["shared_tf_K30", "shared_tf_K30_linvt"])
-def test_shared_tf_device_vs_monolithic_fixture(golden_dir, case):
+@pytest.mark.parametrize("monolithic", [True, False])
+def test_shared_tf_device_vs_monolithic_fixture(golden_dir, case, monolithic):
+    """Two satellites in one Optimizer (optimizer.py:287: one tf) against the monolithic 2 (24 K) + 1 variable NLP solved by
+    scipy trust-constr (tests/golden/make_nlp_xcheck.py).  monolithic=True: ONE device solve of that NLP
+    (MPCX_SOLVE_SHARED_TF, a cooperative launch); False: the decomposition -- batched fixed-tf solves inside a scalar root
+    search on the host -- which is also what the CPU oracle runs."""
     from mpconstellation_amd import solve_shared_tf
     f, ds, mats, x, u, cs = shared_inputs(golden_dir, case)
-    res, ev = solve_shared_tf(*mats, x, u, np.ones(2), cs, np.full(2, float(f["r_des"])), linear_vt=(str(f["variant"]) == "linvt"))
-    assert (res.status == 0).all() and len(ev) <= 45
+    res, ev = solve_shared_tf(*mats, x, u, np.ones(2), cs, np.full(2, float(f["r_des"])), linear_vt=(str(f["variant"]) == "linvt"),
+                              monolithic=monolithic)
+    assert (res.status == 0).all() and ev.converged and len(ev) <= (0 if monolithic else 45)
     assert res.tf[0] == res.tf[1] and abs(res.tf[0] - float(f["tf_opt"])) < 1e-6
-    if case == "shared_tf_K30":                   # (the convex case's optimum sits on a kink of the value function)
+    if monolithic:
+        assert res.iters[0] == res.iters[1] <= 80 and res.kkt[0] == res.kkt[1] <= 1e-8          # one problem, one iteration count
+    elif case == "shared_tf_K30":                 # (the convex case's optimum sits on a kink of the value function)
         assert abs(1.0 + res.g_tf.sum()) < 1e-6
     assert np.abs(res.X - f["X"]).max() < 1e-5 and np.abs(res.NU - f["NU"]).max() < 1e-6
-    # the oracle runs the same decomposition: same tf to the root tolerance
+    # the oracle runs the decomposition: same tf to the root tolerance
     Ps = [N.MpcProblem(d["x"], d["u"], 1.0, d["const"][0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
                        O.constraint_terms(d["x"], d["u"], d["const"][0]), {"r_des": float(f["r_des"])}, variant=str(f["variant"])) for d in ds]
     tf_o, out, _ = N.solve_shared_tf(Ps, 5.0)
     assert abs(res.tf[0] - tf_o) < 1e-6
-    for s in range(2):
-        assert np.abs(res.X[s] - out[s]["X"]).max() < 5e-6
+    for s in range(2):      # (the convex case's optimum sits on a kink of the value function: the decomposition's root is the less accurate side)
+        assert np.abs(res.X[s] - out[s]["X"]).max() < (1e-5 if case.endswith("linvt") else 5e-6)
+
+
+def test_shared_tf_monolithic_batch_properties():
+    """The monolithic shared-tf solve on 64 satellites of the constellation (one tf for all of them): it converges, every
+    satellite reports the same tf / iteration count, the result satisfies each satellite's constraints, the shared tf lies
+    between the smallest of the satellites' own optimal final times and tf_bar (the trust-region terms w_tr (tf - tf_bar)^2
+    of all 64 satellites pull on the one variable, the objective's tf only once), two runs are bit-identical (the
+    launch-wide reductions fold in a fixed order), and the decomposition (fixed-tf batches + host root search) finds
+    the same tf.  One satellite with an empty constraint set makes the whole problem infeasible."""
+    from mpconstellation_amd import mpc_step_batch, Discretizer, solve_shared_tf
+    from test_full_size_gpu import workload
+    S, K = 64, 30
+    xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
+    tf = np.ones(S)
+    own = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    sh = mpc_step_batch(xbar, ubar, tf, consts, r_des, shared_tf=True)
+    assert (own.status == 0).all() and (sh.status == 0).all() and sh.kkt.max() <= 1e-8
+    assert len(set(sh.tf.tolist())) == 1 and len(set(sh.iters.tolist())) == 1 and sh.iters[0] <= 60
+    assert own.tf.min() - 1e-6 <= sh.tf[0] <= 1.0 and sh.tf[0] > own.tf.mean()
+    rn = np.linalg.norm(sh.X[:, :3, :], axis=1)
+    assert np.abs(rn[:, -1] - r_des).max() <= 0.01 + 1e-6 and np.linalg.norm(sh.U, axis=1).max() <= 5 + 1e-6
+    assert np.abs(sh.X[:, :, 0] - xbar[:, :, 0]).max() == 0.0
+    again = mpc_step_batch(xbar, ubar, tf, consts, r_des, shared_tf=True)
+    assert np.array_equal(sh.X, again.X) and np.array_equal(sh.tf, again.tf) and np.array_equal(sh.iters, again.iters)
+    A, Bp, Bn, Sig, xi, st = Discretizer(None).discretize_batch(xbar[:8], ubar[:8], tf[:8], consts[:8])
+    mono, ev1 = solve_shared_tf(A, Bp, Bn, Sig, xi, xbar[:8], ubar[:8], tf[:8], consts[:8], r_des[:8])
+    deco, ev2 = solve_shared_tf(A, Bp, Bn, Sig, xi, xbar[:8], ubar[:8], tf[:8], consts[:8], r_des[:8], monolithic=False)
+    assert ev1.converged and ev2.converged and len(ev1) == 0 and len(ev2) >= 3
+    assert abs(mono.tf[0] - deco.tf[0]) < 1e-6 and np.abs(mono.X - deco.X).max() < 1e-5
+    rd = r_des.copy(); rd[5] = 7.0
+    bad = mpc_step_batch(xbar, ubar, tf, consts, rd, shared_tf=True)
+    assert (bad.status == 8).all() and (bad.iters == 0).all()
 
 
 def test_fixed_tf_flag_vs_oracle(golden_dir):
