@@ -34,7 +34,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return MPCX_E_HIP;
     mpcx_ctx *c = new mpcx_ctx();
     c->device = device; c->err[0] = 0; c->ws = nullptr; c->ws_bytes = 0;
-    c->prev_iters = nullptr; c->order = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
+    c->prev_iters = nullptr; c->order = nullptr; c->pred_hist = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
     c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
     c->copier = nullptr;
     c->counter = nullptr; c->n_slots = prop.multiProcessorCount * 8;
@@ -58,6 +58,7 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
     if (ctx->order) (void)hipFree(ctx->order);
+    if (ctx->pred_hist) (void)hipFree(ctx->pred_hist);
     if (ctx->nreg) (void)hipFree(ctx->nreg);
     if (ctx->counter) (void)hipFree(ctx->counter);
     if (ctx->red) (void)hipFree(ctx->red);

@@ -122,7 +122,7 @@ struct mpcx_ctx {
     size_t ws_bytes;
     // launch order of the solver's workgroups: the previous solve's iteration counts (library-owned copy) sorted
     // longest first; valid only for a following solve of the same batch size
-    int32_t *prev_iters, *order;
+    int32_t *prev_iters, *order, *pred_hist;     // prev_iters: the prediction the order is sorted by; pred_hist: the last solves' counts
     int order_S, order_valid, order_cap;
     // regularisation counts of the last solve ([S][2] int32, include/mpcx.h: mpcx_solve_regularised)
     int32_t *nreg;

@@ -2367,6 +2367,22 @@ __global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t
     for (int i = tid; i < S; i += 1024) order[min(atomicAdd(&base[min(max(prev_iters[i], 0), 255)], 1), S - 1)] = i;
 }
 
+// The predictor the launch order sorts by: the largest iteration count of the satellite's last kPredHist solves.  A launch
+// ends with its slowest workgroup, and with about two satellites per workgroup slot one long satellite that starts late
+// costs its whole length: a satellite that needed many iterations in ANY of the last few solves is started early (an early
+// start costs nothing if it turns out short); the last count alone forgets it as soon as the problem changes a little
+// (successive MPC steps, the two SCP iterations of a step, the benchmark's rotating variants).
+constexpr int kPredHist = 8;
+__global__ void update_prediction_kernel(int S, const int32_t *iters, int32_t *hist, int32_t *pred, int slot, int n_valid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    hist[(size_t)slot * S + i] = iters[i];
+    int m = 0;
+    for (int h = 0; h < n_valid; ++h) m = max(m, hist[(size_t)h * S + i]);
+    pred[i] = m;
+}
+
 // a satellite whose discretisation failed reports that code instead of the solver's
 __global__ void merge_status_kernel(int S, const int32_t *dstat, int32_t *status)
 {
@@ -3019,9 +3035,12 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
         // solve of the same batch size
         if (ctx->order_cap < S) {
             if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
+            if (ctx->pred_hist) (void)hipFree(ctx->pred_hist);
+            ctx->pred_hist = nullptr;
             if (ctx->order) (void)hipFree(ctx->order);
             ctx->prev_iters = ctx->order = nullptr; ctx->order_cap = 0; ctx->order_S = 0; ctx->order_valid = 0;
             MPCX_HIP(ctx, hipMalloc((void **)&ctx->prev_iters, (size_t)S * sizeof(int32_t)));
+            MPCX_HIP(ctx, hipMalloc((void **)&ctx->pred_hist, (size_t)kPredHist * S * sizeof(int32_t)));
             MPCX_HIP(ctx, hipMalloc((void **)&ctx->order, (size_t)S * sizeof(int32_t)));
             ctx->order_cap = S;
         }
@@ -3066,8 +3085,13 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     hipLaunchKernelGGL(solve_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, a);
     MPCX_HIP(ctx, hipGetLastError());
     if (adaptive) {
-        MPCX_HIP(ctx, hipMemcpyAsync(ctx->prev_iters, iters, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        ctx->order_valid = 1;
+        // (order_valid counts the solves of this batch size recorded so far)
+        const int slot = ctx->order_valid % kPredHist, n_valid = ctx->order_valid + 1 < kPredHist ? ctx->order_valid + 1 : kPredHist;
+        hipLaunchKernelGGL(update_prediction_kernel, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, S, iters, ctx->pred_hist,
+                           ctx->prev_iters, slot, n_valid);
+        MPCX_HIP(ctx, hipGetLastError());
+        ctx->order_valid += 1;
+        if (ctx->order_valid >= 2 * kPredHist) ctx->order_valid -= kPredHist;     // (keeps slot and n_valid as they are)
     }
     return MPCX_OK;
 }
