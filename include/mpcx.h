@@ -150,6 +150,11 @@ typedef struct {
  * S is limited to the workgroups the device holds at once (2048 on MI355X); no ragged batches. */
 #define MPCX_SOLVE_SHARED_TF 8
 
+/* Batches of at most 512 satellites (no more than one per two SIMDs of an MI355X) are solved by a kernel with TWO waves per
+ * satellite that share the factorisation of every interior-point iteration; results are bit for bit those of the one-wave
+ * kernel larger batches use.  This flag keeps the one-wave kernel for small batches too (comparisons, profiling). */
+#define MPCX_SOLVE_ONE_WAVE 16
+
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 size_t mpcx_solve_workspace_bytes(int S, int K);
 size_t mpcx_mpc_step_workspace_bytes(int S, int K);

@@ -20,7 +20,25 @@
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
 
-namespace mpcx {
+// This file is compiled twice.  As itself it gives solve_kernel (one wave per satellite: every barrier of a phase function
+// is that wave's) and the C entry points.  Included by solve2w.hip with MPCX_TWO_WAVE defined it gives, in its own
+// namespace, the small-batch kernel whose workgroups have a second wave that shares the factorisation (riccati_factor
+// below): there the phase functions still run on the first wave alone, so their "workgroup barriers" must not be hardware
+// barriers (the second wave never executes them) -- WG_SYNC() is then the memory fence only, and the real two-wave
+// barriers are spelled WG_BARRIER().
+#ifdef MPCX_TWO_WAVE
+#define MPCX_NS mpcx2w
+#define WG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define MPCX_NS mpcx
+#define WG_SYNC() __syncthreads()
+#endif
+#define WG_BARRIER() __syncthreads()
+
+namespace MPCX_NS {
+#ifdef MPCX_TWO_WAVE
+using namespace mpcx;          // (the device helpers of mpcx_device.hpp)
+#endif
 
 // ---- workspace layout (doubles) -------------------------------------------------------
 // iterate / direction record per node
@@ -164,7 +182,7 @@ __device__ __forceinline__ double gshfl8(double v, int q)
 
 // Barrier for the single-wave workgroups of this kernel when lanes exchange data through LDS only: DS operations of
 // one wave execute in issue order, so it is enough to stop the compiler from moving LDS accesses across this point.
-// Unlike __syncthreads() it does not drain outstanding global loads (the node-ahead prefetch stays in flight).
+// Unlike WG_SYNC() it does not drain outstanding global loads (the node-ahead prefetch stays in flight).
 __device__ __forceinline__ void wsync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -694,7 +712,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     out.dual_max = wave_max(dual); out.prim_max = wave_max(prim);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
     out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
-    if (WRITE) __syncthreads();            // the candidate iterate is complete before anybody reads it
+    if (WRITE) WG_SYNC();            // the candidate iterate is complete before anybody reads it
 }
 
 __device__ __forceinline__ int n_ineq(int K, int nT, int fixed_tf) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + (fixed_tf ? 0 : 2); }
@@ -933,7 +951,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
             for (int i = 0; i <= N_ZERO; ++i) nb[i] = 0.0;
         }
       }
-      __syncthreads();
+      WG_SYNC();
       {
           const int ne = ((K - k0 < 32) ? K - k0 : 32) * NB_N;
           gf64 *dst = s.nb + (size_t)k0 * NB_N;
@@ -943,10 +961,10 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
           gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
           for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[32 * NB_N + kl * RHS_LD + i]; }
       }
-      __syncthreads();
+      WG_SYNC();
     }
     sigmax = wave_max(sigmax);
-    __syncthreads();
+    WG_SYNC();
     // terminal Hessians, one lane per element: soft part (objective, radius balls, lam_vt * Hessian of the vt row) for
     // the residuals; + capped rank-1 terms + AL term for the recursion, which reads it from the terminal node's slot
     if (lane < 49) {
@@ -976,7 +994,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         }
         sd.Wtf = W; sd.gtf = g; sd.sigmax = sigmax;
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // ---- tiny dense helpers on LDS matrices --------------------------------------------------------
@@ -1016,14 +1034,26 @@ struct StageOps {
     double F[7 * FS], G2[7 * FS];
     double Bn[21], Bpm[21], Wu[9], D[7], SX[SX_N];        // the rest of the prefetched inputs (fetch order A Bn Bpm Wx Wu D SX)
     double G[49], Pt[49], Minv[49], Kg[21];
+#ifdef MPCX_TWO_WAVE
+    double Qi[9];                                         // Q_uu^-1 of the node: the second wave writes it to the factor record
+#endif
 };
 constexpr int OPS_IN = 91 + 49 + 9 + 7 + SX_N;   // A 49 | Bn 21 | Bpm 21 | Wx 49 (expanded) | Wu 9 | D 7 | SX 8
 
 struct Scratch {   // LDS working set of the recursion (and, between recursions, the staging area of newton_blocks)
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
+#ifdef MPCX_TWO_WAVE
+        StageOps ops[3];           // (two waves: node k+1 is still being swept while node k-1's operands arrive)
+#else
         StageOps ops[2];
+#endif
         double flat[2][FLAT_N];    // sweep operands of one node, double-buffered (fac record + A, Bpm, D)
     };
+#ifdef MPCX_TWO_WAVE
+    double Pn2[2][49];             // P_{k+1} is read by the second wave while the first writes P_k
+    double WlLi1[98];              // the second wave's own L^-1 [Pn | I]
+    int cmd, cmd_arg, good_flag;   // command of the first wave to the second (solve2w.hip), breakdown flag of a node
+#endif
     double Pn[49], WlLi[98], Qyy[49];
     double T[7 * FS];              // Pt F = [Pt A | Pt Bh]
     double sink[64];               // target of the lanes that have nothing to write in a branch-free phase
@@ -1163,6 +1193,398 @@ __device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, gf64 *f
     }
 }
 
+#ifdef MPCX_TWO_WAVE
+// (two-wave build: the same update on the node's LDS copies -- P_k's buffer, gain, Q_uu^-1 -- which the second wave stores)
+__device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double *PnT, int lane)
+{
+    double Qi[9];
+    (void)inv3_spd(w.Quu, Qi);
+    const double ex_x = o.SX[SX_EX], ex_u = o.SX[SX_EU];
+    double om1 = 0.0, om2 = 0.0, t1[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, tc = 0.0;
+    double ax[3], cu[3], c1[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { ax[l] = o.SX[SX_A + l]; cu[l] = o.SX[SX_CU + l]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c1[j] = o.Bpm[j] * ax[0] + o.Bpm[3 + j] * ax[1] + o.Bpm[6 + j] * ax[2];
+    if (ex_x > 0.0) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t1[l] = Qi[l * 3] * c1[0] + Qi[l * 3 + 1] * c1[1] + Qi[l * 3 + 2] * c1[2];
+        om1 = 1.0 / (1.0 / ex_x + (c1[0] * t1[0] + c1[1] * t1[1] + c1[2] * t1[2]));
+    }
+    if (ex_u > 0.0) {
+        double q2[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) q2[l] = Qi[l * 3] * cu[0] + Qi[l * 3 + 1] * cu[1] + Qi[l * 3 + 2] * cu[2];
+        tc = t1[0] * cu[0] + t1[1] * cu[1] + t1[2] * cu[2];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) t2[l] = q2[l] - om1 * tc * t1[l];                  // Qi' c_u with Qi' = Qi - om1 t1 t1^T
+        om2 = 1.0 / (1.0 / ex_u + (cu[0] * t2[0] + cu[1] * t2[1] + cu[2] * t2[2]));
+    }
+    // component j of v1 = a - Quy^T t1 and of v2 = -Kg'^T c_u = -(Quy^T q2) - om1 (t1.c_u) v1, from column j of Quy
+    // (Quy^T q2 = Quy^T (t2 + om1 tc t1))
+    auto sm_v = [&](const double (&qc)[3], int j, double &v1, double &v2) {
+        const double cyj = (j < 3) ? o.SX[SX_A + j] : 0.0;
+        const double qt1 = qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2];
+        v1 = (ex_x > 0.0) ? cyj - qt1 : 0.0;
+        v2 = -(qc[0] * t2[0] + qc[1] * t2[1] + qc[2] * t2[2]) - om1 * tc * qt1 - om1 * tc * v1;
+    };
+    wsync();                                       // every lane has read what it needs of the un-updated values
+    if (lane < 49) {
+        const int mi = lane / 7, mj = lane - 7 * mi;
+        const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
+        double qi[3], qj[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
+        double v1l, v2l, v1h, v2h;
+        sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
+        PnT[lane] += om1 * (v1l * v1h) + om2 * (v2l * v2h);
+    }
+    if (lane < 21) {
+        const int r = lane / 7, c = lane - 7 * r;
+        const double qc[3] = {w.Quy[c], w.Quy[7 + c], w.Quy[14 + c]};
+        double v1, v2;
+        sm_v(qc, c, v1, v2);
+        const double kg = o.Kg[lane] + om1 * t1[r] * v1 + om2 * t2[r] * v2;
+        o.Kg[lane] = kg;
+    }
+    if (lane < 9) {
+        const int r = lane / 3, c = lane - 3 * r;
+        o.Qi[lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
+    }
+}
+#endif
+
+
+#ifdef MPCX_TWO_WAVE
+// The same factorisation shared by the two waves of a small-batch workgroup (role 0 / role 1), one hardware barrier per node.
+// Role 0 keeps what the next node waits for -- the critical chain P_{k+1} -> LDL^T -> X1 -> Pt -> T = Pt F -> S = F^T T ->
+// Q_uu^-1 -> P_k -- and the operand prefetch; role 1 takes everything else off that chain: its own (redundant) LDL^T for
+// X2, the blocks G and Minv the sweeps need, the fused backward sweep of the node before (k+1, whose matrices sit complete
+// in another operand buffer) and all stores to the factor record.  Every element is computed by the same expressions as in
+// the one-wave form (results agree to rounding: 3e-14).  ~7 750 -> ~4 800 cycles per node for a wave that is alone on its
+// SIMD (64 satellites on a 1024-SIMD chip: the small-batch regime of BASELINE configs[1]).
+__device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scratch &w, int lane, int role, bool keep_pt)
+{
+    const Sat s = uniform_view(s_in);
+    const int K = s.K;
+    bool good = true;
+    const int sc = lane >> 3, sr = lane & 7;
+    const bool sact = sr < 7;
+    const int srr = (sr < 7) ? sr : 6, sr3 = (sr < 3) ? sr : 2;
+    const int sink_e = s.o_sink + lane;
+    const int mi = lane / 7, mj = lane - 7 * mi;
+    const int xc = (lane < 7) ? lane : 6;
+    // ---- role 0: operand prefetch (as in the one-wave form, three buffers) ----
+    double pre[3] = {0.0, 0.0, 0.0};
+    const int e1 = lane + 64, e2 = lane + 128;
+    auto wx_src = [](int q) -> int {
+        const int i = q / 7, j = q - 7 * i;
+        return (i < 3 && j < 3) ? N_W3 + i * 3 + j : (i == j ? N_DIAG : N_ZERO);
+    };
+    const int wx1 = (e1 >= 91) ? wx_src(e1 - 91) : 0;
+    const int src2 = (e2 < 140) ? wx_src(e2 - 91) : (e2 < OPS_IN ? N_WU + (e2 - 140) : 0);
+    auto fetch = [&](int k) {
+        cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
+        cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
+        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
+        cgf64 *p2 = nb + src2;
+        pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
+    };
+    auto ops_slot = [](int e) -> int {
+        if (e < 49) return (int)offsetof(StageOps, F) + 8 * ((e / 7) * FS + e % 7);
+        if (e < 70) return (int)offsetof(StageOps, Bn) + 8 * (e - 49);
+        if (e < 91) return (int)offsetof(StageOps, Bpm) + 8 * (e - 70);
+        if (e < 140) return (int)offsetof(StageOps, G2) + 8 * (((e - 91) / 7) * FS + (e - 91) % 7);
+        if (e < 149) return (int)offsetof(StageOps, Wu) + 8 * (e - 140);
+        if (e < 156) return (int)offsetof(StageOps, D) + 8 * (e - 149);
+        return (int)offsetof(StageOps, SX) + 8 * ((e < OPS_IN) ? e - 156 : 0);
+    };
+    const int slot0 = ops_slot(lane), slot1 = ops_slot(e1), slot2 = ops_slot(e2);
+    auto stash = [&](StageOps &o, int k) {
+        const bool dynk = (k <= K - 2);
+        char *base = (char *)&o;
+        *(double *)(base + slot0) = dynk ? pre[0] : 0.0;
+        *(double *)(base + slot1) = ((e1 < 70) ? dynk : (e1 < 91) ? (k >= 1) : true) ? pre[1] : 0.0;
+        if (e2 < OPS_IN) *(double *)(base + slot2) = (e2 < 149 || e2 >= 156 || dynk) ? pre[2] : 0.0;
+    };
+    if (role == 1) {                     // (the operand prefetch is the second wave's: it has the slack)
+        fetch(K - 1);
+        stash(w.ops[(K - 1) % 3], K - 1);
+        if (lane < 49) w.ops[(K - 1) % 3].G2[(lane / 7) * FS + lane % 7] = sd.WxK[lane];
+    } else {
+        for (int e = lane; e < 49; e += 64) w.Pn2[K & 1][e] = 0.0;       // P_K = 0 (read as "P of node k+1" by node K-1)
+        if (lane == 0) { w.zero = 0.0; w.good_flag = 1; }
+    }
+    WG_BARRIER();
+    // ---- role 0 lane roles (P1, P5, P6: as in the one-wave form) ----
+    const bool p1_bh = lane < 21, p1_wx = lane >= 32 && lane < 53;
+    const int p1_e = p1_wx ? lane - 32 : (p1_bh ? lane : 0), p1_i = p1_e / 3, p1_j = p1_e - 3 * p1_i;
+    const int p5_i = lane / FS, p5_j = lane - FS * p5_i;
+    const bool p5b_t = lane < 6, p5b_g = lane >= 6 && lane < 36;
+    const int p5b_q = p5b_g ? lane - 6 : 0;
+    const int p5b_r = p5b_q / FS;
+    const int p5b_j = p5b_t ? 4 + lane : p5b_q - FS * p5b_r;
+    const int p5b_sa = p5b_t ? 1 : 3;
+    const bool p5b_wu = p5b_g && p5b_j >= 7, p5b_qy = p5b_g && p5b_j < 7;
+    int p6_i = 0, p6_j = 0;
+    { int tt = lane; for (int i = 0; i < FS; ++i) { const int n = FS - i; if (tt < n) { p6_i = i; p6_j = i + tt; break; } tt -= n; } }
+    const bool p6_on = lane < 55;
+    const bool p6_qyy = p6_on && p6_j < 7, p6_quy = p6_on && p6_i < 7 && p6_j >= 7, p6_quu = p6_on && p6_i >= 7;
+    // ---- role 1: the fused backward sweep, one node behind (same arithmetic as sweep_backward) ----
+    ChanIn cur{0.0, 0.0, 0.0, 0.0};
+    ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
+    double pnext = 0.0;
+    auto sweep_node = [&](const StageOps &o, int j) {        // node j's p, qu from its complete operand buffer
+        const bool dynj = (j <= K - 2);
+        double sw_G[7], sw_Pt[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { sw_G[q] = o.G[srr * 7 + q]; sw_Pt[q] = o.Pt[srr * 7 + q]; }
+        const double sw_v = cur.rho + pnext;
+        double tt = pnext;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) tt += -sw_G[q] * gshfl8(sw_v, q) + sw_Pt[q] * gshfl8(cur.aff, q);
+        double Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { Acol[q] = o.F[q * FS + srr]; Bpmcol[q] = o.Bpm[q * 3 + sr3]; Bhcol[q] = o.F[q * FS + 7 + sr3]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Kgcol[q] = o.Kg[q * 7 + srr];
+        if (!dynj || !sact) tt = 0.0;
+        double qu = cur.gu;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) qu += Bpmcol[q] * gshfl8(cur.gx, q) + Bhcol[q] * gshfl8(tt, q);
+        if (sr >= 3 || !sact) qu = 0.0;
+        double pp = cur.gx;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) pp += Acol[q] * gshfl8(tt, q);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pp -= Kgcol[q] * gshfl8(qu, q);
+        ustore(s.ws, sact ? s.o_ch + j * CH_N + C_P + sc * 7 + sr : sink_e, pp);
+        ustore(s.ws, (sact && sr < 3) ? s.o_ch + j * CH_N + C_QU + sc * 3 + sr3 : sink_e, qu);
+        pnext = sact ? pp : pnext;
+        // ... and the part of node j's factor record that the first wave left in LDS: gain, Bh, Q_uu^-1
+        const bool on21 = lane < 21;
+        const int l21 = on21 ? lane : 0;
+        const int fb = s.o_fac + j * FAC_N;
+        ustore(s.ws, on21 ? fb + F_KG + lane : sink_e, o.Kg[l21]);
+        ustore(s.ws, on21 ? fb + F_BH + lane : sink_e, o.F[(l21 / 3) * FS + 7 + l21 % 3]);
+        ustore(s.ws, lane < 9 ? fb + F_QI + lane : sink_e, o.Qi[lane < 9 ? lane : 0]);
+    };
+    for (int k = K - 1; k >= 0; --k) {
+        StageOps &o = w.ops[k % 3];
+        const double *Pn = w.Pn2[(k + 1) & 1];
+        const bool dyn = (k <= K - 2);
+        if (role == 0) {
+            // P1: Bh = A Bpm + Bn ; WxBp = Wx Bpm
+            {
+                const double dot = dotN<7>((p1_wx ? o.G2 : o.F) + p1_i * FS, 1, o.Bpm + p1_j, 3);
+                const double val = p1_wx ? dot : (dyn ? o.Bn[p1_e] + dot : 0.0);
+                double *dst = p1_wx ? &o.G2[p1_i * FS + 7 + p1_j] : (p1_bh ? &o.F[p1_i * FS + 7 + p1_j] : &w.sink[lane]);
+                *dst = val;
+            }
+            double rd[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (dyn) {
+                // P2: LDL^T of M = D + Pn in registers; P3 (this wave's half): X1 = Lt^-1 Pn, lane c < 7 owns column c
+                double m[28];
+#pragma unroll
+                for (int i = 0, n = 0; i < 7; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j, ++n) m[n] = Pn[i * 7 + j] + (i == j ? o.D[i] : 0.0);
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) {
+                    const double d = m[pp * (pp + 1) / 2 + pp];
+                    if (!(d > 0.0)) good = false;
+                    rd[pp] = rcp_pos(d);
+                    double col[7];
+#pragma unroll
+                    for (int i = pp + 1; i < 7; ++i) col[i] = m[i * (i + 1) / 2 + pp];
+#pragma unroll
+                    for (int i = pp + 1; i < 7; ++i) {
+                        const double lip = col[i] * rd[pp];
+#pragma unroll
+                        for (int j = pp + 1; j <= i; ++j) m[i * (i + 1) / 2 + j] -= lip * col[j];
+                        m[i * (i + 1) / 2 + pp] = lip;
+                    }
+                }
+                double x[7];
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) x[pp] = Pn[pp * 7 + xc];
+#pragma unroll
+                for (int pp = 1; pp < 7; ++pp)
+#pragma unroll
+                    for (int q = 0; q < pp; ++q) x[pp] -= m[pp * (pp + 1) / 2 + q] * x[q];
+                {
+                    double *dst = (lane < 7) ? &w.WlLi[lane] : &w.sink[lane];
+                    const int st = (lane < 7) ? 14 : 0;
+#pragma unroll
+                    for (int pp = 0; pp < 7; ++pp) dst[pp * st] = x[pp];
+                }
+            }
+            wsync();
+            {
+                // P4 (this wave's third): Pt = Pn - X1^T R X1, symmetric by construction
+                const bool on = lane < 49;
+                const int ci = on ? mi : 0, cj = on ? mj : 0;
+                const int lo = (ci < cj) ? ci : cj, hi = (ci < cj) ? cj : ci;
+                double a1 = 0.0;
+#pragma unroll
+                for (int l = 0; l < 7; ++l) a1 += w.WlLi[l * 14 + lo] * (rd[l] * w.WlLi[l * 14 + hi]);
+                const double pt = dyn ? Pn[lo * 7 + hi] - a1 : 0.0;
+                *(on ? &o.Pt[lane] : &w.sink[lane]) = pt;
+                if (keep_pt) ustore(s.ws, on ? s.o_fac + k * FAC_N + F_PT + lane : sink_e, pt);
+                wsync();
+            }
+            // P5
+            w.T[p5_i * FS + p5_j] = dotN<7>(o.Pt + p5_i * 7, 1, o.F + p5_j, FS);
+            {
+                const double *a = p5b_t ? o.Pt + 42 : o.Bpm + p5b_r;
+                const double *b = (p5b_t ? o.F : o.G2) + p5b_j;
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < 7; ++l) acc += a[l * p5b_sa] * b[l * FS];
+                const double *add = p5b_wu ? &o.Wu[p5b_r * 3 + p5b_j - 7] : &w.zero;
+                double *dst = p5b_t ? &w.T[6 * FS + p5b_j] : (p5b_wu ? &w.Quu[p5b_r * 3 + p5b_j - 7] : (p5b_qy ? &w.Quy[p5b_r * 7 + p5b_j] : &w.sink[lane]));
+                *dst = *add + acc;
+            }
+            wsync();
+            // P6
+            {
+                const double sdot = dotN<7>(o.F + p6_i, FS, w.T + p6_j, FS);
+                double *dst = p6_qyy ? &w.Qyy[p6_i * 7 + p6_j] : (p6_quy ? &w.Quy[(p6_j - 7) * 7 + p6_i] : (p6_quu ? &w.Quu[(p6_i - 7) * 3 + p6_j - 7] : &w.sink[lane]));
+                const double *add = p6_qyy ? &o.G2[p6_i * FS + p6_j] : dst;
+                *dst = *add + sdot;
+            }
+            wsync();
+            // P7-P9: Q_uu^-1, P_k (into the other P buffer), the gain and Q_uu^-1 into the node's operand buffer
+            double Qi[9];
+            if (!inv3_spd(w.Quu, Qi)) good = false;
+            if (lane < 49) {
+                const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
+                double qi[3], qj[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
+                double a1 = w.Qyy[lo * 7 + hi];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const double kj = Qi[l * 3] * qj[0] + Qi[l * 3 + 1] * qj[1] + Qi[l * 3 + 2] * qj[2];
+                    a1 -= qi[l] * kj;
+                }
+                w.Pn2[k & 1][lane] = a1;
+            }
+            {
+                const bool on21 = lane < 21;
+                const int l21 = on21 ? lane : 0;
+                const int r = l21 / 7, c = l21 - 7 * r;
+                const double q0 = w.Quy[c], q1 = w.Quy[7 + c], q2 = w.Quy[14 + c];
+                const double k0 = Qi[0] * q0 + Qi[1] * q1 + Qi[2] * q2, k1 = Qi[3] * q0 + Qi[4] * q1 + Qi[5] * q2,
+                             k2 = Qi[6] * q0 + Qi[7] * q1 + Qi[8] * q2;
+                const double kg = (r == 0) ? k0 : (r == 1 ? k1 : k2);
+                *(on21 ? &o.Kg[lane] : &w.sink[lane]) = kg;
+                double qv = Qi[0];
+#pragma unroll
+                for (int e = 1; e < 9; ++e) qv = (lane == e) ? Qi[e] : qv;
+                *(lane < 9 ? &o.Qi[lane] : &w.sink[lane]) = qv;
+            }
+            // stiff stage terms (rare): rank-1 update of P_k, the gain and Q_uu^-1 -- on this node's LDS copies, which the
+            // second wave writes to the record afterwards
+            if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) {
+                wsync();
+                stiff_stage_update2(o, w, w.Pn2[k & 1], lane);
+            }
+            if (!__all(good) && lane == 0) w.good_flag = 0;
+        } else {
+            // ---- role 1 ----
+            if (k >= 1) fetch(k - 1);
+            nraw = chan_fetch(s, k, sc, srr, sr3);
+            if (dyn) {
+                double m[28], rd[7];
+#pragma unroll
+                for (int i = 0, n = 0; i < 7; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j, ++n) m[n] = Pn[i * 7 + j] + (i == j ? o.D[i] : 0.0);
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) {
+                    const double d = m[pp * (pp + 1) / 2 + pp];
+                    rd[pp] = rcp_pos(d);
+                    double col[7];
+#pragma unroll
+                    for (int i = pp + 1; i < 7; ++i) col[i] = m[i * (i + 1) / 2 + pp];
+#pragma unroll
+                    for (int i = pp + 1; i < 7; ++i) {
+                        const double lip = col[i] * rd[pp];
+#pragma unroll
+                        for (int j = pp + 1; j <= i; ++j) m[i * (i + 1) / 2 + j] -= lip * col[j];
+                        m[i * (i + 1) / 2 + pp] = lip;
+                    }
+                }
+                double x[7];
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) {
+                    const double pv = Pn[pp * 7 + xc];
+                    x[pp] = (lane < 7) ? pv : (lane - 7 == pp ? 1.0 : 0.0);
+                }
+#pragma unroll
+                for (int pp = 1; pp < 7; ++pp)
+#pragma unroll
+                    for (int q = 0; q < pp; ++q) x[pp] -= m[pp * (pp + 1) / 2 + q] * x[q];
+                {
+                    double *dst = (lane < 14) ? &w.WlLi1[lane] : &w.sink[lane];
+                    const int st = (lane < 14) ? 14 : 0;
+#pragma unroll
+                    for (int pp = 0; pp < 7; ++pp) dst[pp * st] = x[pp];
+                }
+                wsync();
+                // G = X1^T R X2, Minv = X2^T R X2 into the node's operand buffer and the factor record
+                const bool on = lane < 49;
+                const int ci = on ? mi : 0, cj = on ? mj : 0;
+                double a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int l = 0; l < 7; ++l) {
+                    const double x1i = w.WlLi1[l * 14 + ci], x2i = w.WlLi1[l * 14 + 7 + ci], x2j = w.WlLi1[l * 14 + 7 + cj];
+                    a2 += x1i * (rd[l] * x2j); a3 += x2i * (rd[l] * x2j);
+                }
+                *(on ? &o.G[lane] : &w.sink[lane]) = a2;
+                *(on ? &o.Minv[lane] : &w.sink[lane]) = a3;
+                const int fb = s.o_fac + k * FAC_N;
+                ustore(s.ws, on ? fb + F_G + lane : sink_e, a2);
+                ustore(s.ws, on ? fb + F_MINV + lane : sink_e, a3);
+            } else {
+                // the terminal node has no dynamics: zero blocks (as the one-wave form stores them)
+                const bool on = lane < 49;
+                *(on ? &o.G[lane] : &w.sink[lane]) = 0.0;
+                *(on ? &o.Minv[lane] : &w.sink[lane]) = 0.0;
+                const int fb = s.o_fac + k * FAC_N;
+                ustore(s.ws, on ? fb + F_G + lane : sink_e, 0.0);
+                ustore(s.ws, on ? fb + F_MINV + lane : sink_e, 0.0);
+            }
+            if (dyn) sweep_node(w.ops[(k + 1) % 3], k + 1);          // node k+1: complete since the last barrier
+            // inputs of node k for its sweep in the next slot
+            cur = chan_mask(nraw, sc, sr, sact);
+            if (!dyn) {
+                const double tg = (sc == 2) ? sd.avt[srr] : sd.ta[sc >= 3 ? sc - 3 : 0][srr];
+                cur.gx = (sact && sc >= 2) ? tg : cur.gx;
+                cur.rho = 0.0; cur.aff = 0.0;
+            }
+            if (k >= 1) stash(w.ops[(k - 1) % 3], k - 1);
+        }
+        WG_BARRIER();
+        if (w.good_flag == 0) { good = false; break; }
+    }
+    if (role == 1 && good) sweep_node(w.ops[0], 0);
+    WG_BARRIER();
+    return good;
+}
+
+// What the first wave's driver calls: tell the second wave (parked in solve_kernel2w's command loop) to join, take role 0.
+enum { CMD_FACTOR = 1, CMD_EXIT = 2 };
+__device__ __forceinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
+{
+    (void)fuse_sweep;                              // (the backward sweep always rides along: it is the second wave's)
+    if (lane == 0) { w.cmd = CMD_FACTOR; w.cmd_arg = keep_pt ? 1 : 0; }
+    WG_BARRIER();
+    return riccati_factor2(s, sd, w, lane, 0, keep_pt);
+}
+#else
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
 // With fuse_sweep the backward linear-term sweep of all 8 channels rides along: node k's p_k, qu_k are formed
 // right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
@@ -1259,7 +1681,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     if (lane < 49) w.ops[(K - 1) & 1].G2[(lane / 7) * FS + lane % 7] = sd.WxK[lane];
     for (int e = lane; e < 49; e += 64) w.Pn[e] = 0.0;
     if (lane == 0) w.zero = 0.0;
-    __syncthreads();
+    WG_SYNC();
     const int mi = lane / 7, mj = lane - 7 * mi;
     const int xc = (lane < 7) ? lane : 6;                 // column of [Pn | I] this lane substitutes (lanes 0..13)
     // P1 roles: lanes 0..20 element e of Bh = A Bpm + Bn (into F), lanes 32..52 element e of Wx Bpm (into G2), one body
@@ -1472,9 +1894,11 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         sweep_finish(w.ops[0], 0, sw_p, sw_qu);
         sweep_store(0, sw_p, sw_qu);
     }
-    __syncthreads();
+    WG_SYNC();
     return __all(good);
 }
+
+#endif
 
 // ---- linear-term sweeps: lane group c = channel, lane r = component ------------------------------
 // Stage matrices are staged through a double-buffered LDS copy (prefetched one node ahead); each lane reads
@@ -1523,7 +1947,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
     sweep_stash_mats(w.flat[(K - 1) & 1], K, K - 1, lane, pre);
     ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
     double pnext = 0.0;
-    __syncthreads();
+    WG_SYNC();
     for (int k = K - 1; k >= 0; --k) {
         const double *f = w.flat[k & 1];
         if (k >= 1) { sweep_fetch_mats<true>(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
@@ -1560,7 +1984,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
         cur = nxt;
         wsync();
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // Forward sweep for channels [c0, c1): stores each channel's trajectory (x, u, nu, lam) per node and
@@ -1589,7 +2013,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     if (!(act && r < 3)) quc = 0.0;
     if (!(act && K >= 2)) pnc = 0.0;
     double y = 0.0, siglam = 0.0;
-    __syncthreads();
+    WG_SYNC();
     for (int k = 0; k < K; ++k) {
         const double *f = w.flat[k & 1];
         FT_DECL
@@ -1645,7 +2069,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     siglam += __shfl_xor(siglam, 2, 8);
     siglam += __shfl_xor(siglam, 4, 8);
     if (act && r == 0) sd.siglam[c] = siglam;
-    __syncthreads();
+    WG_SYNC();
 }
 
 // direction (+)= trajectory of channel 0 + sum_j sol[j] * trajectory of channel 1+j ; one lane per (node, component),
@@ -1686,7 +2110,7 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
-        __syncthreads();
+        WG_SYNC();
         for (int e = lane; e < DIR_N * 32; e += 64) {
             const int i = e >> 5, kl = e & 31, k = k0 + kl;
             const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
@@ -1701,7 +2125,7 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
             const double val = (i >= T_LAM) ? fma(Dj, stg[(T_NU + j) * CMB_LD + kl], rj) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
             if (act) dr[dst] = base + val;
         }
-        __syncthreads();
+        WG_SYNC();
     }
     if (lane == 0) {
         if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = sd.linvt ? 0.0 : -s.itg[G_LVT] + sd.sol[1]; }
@@ -1710,7 +2134,7 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
         // the zetas of the stiff terminal terms are border unknowns like dtf: kept for the refinement's residual
         for (int t = 0; t < NTERM; ++t) sd.zeta[t] = (first ? 0.0 : sd.zeta[t]) + sd.sol[2 + t];
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // The bordered system ("Solver algorithm"): unknowns dtf, the multiplier of the vt row and one zeta per
@@ -1748,7 +2172,7 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
         if (sd.fixed_tf && (p == NBD - 1 || q == NBD - 1)) v = (p == q) ? 1.0 : 0.0;      // dtf = 0: out of the border
         sd.Mb[p][q] = v; sd.Sb[p][q] = v;    // Sb keeps the matrix for the refinement step of border_solve
     }
-    __syncthreads();
+    WG_SYNC();
     double S[NBD][NBD];
 #pragma unroll
     for (int p = 0; p < NBD; ++p)
@@ -1779,7 +2203,7 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
             S[i][p] = m;                                  // unit lower factor
         }
     }
-    __syncthreads();
+    WG_SYNC();
     if (lane == 0) {                                       // factors for border_solve (also of the refinement passes)
 #pragma unroll
         for (int p = 0; p < NBD; ++p) {
@@ -1788,7 +2212,7 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
             for (int i = p + 1; i < NBD; ++i) sd.Mb[i][p] = S[i][p];
         }
     }
-    __syncthreads();
+    WG_SYNC();
     return ok;
 }
 
@@ -1850,13 +2274,13 @@ __device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rv
     ldl_solve(r);
 #pragma unroll
     for (int p = 0; p < NBD; ++p) x[p] += r[p];
-    __syncthreads();
+    WG_SYNC();
     if (lane == 0) {
         sd.sol[0] = x[NBD - 1];
 #pragma unroll
         for (int p = 0; p < NBD - 1; ++p) sd.sol[1 + p] = x[p];
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 
@@ -1881,7 +2305,7 @@ __device__ __noinline__ void grid_reduce(GridSync &g, double (&v)[GR_N], int lan
         for (int j = 0; j < GR_N; ++j) __hip_atomic_store(slot + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();
-    __syncthreads();
+    WG_SYNC();
     if (lane == 0) {
         __hip_atomic_fetch_add(g.arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int target = (g.phase + 1) * g.S;
@@ -1892,7 +2316,7 @@ __device__ __noinline__ void grid_reduce(GridSync &g, double (&v)[GR_N], int lan
             __builtin_amdgcn_s_sleep(16);
         }
     }
-    __syncthreads();
+    WG_SYNC();
     __threadfence();
     if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) g.aborted = true;
     const double *base = g.red + (size_t)(g.phase & 1) * g.S * GR_N;
@@ -1911,7 +2335,7 @@ __device__ __noinline__ void grid_reduce(GridSync &g, double (&v)[GR_N], int lan
         v[j] = acc;
     }
     ++g.phase;
-    __syncthreads();
+    WG_SYNC();
 }
 __device__ __forceinline__ void gr_clear(double (&v)[GR_N])
 {
@@ -1937,7 +2361,7 @@ __device__ __noinline__ bool border_factor_shared(SatData &sd, int lane)
         } else v = (q == NBD - 1 ? sd.Wtf : 0.0) - sd.siglam[c];
         sd.Mb[p][q] = v; sd.Sb[p][q] = v;
     }
-    __syncthreads();
+    WG_SYNC();
     double S[NBD][NBD];
 #pragma unroll
     for (int p = 0; p < NBD; ++p)
@@ -1968,7 +2392,7 @@ __device__ __noinline__ bool border_factor_shared(SatData &sd, int lane)
             S[i][p] = m;
         }
     }
-    __syncthreads();
+    WG_SYNC();
     if (lane == 0) {
 #pragma unroll
         for (int p = 0; p < NBD - 1; ++p) {
@@ -1978,7 +2402,7 @@ __device__ __noinline__ bool border_factor_shared(SatData &sd, int lane)
         }
         sd.tS = S[NBD - 1][NBD - 1];
     }
-    __syncthreads();
+    WG_SYNC();
     return ok;
 }
 
@@ -2065,13 +2489,13 @@ __device__ __noinline__ bool border_solve_shared(SatData &sd, GridSync &g, doubl
     backward(r, ddtf);
 #pragma unroll
     for (int p = 0; p < NBD; ++p) x[p] += r[p];
-    __syncthreads();
+    WG_SYNC();
     if (lane == 0) {
         sd.sol[0] = x[NBD - 1];
 #pragma unroll
         for (int p = 0; p < NBD - 1; ++p) sd.sol[1 + p] = x[p];
     }
-    __syncthreads();
+    WG_SYNC();
     return true;
 }
 
@@ -2218,7 +2642,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
         gin[t] = sd.tgh[t] * share + sd.twin[t] * adx + (on ? sd.zeta[t] : 0.0);
         gex[t] = on ? (adx - sd.zeta[t] / wex + sd.tgh[t] / sd.tw[t]) * wex : 0.0;
     }
-    __syncthreads();
+    WG_SYNC();
     // terminal-node rhs completion: the rank-1 terms and the AL shift
     if (lane == 0) {
         gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
@@ -2226,7 +2650,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             for (int i = 0; i < 7; ++i) rec[R_GX + i] += gin[t] * sd.ta[t][i];
         for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_x * sd.avt[i];
     }
-    __syncthreads();
+    WG_SYNC();
 }
 
 // Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
@@ -2341,10 +2765,11 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
 #undef CHK
     amax = wave_min(amax);
     finite = (wave_max(bad) == 0.0);
-    __syncthreads();
+    WG_SYNC();
     return amax;
 }
 
+#ifndef MPCX_TWO_WAVE
 // Launch order: satellites sorted by the previous solve's iteration count, longest first (counting sort, one block).
 // The order inside one count is whatever the atomics give; the solver's results do not depend on the order.
 __global__ __launch_bounds__(1024) void launch_order_kernel(int S, const int32_t *prev_iters, int32_t *order)
@@ -2394,6 +2819,8 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
     hipLaunchKernelGGL(merge_status_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, dstat, status);
 }
 
+#endif  // !MPCX_TWO_WAVE
+
 #ifdef MPCX_PHASE_TIMING
 #define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, pt0_ = 0; unsigned pc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; \
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
@@ -2408,6 +2835,39 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 2     // waves per SIMD the register allocation is bounded for (256 registers; 3 was measured slower)
 #endif
+
+// View of satellite `sat`'s problem and of workspace slot `slot` (K: its node count, Kmax: the row length of the arrays)
+__device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const int slot, const int K, const int Kmax)
+{
+    Sat s;
+    s.K = K; s.ldk = Kmax;
+    s.stage = (cgf64 *)a.stage + (size_t)sat * (Kmax - 1) * MPCX_STAGE_DOUBLES;
+    s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * Kmax;
+    s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
+    const int KP = padded_nodes(K);
+    s.KP = KP;
+    gf64 *ws = (gf64 *)a.ws + (size_t)slot * a.ws_stride;
+    s.ws = ws;
+    s.it = ws; ws += (size_t)KP * IT_N;
+    s.dr = ws; ws += (size_t)KP * IT_N;
+    s.itB = ws; ws += (size_t)KP * IT_N;
+    s.nbs = ws; ws += (size_t)KP * NS_N;
+    s.stT = ws; ws += (size_t)KP * MPCX_STAGE_DOUBLES;
+    s.rbh = ws; ws += (size_t)KP * 3;
+    s.nb = ws; ws += (size_t)K * NB_N;
+    s.fac = ws; ws += (size_t)K * FAC_N;
+    s.ch = ws; ws += (size_t)K * CH_N;
+    s.traj = ws; ws += (size_t)K * NCH * TR_N;
+    s.itg = ws; ws += GL_N;
+    s.drg = ws; ws += GL_N;
+    s.itgB = ws; ws += GL_N;
+    s.sink = ws;
+    // (offsets as integers computed from the layout, not as pointer differences: the compiler would fold base + (sink -
+    //  base) back into a second pointer and emit a branch with one store per path)
+    s.o_fac = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N);
+    s.o_ch = s.o_fac + K * FAC_N; s.o_traj = s.o_ch + K * CH_N; s.o_sink = s.o_traj + K * NCH * TR_N + 3 * GL_N;
+    return s;
+}
 
 // Shared tf: one residual evaluation of the whole launch from the satellites' own (grid_reduce) plus the rows and pairs
 // that belong to the launch: tf's stationarity row 1 + sum_s g_s - z_0 + z_1 and the two sides of its range constraint
@@ -2453,33 +2913,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         }
         return;
     }
-    Sat s;
-    s.K = K; s.ldk = Kmax;
-    s.stage = (cgf64 *)a.stage + (size_t)sat * (Kmax - 1) * MPCX_STAGE_DOUBLES;
-    s.xbar = (cgf64 *)a.xbar + (size_t)sat * 7 * Kmax;
-    s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
-    const int KP = padded_nodes(K);
-    s.KP = KP;
-    gf64 *ws = (gf64 *)a.ws + (size_t)slot * a.ws_stride;
-    s.ws = ws;
-    s.it = ws; ws += (size_t)KP * IT_N;
-    s.dr = ws; ws += (size_t)KP * IT_N;
-    s.itB = ws; ws += (size_t)KP * IT_N;
-    s.nbs = ws; ws += (size_t)KP * NS_N;
-    s.stT = ws; ws += (size_t)KP * MPCX_STAGE_DOUBLES;
-    s.rbh = ws; ws += (size_t)KP * 3;
-    s.nb = ws; ws += (size_t)K * NB_N;
-    s.fac = ws; ws += (size_t)K * FAC_N;
-    s.ch = ws; ws += (size_t)K * CH_N;
-    s.traj = ws; ws += (size_t)K * NCH * TR_N;
-    s.itg = ws; ws += GL_N;
-    s.drg = ws; ws += GL_N;
-    s.itgB = ws; ws += GL_N;
-    s.sink = ws;
-    // (offsets as integers computed from the layout, not as pointer differences: the compiler would fold base + (sink -
-    //  base) back into a second pointer and emit a branch with one store per path)
-    s.o_fac = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N);
-    s.o_ch = s.o_fac + K * FAC_N; s.o_traj = s.o_ch + K * CH_N; s.o_sink = s.o_traj + K * NCH * TR_N + 3 * GL_N;
+    Sat s = sat_view(a, sat, slot, K, Kmax);
+    const int KP = s.KP;
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
@@ -2495,7 +2930,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         for (int i = 0; i < 16; ++i) sd.fpt[i] = 0;
 #endif
     }
-    __syncthreads();
+    WG_SYNC();
     double gr[GR_N];                // (shared tf: operands / results of the launch-wide reductions)
     if (SHARED) {
         // the launch is ONE problem: empty if any satellite's constraint set is, or tf's own range (which build_terminal
@@ -2504,7 +2939,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         gr[GR_SUM] = fmax(sd.infeas, -(sd.b_tf[0] + sd.b_tf[1]));
         grid_reduce(*gsync, gr, lane);
         if (lane == 0) sd.infeas = gsync->aborted ? 1.0 : gr[GR_SUM];
-        __syncthreads();
+        WG_SYNC();
     }
     if (sd.infeas > 0.0) {      // empty constraint set: the reference trajectory goes back unchanged, no iteration is spent
         for (int e = lane; e < 7 * Kmax; e += 64) { a.X[(size_t)sat * 7 * Kmax + e] = s.xbar[e]; a.NU[(size_t)sat * 7 * Kmax + e] = 0.0; }
@@ -2526,12 +2961,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             const int nk = (K - 1 - k0 < 16) ? K - 1 - k0 : 16;
             cgf64 *rec = s.A(k0);
             for (int e = lane; e < nk * MPCX_STAGE_DOUBLES; e += 64) stg[e] = rec[e];
-            __syncthreads();
+            WG_SYNC();
             for (int e = lane; e < 16 * MPCX_STAGE_DOUBLES; e += 64) {
                 const int f = e >> 4, kl = e & 15;
                 if (kl < nk) s.stT[f * KP + k0 + kl] = stg[kl * MPCX_STAGE_DOUBLES + f];
             }
-            __syncthreads();
+            WG_SYNC();
         }
     }
     for (int k = lane; k < K; k += 64) {
@@ -2569,7 +3004,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = kMuInit / s.itg[G_STF];
         s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = kMuInit / s.itg[G_STF + 1];
     }
-    __syncthreads();
+    WG_SYNC();
 
     double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
     // (shared tf: the counts of the whole launch -- S satellites without their own tf rows plus tf's two range inequalities)
@@ -2855,17 +3290,18 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     }
 }
 
-// Persistent workgroups: the launch has as many single-wave workgroups as the device holds at once (or S, if fewer), each
-// takes satellites off a counter until none is left, in launch order (longest first when the previous solve's iteration
-// counts are known).  A workgroup keeps ONE workspace slot for all its satellites: the solver's working set is
-// slots x 206 KB whatever the batch size (8192 satellites: 0.44 GB instead of 1.8 GB), and a slot's lines are rewritten
-// by the next satellite while they are still cached instead of being written back as dead data.
 // The two kernels' LDS working set: ONE pair of module-scope objects, so that it sits at the same LDS address in both and
 // the out-of-line phase functions (which take it by reference) keep addressing it with compile-time offsets -- with a
 // pair per kernel the addresses reach them as run-time pointers (measured: solve_kernel 6.85 -> 8.4 ms at S4096).
 __shared__ SatData g_sd;
 __shared__ Scratch g_w;
 
+#ifndef MPCX_TWO_WAVE
+// Persistent workgroups: the launch has as many single-wave workgroups as the device holds at once (or S, if fewer), each
+// takes satellites off a counter until none is left, in launch order (longest first when the previous solve's iteration
+// counts are known).  A workgroup keeps ONE workspace slot for all its satellites: the solver's working set is
+// slots x 206 KB whatever the batch size (8192 satellites: 0.44 GB instead of 1.8 GB), and a slot's lines are rewritten
+// by the next satellite while they are still cached instead of being written back as dead data.
 __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
 {
     SatData &sd = g_sd;
@@ -2897,9 +3333,12 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_shared_kernel(Solv
     solve_satellite<true>(a, (int)blockIdx.x, (int)blockIdx.x, sd, w, lane, &g);
 }
 
-}  // namespace mpcx
+}  // namespace MPCX_NS
 
-using namespace mpcx;
+using namespace MPCX_NS;
+
+int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);      // solve2w.hip
+constexpr int kTwoWaveMax = 512;
 
 static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
 {
@@ -2913,7 +3352,7 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
 }
 
 
-namespace mpcx {
+namespace MPCX_NS {
 // Diagnostic export of what solve_kernel builds before its first iteration: the terminal inequality rows a_j . x_K <= b_j
 // (build_terminal: Optimizer.get_constraint_terms, optimizer.py:80-170, as consumed by the rules :398-403, 406-446,
 // 471-489, 351-352) and the relaxed scalar bounds.  Same device function, same lane, same LDS struct as in the solve.
@@ -2939,7 +3378,7 @@ __global__ __launch_bounds__(64) void constraint_terms_kernel(int S, int K, cons
         q[6] = sd.vt_des; q[7] = sd.infeas;
     }
 }
-}  // namespace mpcx
+}  // namespace MPCX_NS
 
 extern "C" int mpcx_constraint_terms_dev(mpcx_ctx *ctx, int S, int K, const double *xbar, const double *consts,
                                          const double *r_des, const mpcx_solve_opts *opts, double *aT, double *bT,
@@ -3082,6 +3521,11 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     MPCX_HIP(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(int32_t), (hipStream_t)stream));
     a.counter = ctx->counter;
     const int slots = S < ctx->n_slots ? S : ctx->n_slots;
+    // small batches -- at most one satellite per two SIMDs -- go to the two-wave build (solve2w.hip): a second wave per
+    // satellite shares the factorisation; results are bit for bit the one-wave kernel's (MPCX_SOLVE_ONE_WAVE keeps that)
+    if (S <= kTwoWaveMax && !(opts->flags & MPCX_SOLVE_ONE_WAVE)) {
+        if (mpcx2w_launch(&a, sizeof a, slots, (hipStream_t)stream) != 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: two-wave launch failed");
+    } else
     hipLaunchKernelGGL(solve_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, a);
     MPCX_HIP(ctx, hipGetLastError());
     if (adaptive) {
@@ -3223,3 +3667,53 @@ extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, co
     ar.download(tf_out, dtfo, S); ar.download(status, dstat, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
     return ar.finish();
 }
+
+#else  // MPCX_TWO_WAVE: the small-batch kernel and its launcher (called by mpcx_solve_batch_ragged_dev in the other build)
+
+// Two waves per satellite.  The first runs solve_satellite exactly as the one-wave kernel's wave does; the second waits in a
+// command loop and joins it for every factorisation (riccati_factor2).  Same work queue, same slot workspaces.
+__global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel2w(SolveArgs a)
+{
+    SatData &sd = g_sd;
+    Scratch &w = g_w;
+    __shared__ int next_item;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (;;) {
+        if (threadIdx.x == 0) next_item = atomicAdd(a.counter, 1);
+        WG_BARRIER();
+        const int b = __builtin_amdgcn_readfirstlane(next_item);
+        WG_BARRIER();
+        if (b >= a.S) return;
+        int sat = a.order ? a.order[b] : b;
+        if ((unsigned)sat >= (unsigned)a.S) sat = b;
+        if (wave == 0) {
+            solve_satellite<false>(a, sat, (int)blockIdx.x, sd, w, lane);
+            if (lane == 0) w.cmd = CMD_EXIT;
+            WG_BARRIER();
+        } else {
+            const int Kmax = a.K;
+            int K = a.Ks ? a.Ks[sat] : Kmax;
+            if (K < 3 || K > Kmax) K = Kmax;                       // (the first wave reports MPCX_ST_BADK and sends CMD_EXIT at once)
+            const Sat s = sat_view(a, sat, (int)blockIdx.x, K, Kmax);
+            for (;;) {
+                WG_BARRIER();
+                if (w.cmd == CMD_EXIT) break;
+                (void)riccati_factor2(s, sd, w, lane, 1, w.cmd_arg != 0);
+            }
+        }
+        WG_BARRIER();
+    }
+}
+
+}  // namespace MPCX_NS
+
+// (SolveArgs of the two builds are the same struct compiled twice: handed over as bytes)
+int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream)
+{
+    MPCX_NS::SolveArgs a;
+    if (args_bytes != sizeof a) return -1;
+    memcpy(&a, args, sizeof a);
+    hipLaunchKernelGGL(MPCX_NS::solve_kernel2w, dim3(blocks), dim3(128), 0, stream, a);
+    return 0;
+}
+#endif

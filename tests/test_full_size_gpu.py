@@ -109,8 +109,35 @@ def test_satellites_are_independent_units():
         first, count = shard_block(S, 8, rank)
         xb, ub, cb, rb = workload(S, K, first, count)
         assert np.array_equal(xb, xbar[first:first + count])
-        part = mpc_step_batch(xb, ub, np.ones(count), cb, rb)
+        # (flags=16, MPCX_SOLVE_ONE_WAVE: the 128-satellite block through the same one-wave kernel as the 1024 batch; batches of
+        #  up to 512 otherwise run on the two-wave kernel, which agrees with it to rounding, not bit for bit: see below)
+        part = mpc_step_batch(xb, ub, np.ones(count), cb, rb, flags=16)
         assert np.array_equal(part.X, whole.X[first:first + count]) and np.array_equal(part.tf, whole.tf[first:first + count])
+
+
+def test_two_wave_small_batch_kernel():
+    """Batches of up to 512 satellites run on the two-wave kernel (solve2w.hip: a second wave per satellite shares the
+    factorisation).  It must give what the one-wave kernel gives (MPCX_SOLVE_ONE_WAVE = 16) -- same iteration counts, same
+    statuses, solutions equal to rounding -- on the benchmark constellation at K = 30 and 100, on OptimalController's
+    option set (stiff terminal windows: refinement passes) and at the shortest horizon; and like the one-wave kernel it
+    must not care who shares the batch (bit for bit between a batch of 64, its reversal and single-satellite calls)."""
+    from mpconstellation_amd import mpc_step_batch
+    for S, K, opts in ((64, 30, {}), (48, 100, {}), (512, 30, {}), (128, 30, {"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}), (5, 3, {})):
+        xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
+        tf = np.ones(S)
+        one = mpc_step_batch(xbar, ubar, tf, consts, r_des, options=opts, flags=16, regularised=True)
+        two = mpc_step_batch(xbar, ubar, tf, consts, r_des, options=opts, regularised=True)
+        assert (two.status == 0).all() and np.array_equal(one.status, two.status)
+        assert np.array_equal(one.iters, two.iters) and np.array_equal(one.n_regularised, two.n_regularised)
+        assert np.abs(one.X - two.X).max() < 1e-9 and np.abs(one.U - two.U).max() < 1e-8 and np.abs(one.tf - two.tf).max() < 1e-10      # (observed 3e-14 .. 3e-11)
+    xbar, ubar, consts, r_des = workload(4096, 30, first=0, count=64)
+    tf = np.ones(64)
+    two = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    rev = mpc_step_batch(xbar[::-1].copy(), ubar[::-1].copy(), tf, consts[::-1].copy(), r_des[::-1].copy())
+    assert np.array_equal(two.X, rev.X[::-1]) and np.array_equal(two.tf, rev.tf[::-1]) and np.array_equal(two.iters, rev.iters[::-1])
+    for s in (0, 17, 63):
+        single = mpc_step_batch(xbar[s:s + 1], ubar[s:s + 1], tf[:1], consts[s:s + 1], r_des[s:s + 1])
+        assert np.array_equal(single.X[0], two.X[s]) and single.tf[0] == two.tf[s]
 
 
 def test_minimum_horizon_and_single_satellite():
@@ -231,7 +258,7 @@ def test_config4_every_rank_block():
             ref = N.solve(P)
             assert ref["status"] == 0
             assert np.abs(X[s] - ref["X"]).max() < 5e-6 and np.abs(U[s] - ref["U"]).max() < 5e-6 and abs(tfo[s] - ref["tf"]) < 5e-6
-        res = mpc_step_batch(h["xbar"][pick], h["ubar"][pick], np.ones(len(pick)), h["consts"][pick], h["r_des"][pick])
+        res = mpc_step_batch(h["xbar"][pick], h["ubar"][pick], np.ones(len(pick)), h["consts"][pick], h["r_des"][pick], flags=16)
         assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])
         if rank == 3:                                      # the block's inputs are what the generator gives for these indices
             xb, ub, cs, rd = workload(65536, K, first=first, count=count)
