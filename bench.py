@@ -170,7 +170,8 @@ def measured_traffic(workload, kernel="solve_kernel"):
     import hashlib
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         prof = json.load(open(f))
-        w = prof.get("workloads", {}).get(workload, {}).get(kernel)
+        ks = prof.get("workloads", {}).get(workload, {})
+        w = ks.get(kernel) or ks.get(kernel + "2w")          # (batches of up to 512 run on the two-wave build's kernel)
         if not w: continue
         src = os.path.relpath(f, ROOT)
         want = prof.get("kernel_source_sha256")
