@@ -39,28 +39,37 @@ def foh_resample_ragged(u, Ku, n):
     (linearize_discretize.py:393-411) for SequenceController(u_s, tf_u, tf_sim = tf_u): np.linspace's nodes (i * step, the
     last one exactly 1), k = int(tau // dtau) (numpy's float floor_divide is CPython's algorithm), tau_k = k / (K-1),
     the blend as written in control.py:122-126."""
-    u = np.asarray(u, dtype=np.float64)
-    S = u.shape[0]
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    S, _, Kmax = u.shape
     Ku = np.asarray(Ku).reshape(S, 1); nn = np.asarray(n).reshape(S, 1)
     nmax = int(nn.max())
     i = np.arange(nmax, dtype=np.float64)[None, :]
     with np.errstate(divide="ignore", invalid="ignore"):
         step = 1.0 / (nn - 1.0)
-        tau = np.where(nn > 1, i * step, 0.0)
-        tau = np.where((i == nn - 1) & (nn > 1), 1.0, tau)
+        tau = i * step
+        tau[np.broadcast_to(nn <= 1, tau.shape)] = 0.0
+        at1 = (i == nn - 1) & (nn > 1)              # np.linspace's last node is exactly 1
+        tau[at1] = 1.0
         km1 = (Ku - 1).astype(np.float64)
         dtau = 1 / km1
         k = np.floor_divide(tau, dtau)
-    at1 = tau == 1
-    k = np.clip(np.where(at1, 0, k), 0, Ku - 2).astype(np.int64)
+    k = np.clip(k, 0, Ku - 2).astype(np.int64)
+    k[at1] = 0
     tau_k = k / km1; tau_kp1 = (k + 1) / km1
-    lam_n = (tau_kp1 - tau) / (tau_kp1 - tau_k); lam_p = (tau - tau_k) / (tau_kp1 - tau_k)
-    uk = np.take_along_axis(u, np.broadcast_to(k[:, None, :], (S, 3, nmax)), axis=2)
-    uk1 = np.take_along_axis(u, np.broadcast_to(k[:, None, :] + 1, (S, 3, nmax)), axis=2)
-    out = lam_n[:, None, :] * uk + lam_p[:, None, :] * uk1
-    last = np.take_along_axis(u, np.broadcast_to((Ku - 1)[:, None, :], (S, 3, 1)), axis=2)
-    out = np.where(at1[:, None, :], last, out)
-    return np.where((i < nn)[:, None, :], out, 0.0)
+    den = tau_kp1 - tau_k
+    lam_n = (tau_kp1 - tau) / den; lam_p = (tau - tau_k) / den
+    keep = i < nn
+    out = np.zeros((S, 3, nmax))
+    base = np.arange(S, dtype=np.int64)[:, None] * (3 * Kmax)
+    flat = u.reshape(-1)
+    last = (Ku - 1).astype(np.int64)
+    for c in range(3):                          # (flat gathers: much cheaper than take_along_axis on a broadcast index)
+        off = base + c * Kmax
+        val = lam_n * flat[off + k] + lam_p * flat[off + k + 1]
+        val[at1] = np.broadcast_to(flat[off + last], val.shape)[at1]
+        oc = out[:, c, :]
+        oc[keep] = val[keep]
+    return out
 
 
 MAX_SLOTS = 8      # contexts (streams) used side by side (run_concurrently)
