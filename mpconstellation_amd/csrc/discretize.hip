@@ -47,7 +47,28 @@ struct RhsCtx {
     FohCache foh;        // the thrust table's interval in use (see foh3_cached)
 };
 
-// One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.
+// 1/d and 1/sqrt(d) for d > 0 well inside the normal range: hardware seed + two Newton steps (half an ulp, measured:
+// profiles/tools/rcp_accuracy.hip) instead of the IEEE division / square-root sequences (~3x the instructions)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    return r;
+}
+__device__ __forceinline__ double rsq_nr(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const double e = fma(-d * r, r, 1.0); r = fma(0.5 * r, e, r); }
+    return r;
+}
+
+// One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.  The ~48 evaluations per interval are
+// two thirds of the kernel's instructions, and a third of theirs were the IEEE division / square-root sequences of the
+// Jacobian blocks and of the dynamics: here both are arranged around one reciprocal each of |r| and m (round 3; the
+// quadrature integrands of node_integrand keep the forms of mpcx_device.hpp).  Results move by rounding only (a few ulp per
+// evaluation, 1e-13 on A_k, B_k against the reference's arrays; the accepted RK45 nodes are the same).
 __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], double ts,
                                          double (&out)[7], int &err)
 {
@@ -55,8 +76,42 @@ __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], doubl
     foh3_cached(ts, p.us, p.Ku, p.ldu, p.foh, u, err);
     const double rx = bcast8<7>(ys[0]), ry = bcast8<7>(ys[1]), rz = bcast8<7>(ys[2]);
     const double m = bcast8<7>(ys[6]);
+    const SatConst &c = p.cst;
+    const double r[3] = {rx, ry, rz};
+    const double r2 = rx * rx + ry * ry + rz * rz;
+    const double irn = rsq_nr(r2), irn2 = irn * irn, ir3 = irn2 * irn, ir5 = ir3 * irn2;
+    const double im = rcp_nr(m > 0.0 ? m : 1.0);
+    // G = d a / d r, gm = d a / d m (jacobian_blocks)
+    const double c1 = -c.mu * ir3, c2 = 3.0 * c.mu * ir5;
     double G[3][3], gm[3];
-    jacobian_blocks(rx, ry, rz, m, u, p.cst, p.flags, G, gm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) G[i][j] = (i == j ? c1 : 0.0) + c2 * (r[i] * r[j]);
+    double j2a[3] = {0.0, 0.0, 0.0};
+    if (p.flags & MPCX_FLAG_J2) {
+        const double kJ2 = 1.5 * c.j2 * c.mu * (c.re * c.re);
+        const double q2 = (rz * rz) * irn2;
+        const double g[3] = {5.0 * q2 - 1.0, 5.0 * q2 - 1.0, 5.0 * q2 - 3.0};
+        const double ir4 = irn2 * irn2, ir7 = ir5 * irn2;
+        double ddr[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ddr[j] = 5.0 * (rz * rz) * (-2.0 * (r[j] * ir4));
+        ddr[2] += (5.0 * irn2) * (2.0 * rz);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = ((kJ2 * g[i]) * r[i]) * (-5.0 * r[j] * ir7) + kJ2 * ir5 * (r[i] * ddr[j]);
+                if (i == j) t += kJ2 * ir5 * g[i];
+                G[i][j] += t;
+            }
+            j2a[i] = (kJ2 * ir5) * (g[i] * r[i]);
+        }
+    }
+    const double im2 = im * im;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gm[i] = -u[i] * im2;
     const double tf = p.tf;
     // Phi column: (tf * Dxf) @ col
     double op[7];
@@ -71,9 +126,17 @@ __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], doubl
     }
     op[6] = 0.0;
     // x column: tf * f(x, u)   (meaningful on lane 7 only)
-    const double xv[7] = {rx, ry, rz, ys[3], ys[4], ys[5], m};
     double yd[7];
-    dynamics_unscaled(xv, u, p.cst, p.flags, yd);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { yd[i] = ys[3 + i]; yd[3 + i] = c1 * r[i] + u[i] * im + j2a[i]; }
+    if (p.flags & MPCX_FLAG_DRAG) {                          // simulator.py:150-153 (the Python Discretizer never sets it)
+        const double vn = sqrt(ys[3] * ys[3] + ys[4] * ys[4] + ys[5] * ys[5]);
+        const double coef = -0.5 * kCd * c.s * im * (kRho500 / c.rho) * vn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) yd[3 + i] += coef * ys[3 + i];
+    }
+    const double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+    yd[6] = -(uu * rsq_nr(fmax(uu, 1e-300))) * rcp_nr(c.g0 * c.isp);
     const bool isx = (p.c == 7);
     if (isx && m <= 0.0) err = MPCX_ST_MASS;
 #pragma unroll
