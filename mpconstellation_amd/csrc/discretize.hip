@@ -12,8 +12,8 @@
 // (scipy's controller, reproduced decision for decision); the loop is wave-uniform and a
 // group that has reached its end point idles under predicate.  At every accepted node each
 // lane forms one of the 8 quadrature columns [B lam-, B lam+, Sigma, xi], solves
-// Phi(tau_i) g = column (6x6 LU with partial pivoting, Phi staged through LDS) and adds its
-// trapezoid slice, so no node is ever stored.
+// Phi(tau_i) g = column (6x6 elimination with partial pivoting, distributed over the group by columns: lu_solve_cols)
+// and adds its trapezoid slice, so no node is ever stored.
 #include "mpcx_device.hpp"
 #include "mpcx_host.hpp"
 
@@ -42,7 +42,7 @@ __device__ __forceinline__ double group_sum(double v)
 struct RhsCtx {
     const double *us;
     int Ku, ldu, flags, c;
-    double tf;
+    double tf, inv_ve;   // inv_ve = 1 / (g0 Isp)
     SatConst cst;
     FohCache foh;        // the thrust table's interval in use (see foh3_cached)
 };
@@ -64,32 +64,29 @@ __device__ __forceinline__ double rsq_nr(double d)
     return r;
 }
 
-// One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.  The ~48 evaluations per interval are
-// two thirds of the kernel's instructions, and a third of theirs were the IEEE division / square-root sequences of the
-// Jacobian blocks and of the dynamics: here both are arranged around one reciprocal each of |r| and m (round 3; the
-// quadrature integrands of node_integrand keep the forms of mpcx_device.hpp).  Results move by rounding only (a few ulp per
-// evaluation, 1e-13 on A_k, B_k against the reference's arrays; the accepted RK45 nodes are the same).
-__device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], double ts,
-                                         double (&out)[7], int &err)
+// The linearisation at one point (x, u): tf * G = tf * d a / d r, tf * gm = tf * d a / d m (jacobian_blocks), the acceleration and the
+// mass flow of Simulator.satellite_dynamics (dynamics_unscaled, tf = 1).  The ~48 right-hand sides and ~9 quadrature nodes per
+// interval are nearly all of the kernel's instructions, and a third of theirs were IEEE division / square-root sequences:
+// here everything is arranged around one reciprocal each of |r|, m and |u| (round 3).  Results move by rounding only (a few
+// ulp per evaluation, 1e-13 on A_k, B_k against the reference's arrays; the accepted RK45 nodes are the same).
+struct Lin {
+    double Gt[3][3], gmt[3], acc[3], mdot, im, iun, un;
+};
+
+__device__ __forceinline__ void lin_eval(const double (&r)[3], const double (&v)[3], double m, const double (&u)[3],
+                                         const SatConst &c, int flags, double tf, double inv_ve, Lin &L)
 {
-    double u[3];
-    foh3_cached(ts, p.us, p.Ku, p.ldu, p.foh, u, err);
-    const double rx = bcast8<7>(ys[0]), ry = bcast8<7>(ys[1]), rz = bcast8<7>(ys[2]);
-    const double m = bcast8<7>(ys[6]);
-    const SatConst &c = p.cst;
-    const double r[3] = {rx, ry, rz};
+    const double rx = r[0], ry = r[1], rz = r[2];
     const double r2 = rx * rx + ry * ry + rz * rz;
     const double irn = rsq_nr(r2), irn2 = irn * irn, ir3 = irn2 * irn, ir5 = ir3 * irn2;
     const double im = rcp_nr(m > 0.0 ? m : 1.0);
-    // G = d a / d r, gm = d a / d m (jacobian_blocks)
-    const double c1 = -c.mu * ir3, c2 = 3.0 * c.mu * ir5;
-    double G[3][3], gm[3];
+    const double c1 = -c.mu * ir3, c1t = tf * c1, c2t = tf * (3.0 * c.mu * ir5);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) G[i][j] = (i == j ? c1 : 0.0) + c2 * (r[i] * r[j]);
+        for (int j = 0; j < 3; ++j) L.Gt[i][j] = (i == j ? c1t : 0.0) + c2t * (r[i] * r[j]);
     double j2a[3] = {0.0, 0.0, 0.0};
-    if (p.flags & MPCX_FLAG_J2) {
+    if (flags & MPCX_FLAG_J2) {
         const double kJ2 = 1.5 * c.j2 * c.mu * (c.re * c.re);
         const double q2 = (rz * rz) * irn2;
         const double g[3] = {5.0 * q2 - 1.0, 5.0 * q2 - 1.0, 5.0 * q2 - 3.0};
@@ -104,94 +101,104 @@ __device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], doubl
             for (int j = 0; j < 3; ++j) {
                 double t = ((kJ2 * g[i]) * r[i]) * (-5.0 * r[j] * ir7) + kJ2 * ir5 * (r[i] * ddr[j]);
                 if (i == j) t += kJ2 * ir5 * g[i];
-                G[i][j] += t;
+                L.Gt[i][j] += tf * t;
             }
             j2a[i] = (kJ2 * ir5) * (g[i] * r[i]);
         }
     }
-    const double im2 = im * im;
+    const double gs = -(tf * (im * im));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gm[i] = -u[i] * im2;
-    const double tf = p.tf;
-    // Phi column: (tf * Dxf) @ col
-    double op[7];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        op[i] = tf * ys[3 + i];
-        double acc = (tf * G[i][0]) * ys[0];
-        acc += (tf * G[i][1]) * ys[1];
-        acc += (tf * G[i][2]) * ys[2];
-        acc += (tf * gm[i]) * ys[6];
-        op[3 + i] = acc;
-    }
-    op[6] = 0.0;
-    // x column: tf * f(x, u)   (meaningful on lane 7 only)
-    double yd[7];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { yd[i] = ys[3 + i]; yd[3 + i] = c1 * r[i] + u[i] * im + j2a[i]; }
-    if (p.flags & MPCX_FLAG_DRAG) {                          // simulator.py:150-153 (the Python Discretizer never sets it)
-        const double vn = sqrt(ys[3] * ys[3] + ys[4] * ys[4] + ys[5] * ys[5]);
+    for (int i = 0; i < 3; ++i) { L.gmt[i] = gs * u[i]; L.acc[i] = c1 * r[i] + u[i] * im + j2a[i]; }
+    if (flags & MPCX_FLAG_DRAG) {                            // simulator.py:150-153 (the Python Discretizer never sets it)
+        const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         const double coef = -0.5 * kCd * c.s * im * (kRho500 / c.rho) * vn;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) yd[3 + i] += coef * ys[3 + i];
+        for (int i = 0; i < 3; ++i) L.acc[i] += coef * v[i];
     }
     const double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-    yd[6] = -(uu * rsq_nr(fmax(uu, 1e-300))) * rcp_nr(c.g0 * c.isp);
+    L.iun = rsq_nr(fmax(uu, 1e-300));
+    L.un = uu * L.iun;
+    L.mdot = -L.un * inv_ve;
+    L.im = im;
+}
+
+// One evaluation of dPhi (linearize_discretize.py:262-290) for this lane's column.
+__device__ __forceinline__ void rhs_eval(RhsCtx &p, const double (&ys)[7], double ts,
+                                         double (&out)[7], int &err)
+{
+    double u[3];
+    foh3_cached(ts, p.us, p.Ku, p.ldu, p.foh, u, err);
+    const double r[3] = {bcast8<7>(ys[0]), bcast8<7>(ys[1]), bcast8<7>(ys[2])};
+    const double v[3] = {ys[3], ys[4], ys[5]};               // drag acts in the x column only: lane 7's own velocity
+    const double m = bcast8<7>(ys[6]);
+    const double tf = p.tf;
+    Lin L;
+    lin_eval(r, v, m, u, p.cst, p.flags, tf, p.inv_ve, L);
     const bool isx = (p.c == 7);
     if (isx && m <= 0.0) err = MPCX_ST_MASS;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) out[i] = isx ? tf * yd[i] : op[i];
+    for (int i = 0; i < 3; ++i) {
+        out[i] = tf * ys[3 + i];                             // both the Phi columns ([0 I 0] rows of Dxf) and x
+        double a = L.Gt[i][0] * ys[0];                       // Phi column: (tf * Dxf) @ col
+        a += L.Gt[i][1] * ys[1];
+        a += L.Gt[i][2] * ys[2];
+        a += L.gmt[i] * ys[6];
+        out[3 + i] = isx ? tf * L.acc[i] : a;                // x column: tf * f(x, u)
+    }
+    out[6] = isx ? tf * L.mdot : 0.0;
 }
 
-// Solve P z = b in place (6x6, partial pivoting); returns false on a zero pivot.
-__device__ __forceinline__ bool lu_solve6(double (&P)[6][6], double (&b)[6])
+// Solve P z = b for the 8 right-hand sides of a group at once, P distributed by columns: lane j < 6 holds column j in
+// col[], every lane its own right-hand side in b[] (lanes 6, 7 run the same instructions on columns nobody reads).
+// Gaussian elimination with partial pivoting, the operations of a LAPACK-style solve in the same order: at step p the
+// owner of column p finds the pivot row and the multipliers, both go to the group by DPP broadcast, every lane swaps and
+// eliminates in its own column and right-hand side.  No lane factorises the whole matrix (8x fewer elimination
+// operations than the replicated 6x6 of round 2, no LDS staging of Phi, 60 registers less).  Returns false on a zero pivot.
+__device__ __forceinline__ bool lu_solve_cols(double (&col)[6], double (&b)[6])
 {
     bool ok = true;
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-        int piv = p;
-        double best = fabs(P[p][p]);
-#pragma unroll
-        for (int i = p + 1; i < 6; ++i) {
-            const double v = fabs(P[i][p]);
-            if (v > best) { best = v; piv = i; }
-        }
-        if (best == 0.0) ok = false;
-#pragma unroll
-        for (int i = p + 1; i < 6; ++i) {
-            const bool sw = (piv == i);
-#pragma unroll
-            for (int j = p; j < 6; ++j) {
-                const double a = P[p][j], bb = P[i][j];
-                P[p][j] = sw ? bb : a;
-                P[i][j] = sw ? a : bb;
-            }
-            const double a = b[p], bb = b[i];
-            b[p] = sw ? bb : a;
-            b[i] = sw ? a : bb;
-        }
-        const double inv = 1.0 / P[p][p];
-#pragma unroll
-        for (int i = p + 1; i < 6; ++i) {
-            const double mlt = P[i][p] * inv;
-#pragma unroll
-            for (int j = p + 1; j < 6; ++j) P[i][j] -= mlt * P[p][j];
-            b[i] -= mlt * b[p];
-        }
+    double invd[6];
+#define MPCX_LU_STEP(P_)                                                                              \
+    {                                                                                                 \
+        constexpr int p = P_;                                                                         \
+        int piv = p;                                                                                  \
+        double best = fabs(col[p]);                                                                   \
+        _Pragma("unroll") for (int i = p + 1; i < 6; ++i) {                                           \
+            const double v = fabs(col[i]);                                                            \
+            if (v > best) { best = v; piv = i; }                                                      \
+        }                                                                                             \
+        piv = bcast8i<p>(piv);                                                                        \
+        if (bcast8<p>(best) == 0.0) ok = false;                                                       \
+        _Pragma("unroll") for (int i = p + 1; i < 6; ++i) {                                           \
+            const bool sw = (piv == i);                                                               \
+            const double a = col[p], bb = col[i];                                                     \
+            col[p] = sw ? bb : a; col[i] = sw ? a : bb;                                               \
+            const double ra = b[p], rb = b[i];                                                        \
+            b[p] = sw ? rb : ra; b[i] = sw ? ra : rb;                                                 \
+        }                                                                                             \
+        invd[p] = bcast8<p>(rcp_nr(col[p]));                                                          \
+        _Pragma("unroll") for (int i = p + 1; i < 6; ++i) {                                           \
+            const double mlt = bcast8<p>(col[i]) * invd[p];                                           \
+            col[i] -= mlt * col[p];                                                                   \
+            b[i] -= mlt * b[p];                                                                       \
+        }                                                                                             \
     }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = b[i];
-#pragma unroll
-        for (int j = i + 1; j < 6; ++j) s -= P[i][j] * b[j];
-        b[i] = s / P[i][i];
-    }
+    MPCX_LU_STEP(0) MPCX_LU_STEP(1) MPCX_LU_STEP(2) MPCX_LU_STEP(3) MPCX_LU_STEP(4) MPCX_LU_STEP(5)
+#undef MPCX_LU_STEP
+    // back substitution: U[i][j] lives on lane j
+    b[5] *= invd[5];
+    b[4] = (b[4] - bcast8<5>(col[4]) * b[5]) * invd[4];
+    b[3] = (b[3] - bcast8<4>(col[3]) * b[4] - bcast8<5>(col[3]) * b[5]) * invd[3];
+    b[2] = (b[2] - bcast8<3>(col[2]) * b[3] - bcast8<4>(col[2]) * b[4] - bcast8<5>(col[2]) * b[5]) * invd[2];
+    b[1] = (b[1] - bcast8<2>(col[1]) * b[2] - bcast8<3>(col[1]) * b[3] - bcast8<4>(col[1]) * b[4] - bcast8<5>(col[1]) * b[5]) * invd[1];
+    b[0] = (b[0] - bcast8<1>(col[0]) * b[1] - bcast8<2>(col[0]) * b[2] - bcast8<3>(col[0]) * b[3] - bcast8<4>(col[0]) * b[4] -
+            bcast8<5>(col[0]) * b[5]) * invd[0];
     return ok;
 }
 
 // Quadrature integrand column of this lane at an accepted node (linearize_discretize.py:60-75):
 // g = Phi(t)^-1 [B lam-, B lam+, Sigma, xi][:, c]
-__device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const double (&y)[7],
+__device__ __forceinline__ void node_integrand(RhsCtx &p, const double (&y)[7],
                                                double t, double tau_k, double tau_kp1,
                                                double (&g)[7], int &err)
 {
@@ -201,52 +208,36 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const dou
     for (int i = 0; i < 7; ++i) x[i] = bcast8<7>(y[i]);
     double u[3];
     foh3_cached(t, p.us, p.Ku, p.ldu, p.foh, u, err);
-    const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);
+    const double lam_n = (tau_kp1 - t) / (tau_kp1 - tau_k);      // exact 1 and 0 at the interval's ends
     const double lam_p = (t - tau_k) / (tau_kp1 - tau_k);
-    const double tf = p.tf, m = x[6];
+    const double tf = p.tf;
 
-    // stage Phi through LDS so that every lane sees the whole matrix
-    if (c < 7) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) rec[i * 7 + c] = y[i];
-    }
-    __syncthreads();
-    double P[6][6], q[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) P[i][j] = rec[i * 7 + j];
-        q[i] = rec[i * 7 + 6];
-    }
-    __syncthreads();
+    const double r[3] = {x[0], x[1], x[2]}, v[3] = {x[3], x[4], x[5]};
+    Lin L;
+    lin_eval(r, v, x[6], u, p.cst, p.flags, tf, p.inv_ve, L);
 
     // B column (B_func :186-215), Sigma (:239-254), xi (:218-236)
-    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     const int j = (c < 3) ? c : c - 3;
     const double uj = (j == 0) ? u[0] : (j == 1 ? u[1] : u[2]);
     const double lam = (c < 3) ? lam_n : lam_p;
-    const double Bm = (tf * (1.0 / m)) * lam;
-    const double den = p.cst.g0 * p.cst.isp * un;
-    const double B6 = (un <= kEps) ? 0.0 : (tf * (-uj / den)) * lam;
-
-    double yd[7];
-    dynamics_unscaled(x, u, p.cst, p.flags, yd);        // Sigma = f(.; tf = 1)
-
-    double G[3][3], gm[3];
-    jacobian_blocks(x[0], x[1], x[2], m, u, p.cst, p.flags, G, gm);
+    const double Bm = (tf * L.im) * lam;
+    const bool nou = L.un <= kEps;                        // B_func's guard: no mass-flow sensitivity at zero thrust
+    const double b6s = -(tf * (p.inv_ve * L.iun));        // tf * d mdot / d u_j = b6s * u_j
+    const double B6 = nou ? 0.0 : (b6s * uj) * lam;
     double xi[7];
     double bu6 = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         xi[i] = -(tf * x[3 + i]);
-        double ax = (tf * G[i][0]) * x[0];
-        ax += (tf * G[i][1]) * x[1];
-        ax += (tf * G[i][2]) * x[2];
-        ax += (tf * gm[i]) * x[6];
-        xi[3 + i] = -(ax + (tf * (1.0 / m)) * u[i]);
-        bu6 += (un <= kEps) ? 0.0 : (tf * (-u[i] / den)) * u[i];
+        double ax = L.Gt[i][0] * x[0];
+        ax += L.Gt[i][1] * x[1];
+        ax += L.Gt[i][2] * x[2];
+        ax += L.gmt[i] * x[6];
+        xi[3 + i] = -(ax + (tf * L.im) * u[i]);
+        bu6 += nou ? 0.0 : (b6s * u[i]) * u[i];
     }
     xi[6] = -(0.0 + bu6);
+    const double sg[7] = {x[3], x[4], x[5], L.acc[0], L.acc[1], L.acc[2], L.mdot};      // Sigma = f(.; tf = 1)
 
     double R[7];
 #pragma unroll
@@ -256,13 +247,13 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, double *rec, const dou
         if (i == 3 + 1) rb = (j == 1) ? Bm : 0.0;
         if (i == 3 + 2) rb = (j == 2) ? Bm : 0.0;
         if (i == 6) rb = B6;
-        R[i] = (c < 6) ? rb : (c == 6 ? yd[i] : xi[i]);
+        R[i] = (c < 6) ? rb : (c == 6 ? sg[i] : xi[i]);
     }
-    // Phi = [[P q],[0 1]]  =>  g6 = R6 ; P g' = R' - q R6
-    double b[6];
+    // Phi = [[P q],[0 1]]  =>  g6 = R6 ; P g' = R' - q R6      (column j of P is lane j's y, q lane 6's)
+    double col[6], b[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = R[i] - q[i] * R[6];
-    if (!lu_solve6(P, b)) err = MPCX_ST_SINGULAR;
+    for (int i = 0; i < 6; ++i) { col[i] = y[i]; b[i] = R[i] - bcast8<6>(y[i]) * R[6]; }
+    if (!lu_solve_cols(col, b)) err = MPCX_ST_SINGULAR;
 #pragma unroll
     for (int i = 0; i < 6; ++i) g[i] = b[i];
     g[6] = R[6];
@@ -307,6 +298,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
     const int n_uni = UNIFORM ? (a.flags >> 8) : 0;                 // integrator_steps
     p.tf = a.tf[s];
     p.cst.load(a.consts + (size_t)s * MPCX_NCONST);
+    p.inv_ve = 1.0 / (p.cst.g0 * p.cst.isp);
     const double *xs = a.xbar + (size_t)s * 7 * a.K;
 
     // np.linspace(0, 1, K)[k], [k+1]
@@ -357,7 +349,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
     double acc[7], gprev[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) acc[i] = 0.0;
-    node_integrand(p, rec, y, t, tau_k, tau_kp1, gprev, err);
+    node_integrand(p, y, t, tau_k, tau_kp1, gprev, err);
 
     // uniform mode: index of the next evaluation point, time of the previous one, the interpolated state at it
     const double ustep = UNIFORM ? (tau_kp1 - tau_k) / (double)(n_uni - 1) : 0.0;   // np.linspace(tau_k, tau_kp1, n)
@@ -420,7 +412,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
             const double e = f[i] * RK_E[0] + K1[i] * RK_E[1] + K2[i] * RK_E[2] + K3[i] * RK_E[3] +
                              K4[i] * RK_E[4] + K5[i] * RK_E[5] + K6[i] * RK_E[6];
             const double sc = atol + fmax(fabs(y[i]), fabs(yn[i])) * rtol;
-            const double q = e * h / sc;
+            const double q = (e * h) * rcp_nr(sc);
             se += q * q;
         }
         const double error_norm = sqrt(group_sum(se)) / sqrt(56.0);
@@ -476,7 +468,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
                         const double accq = Q[i][0] * p1 + Q[i][1] * p2 + Q[i][2] * p3 + Q[i][3] * p4;
                         yd[i] = has ? h * accq + yold[i] : y[i];
                     }
-                    node_integrand(p, rec, yd, has ? te : t, tau_k, tau_kp1, g, err);
+                    node_integrand(p, yd, has ? te : t, tau_k, tau_kp1, g, err);
                     if (has) {
                         const double d = te - te_prev;
 #pragma unroll
@@ -493,7 +485,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
         // node quadrature (wave-uniform call; only accepting groups commit)
         if (!UNIFORM && __any(accept)) {
             double g[7];
-            node_integrand(p, rec, y, t, tau_k, tau_kp1, g, err);
+            node_integrand(p, y, t, tau_k, tau_kp1, g, err);
             if (accept) {
                 const double d = h;          // ts[i+1] - ts[i]
 #pragma unroll

@@ -77,13 +77,14 @@ __device__ __forceinline__ void foh3(double tau, const double *__restrict__ u, i
 // The same first-order hold with the interval in use kept in registers: the two table columns, the node index and the
 // interval's end points are reloaded / recomputed only when tau leaves the cached interval (an RK45 step is short
 // against 1/(Ku-1): the stages of a step and many steps in a row stay inside one interval).  Inside -- away from both
-// ends by more than any rounding of the index computation -- k is certain and the result is bit for bit foh3's (same
-// expressions for lam_n, lam_p); otherwise foh3's own index computation decides.  Saves the fmod of py_floordiv and six
-// dependent global loads per right-hand side.
+// ends by more than any rounding of the index computation -- k is certain and the weights are foh3's up to one rounding
+// (multiplication by the interval's cached reciprocal length instead of two divisions); otherwise -- node times included --
+// foh3's own index computation and expressions decide.  Saves the fmod of py_floordiv, two divisions and six dependent
+// global loads per right-hand side.
 struct FohCache {
     int k;
-    double tau_k, tau_kp1, uk[3], uk1[3];
-    __device__ __forceinline__ void reset() { k = -1; tau_k = 2.0; tau_kp1 = -1.0; }
+    double tau_k, tau_kp1, inv, uk[3], uk1[3];
+    __device__ __forceinline__ void reset() { k = -1; tau_k = 2.0; tau_kp1 = -1.0; inv = 0.0; }
 };
 
 __device__ __forceinline__ void foh3_cached(double tau, const double *__restrict__ u, int Ku, int ld, FohCache &c, double (&out)[3],
@@ -107,12 +108,25 @@ __device__ __forceinline__ void foh3_cached(double tau, const double *__restrict
             c.tau_k = (double)k / km1; c.tau_kp1 = (double)(k + 1) / km1;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { c.uk[i] = u[i * ld + k]; c.uk1[i] = u[i * ld + k + 1]; }
+            c.inv = 1.0 / (c.tau_kp1 - c.tau_k);
         }
+        const double lam_n = (c.tau_kp1 - tau) / (c.tau_kp1 - c.tau_k);
+        const double lam_p = (tau - c.tau_k) / (c.tau_kp1 - c.tau_k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
+        return;
     }
-    const double lam_n = (c.tau_kp1 - tau) / (c.tau_kp1 - c.tau_k);
-    const double lam_p = (tau - c.tau_k) / (c.tau_kp1 - c.tau_k);
+    const double lam_n = (c.tau_kp1 - tau) * c.inv, lam_p = (tau - c.tau_k) * c.inv;
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = lam_n * c.uk[i] + lam_p * c.uk1[i];
+}
+
+// bcast8 for a 32-bit integer
+template <int Q>
+__device__ __forceinline__ int bcast8i(int v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x150 + Q, 0xF, 0xF, true);
+    return __builtin_amdgcn_update_dpp(t, v, 0x150 + 8 + Q, 0xF, 0xC, false);
 }
 
 // Value of lane q of the caller's 8-lane group in all 8 lanes (q a compile-time constant): two v_mov_b64_dpp -- gfx950 has
