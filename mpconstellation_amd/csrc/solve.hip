@@ -77,7 +77,7 @@ constexpr int RHS_LD = RHS_N + 1, CMB_LD = 33;   // LDS strides of newton_blocks
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0, kMuErr = 1e-6;
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kMuInitClean = 0.01, kCleanRadius = 3.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0, kMuErr = 1e-6;
 constexpr int kFbN = 8;
 
 struct SolveOpts {
@@ -2969,6 +2969,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             WG_SYNC();
         }
     }
+    bool pushed = false;
     for (int k = lane; k < K; k += 64) {
         double x[7], u[3];
         for (int i = 0; i < 7; ++i) x[i] = s.xbar[(size_t)i * s.ldk + k];
@@ -2980,13 +2981,36 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         for (int i = 0; i < IT_N; ++i) { p[i] = 0.0; d[i] = 0.0; }
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
-        // slacks pushed into the interior (bound_push), multipliers 1
+        // slacks pushed into the interior (bound_push); the multipliers follow below, once the start value of mu is known
+        const double pu = kBoundPush * fmax(1.0, fabs(sd.b_u)), su = -(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u);
+        const double pmax = kBoundPush * fmax(1.0, fabs(sd.b_rmax)), smax = -(rn * rn - sd.b_rmax);
+        const double pmin = kBoundPush * fmax(1.0, fabs(sd.b_rmin)), smin = -(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin);
+        p[I_SU] = fmax(su, pu); p[I_SRMAX] = fmax(smax, pmax); p[I_SRMIN] = fmax(smin, pmin);
+        // (the constraints proper: thrust ball k = 0..K-1, r_max ball k = 1..K-1, r_min plane k = 1..K-2)
+        if (su < pu || (k >= 1 && smax < pmax) || (k >= 1 && k <= K - 2 && smin < pmin)) pushed = true;
+    }
+    // A clean start ("Solver algorithm"): the reference strictly inside its stage constraints and the tf range
+    // begins at mu = kMuInitClean and lets mu fall superlinearly; any other start, a fixed-tf solve and the shared-tf launch
+    // (one mu for all its satellites) keep kMuInit and the kSigma rule.
+    bool clean = !SHARED && !sd.fixed_tf && !__any(pushed);      // (fixed-tf solves feed a host root search with their g_tf: left as they were)
+    if (clean) {
+        const double tf = sd.tfbar;
+        if (-(-tf - sd.b_tf[0]) < kBoundPush * fmax(1.0, fabs(sd.b_tf[0])) || -(tf - sd.b_tf[1]) < kBoundPush * fmax(1.0, fabs(sd.b_tf[1])))
+            clean = false;
+        // ... and the reference ends within kCleanRadius half-widths of the terminal radius window
+        const double xr[3] = {s.xbar[K - 1], s.xbar[(size_t)Kmax + K - 1], s.xbar[(size_t)2 * Kmax + K - 1]};
+        if (!(fabs(sqrt(xr[0] * xr[0] + xr[1] * xr[1] + xr[2] * xr[2]) - a.r_des[sat]) <= kCleanRadius * o.eps_r)) clean = false;
+    }
+#ifdef MPCX_NO_CLEAN_START      // measurement builds only (profiles/tools): every start treated as it was before round 3
+    clean = false;
+#endif
+    const double mu0 = clean ? kMuInitClean : kMuInit;
+    for (int k = lane; k < K; k += 64) {
+        const auto p = s.itn(k);
         // L1 slack pairs start dual feasible and centred: z+ = z- = w_nu/2, s = t = mu/z
-        if (k <= K - 2) for (int i = 0; i < 7; ++i) { const double zl = sd.w_nu / 2.0, sl = kMuInit / zl; p[I_T + i] = sl; p[I_STP + i] = sl; p[I_STN + i] = sl; p[I_ZTP + i] = zl; p[I_ZTN + i] = zl; }
+        if (k <= K - 2) for (int i = 0; i < 7; ++i) { const double zl = sd.w_nu / 2.0, sl = mu0 / zl; p[I_T + i] = sl; p[I_STP + i] = sl; p[I_STN + i] = sl; p[I_ZTP + i] = zl; p[I_ZTN + i] = zl; }
         else for (int i = 0; i < 7; ++i) { p[I_STP + i] = 1.0; p[I_STN + i] = 1.0; p[I_ZTP + i] = 1.0; p[I_ZTN + i] = 1.0; }
-        p[I_SU] = fmax(-(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - sd.b_u), kBoundPush * fmax(1.0, fabs(sd.b_u))); p[I_ZU] = kMuInit / p[I_SU];
-        p[I_SRMAX] = fmax(-(rn * rn - sd.b_rmax), kBoundPush * fmax(1.0, fabs(sd.b_rmax))); p[I_ZRMAX] = kMuInit / p[I_SRMAX];
-        p[I_SRMIN] = fmax(-(-(rb[0] * x[0] + rb[1] * x[1] + rb[2] * x[2]) - sd.b_rmin), kBoundPush * fmax(1.0, fabs(sd.b_rmin))); p[I_ZRMIN] = kMuInit / p[I_SRMIN];
+        p[I_ZU] = mu0 / p[I_SU]; p[I_ZRMAX] = mu0 / p[I_SRMAX]; p[I_ZRMIN] = mu0 / p[I_SRMIN];
     }
     if (lane == 0) {
         for (int i = 0; i < GL_N; ++i) { s.itg[i] = 0.0; s.drg[i] = 0.0; }
@@ -2995,18 +3019,18 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         for (int j = 0; j < sd.nT; ++j) {
             double gj = -sd.bT[j];
             for (int i = 0; i < 7; ++i) gj += sd.aT[j][i] * xK[i];
-            s.itg[gs_term(j)] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[gz_term(j)] = kMuInit / s.itg[gs_term(j)];
+            s.itg[gs_term(j)] = fmax(-gj, kBoundPush * fmax(1.0, fabs(sd.bT[j]))); s.itg[gz_term(j)] = mu0 / s.itg[gs_term(j)];
         }
         const double r2 = xK[0] * xK[0] + xK[1] * xK[1] + xK[2] * xK[2];
-        s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = kMuInit / s.itg[G_SRF];
+        s.itg[G_SRF] = fmax(-(r2 - sd.b_rfmax), kBoundPush * fmax(1.0, fabs(sd.b_rfmax))); s.itg[G_ZRF] = mu0 / s.itg[G_SRF];
         const double tf = (sd.fixed_tf && !SHARED) ? a.tf_out[sat] : sd.tfbar;      // (fixed: the value to hold comes in through tf_out)
         s.itg[G_TF] = tf;
-        s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = kMuInit / s.itg[G_STF];
-        s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = kMuInit / s.itg[G_STF + 1];
+        s.itg[G_STF] = fmax(-(-tf - sd.b_tf[0]), kBoundPush * fmax(1.0, fabs(sd.b_tf[0]))); s.itg[G_ZTF] = mu0 / s.itg[G_STF];
+        s.itg[G_STF + 1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); s.itg[G_ZTF + 1] = mu0 / s.itg[G_STF + 1];
     }
     WG_SYNC();
 
-    double mu = kMuInit, dw_last = 0.0;        // mu: this iteration's complementarity target
+    double mu = mu0, dw_last = 0.0;            // mu: this iteration's complementarity target
     // (shared tf: the counts of the whole launch -- S satellites without their own tf rows plus tf's two range inequalities)
     const int nzc = SHARED ? a.S * n_ineq(K, sd.nT, 1) + 2 : n_ineq(K, sd.nT, sd.fixed_tf);
     const int nlc = (SHARED ? a.S : 1) * (7 * (K - 1) + (sd.nT == 6 ? 1 : 0));
@@ -3049,7 +3073,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             mu = fmax(o.tol / 10.0, fmin(kMuInit, kFbBoost * mu_cur));
         }
         // (never below kMuErr * E_0: the mean complementarity may collapse while the iterate is still infeasible)
-        if (!mono) mu = fmax(fmax(kSigma * mu_cur, o.tol / 10.0), kMuErr * E0);
+        if (!mono) mu = fmax(fmax(clean ? fmin(kSigma * mu_cur, mu_cur * sqrt(mu_cur)) : kSigma * mu_cur, o.tol / 10.0), kMuErr * E0);
         else {
             // mu moves on only when the barrier problem is solved to E_mu <= 10 mu: mu <- max(tol/10, min(0.2 mu, mu^1.5))
             for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error_n(r0, nzc, nlc, mu) <= 10.0 * mu; ++lv)

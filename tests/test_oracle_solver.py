@@ -101,7 +101,7 @@ def test_status_codes(golden_dir):
     r = N.solve(P, max_iter=4)
     assert r["status"] == N.ST_MAXITER and r["iters"] == 4
     # a tolerance fp64 does not reach: three consecutive iterates at the acceptable level end the run
-    r = N.solve(P, tol=1e-12, acceptable_tol=1e-6, acceptable_iter=3, max_iter=120)
+    r = N.solve(P, tol=1e-15, acceptable_tol=1e-6, acceptable_iter=3, max_iter=120)
     assert r["status"] == N.ST_ACCEPTABLE and r["kkt"] <= 1e-6
 
 
