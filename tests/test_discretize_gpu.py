@@ -86,6 +86,30 @@ def test_random_batch_vs_oracle():
             assert relerr(g, o[k]) < RTOL, (s, k)
 
 
+def test_long_intervals_exercise_the_pivoting():
+    """Intervals of a third to a full orbit: Phi is far from the identity, its first column's largest entry is off the
+    diagonal, so the quadrature solve's partial pivoting (lu_solve_cols: pivot row chosen by the column's owner, rows
+    swapped in every lane) really exchanges rows -- on the benchmark's short intervals it never does.  Against the CPU
+    oracle, which inverts Phi by its own pivoted LU (np.linalg.inv of the reference)."""
+    from mpconstellation_amd import Discretizer
+    cst = np.array([39.47841760435743, 0.92, 1.08262668E-3, 46.5, 0.0873, 1e-12, 6.9e6, 3.7e-17])
+    tan = O.make_ctrl(O.CTRL_TANGENTIAL, (0.3, 0, 0))
+    y0 = np.array([1, 0, 0, 0, 2 * np.pi, 0.4, 1.0])
+    disc = Discretizer(_Const(cst))
+    swaps = 0
+    for K, tf in ((3, 2.0), (4, 1.0), (3, 0.7), (5, 3.0)):
+        x, rc, _ = O.propagate(y0, tf, cst, tan, K)
+        assert rc == 0
+        u = np.full((3, K), 0.2)
+        A, Bp, Bn, Sig, xi = disc.discretize(satellite_dynamics, x, u, tf)
+        o = O.discretize(x, u, tf, cst)
+        assert o["status"] == 0
+        for k, g in zip(KEYS, (A, Bp, Bn, Sig, xi)):
+            assert relerr(g, o[k]) < 1e-8, (K, tf, k)          # (Phi's condition number is 1e3 .. 2e4 here)
+        swaps += int((np.abs(o["A"][:, 1:6, 0]).max(axis=1) > np.abs(o["A"][:, 0, 0])).sum())
+    assert swaps >= 3
+
+
 def test_status_codes():
     from mpconstellation_amd import Discretizer
     cst = np.array([39.47841760435743, 0.92, 1.08262668E-3, 46.5, 0.0873, 1e-12, 6.9e6, 3.7e-17])
