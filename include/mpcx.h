@@ -150,9 +150,10 @@ typedef struct {
  * S is limited to the workgroups the device holds at once (2048 on MI355X); no ragged batches. */
 #define MPCX_SOLVE_SHARED_TF 8
 
-/* Batches of at most 512 satellites (no more than one per two SIMDs of an MI355X) are solved by a kernel with TWO waves per
- * satellite that share the factorisation of every interior-point iteration; results are bit for bit those of the one-wave
- * kernel larger batches use.  This flag keeps the one-wave kernel for small batches too (comparisons, profiling). */
+/* Batches of at most 1024 satellites (no more than one per SIMD of an MI355X) are solved by a kernel with TWO waves per
+ * satellite that share the factorisation of every interior-point iteration; its results agree with the one-wave kernel
+ * larger batches use to rounding (1e-13 .. 1e-11 on the solutions, same iteration counts), not bit for bit.  This flag
+ * keeps the one-wave kernel for small batches too: a satellite's result is then bit for bit what any larger batch gives it. */
 #define MPCX_SOLVE_ONE_WAVE 16
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);

@@ -3362,7 +3362,10 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_shared_kernel(Solv
 using namespace MPCX_NS;
 
 int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);      // solve2w.hip
-constexpr int kTwoWaveMax = 512;
+#ifndef MPCX_TWO_WAVE_MAX
+#define MPCX_TWO_WAVE_MAX 1024      // two waves per satellite pay up to one satellite per SIMD (profiles/r03/batch_size_sweep.txt)
+#endif
+constexpr int kTwoWaveMax = MPCX_TWO_WAVE_MAX;
 
 static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
 {

@@ -2,6 +2,8 @@
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
+from mpconstellation_amd import _ffi
+if os.environ.get("MPCX_LIB"): _ffi.LIB_PATH = os.path.abspath(os.environ["MPCX_LIB"])       # A/B against another build
 import torch, bench
 for S in [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 2048, 3072, 4096, 8192]:
     name = f"S{S}_K30"

@@ -89,7 +89,7 @@ def test_satellites_are_independent_units():
     """What the multi-GPU sharding relies on: a satellite's result does not depend on which batch, which position or
     which block it is solved in (bit for bit)."""
     from mpconstellation_amd import mpc_step_batch
-    S, K = 1024, 30
+    S, K = 2048, 30
     xbar, ubar, consts, r_des = workload(S, K)
     tf = np.ones(S)
     whole = mpc_step_batch(xbar, ubar, tf, consts, r_des)
@@ -109,20 +109,20 @@ def test_satellites_are_independent_units():
         first, count = shard_block(S, 8, rank)
         xb, ub, cb, rb = workload(S, K, first, count)
         assert np.array_equal(xb, xbar[first:first + count])
-        # (flags=16, MPCX_SOLVE_ONE_WAVE: the 128-satellite block through the same one-wave kernel as the 1024 batch; batches of
-        #  up to 512 otherwise run on the two-wave kernel, which agrees with it to rounding, not bit for bit: see below)
+        # (flags=16, MPCX_SOLVE_ONE_WAVE: the 256-satellite block through the same one-wave kernel as the 2048 batch; batches of
+        #  up to 1024 otherwise run on the two-wave kernel, which agrees with it to rounding, not bit for bit: see below)
         part = mpc_step_batch(xb, ub, np.ones(count), cb, rb, flags=16)
         assert np.array_equal(part.X, whole.X[first:first + count]) and np.array_equal(part.tf, whole.tf[first:first + count])
 
 
 def test_two_wave_small_batch_kernel():
-    """Batches of up to 512 satellites run on the two-wave kernel (solve2w.hip: a second wave per satellite shares the
+    """Batches of up to 1024 satellites run on the two-wave kernel (solve2w.hip: a second wave per satellite shares the
     factorisation).  It must give what the one-wave kernel gives (MPCX_SOLVE_ONE_WAVE = 16) -- same iteration counts (see below), same
     statuses, solutions equal to rounding -- on the benchmark constellation at K = 30 and 100, on OptimalController's
     option set (stiff terminal windows: refinement passes) and at the shortest horizon; and like the one-wave kernel it
     must not care who shares the batch (bit for bit between a batch of 64, its reversal and single-satellite calls)."""
     from mpconstellation_amd import mpc_step_batch
-    for S, K, opts in ((64, 30, {}), (48, 100, {}), (512, 30, {}), (128, 30, {"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}), (5, 3, {})):
+    for S, K, opts in ((64, 30, {}), (48, 100, {}), (1024, 30, {}), (128, 30, {"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}), (5, 3, {})):
         xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
         tf = np.ones(S)
         one = mpc_step_batch(xbar, ubar, tf, consts, r_des, options=opts, flags=16, regularised=True)
