@@ -2918,6 +2918,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
+    PT_BEGIN
     if (lane == 0) {
         double xK[7];
         for (int i = 0; i < 7; ++i) xK[i] = s.xbar[(size_t)i * Kmax + K - 1];
@@ -3053,6 +3054,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
     // (sq in its mu = 0 form: it serves E_0 and, for any mu, the line search's ||F_mu||)
     ResAcc r0;
+    PT_END(6)
     PT_BEGIN
     eval_residual<false>(s, sd, 0.0, 0.0, 0.0, lane, r0);
     PT_END(0)
