@@ -171,7 +171,7 @@ def measured_traffic(workload, kernel="solve_kernel"):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         prof = json.load(open(f))
         ks = prof.get("workloads", {}).get(workload, {})
-        w = ks.get(kernel) or ks.get(kernel + "2w")          # (batches of up to 512 run on the two-wave build's kernel)
+        w = ks.get(kernel) or ks.get(kernel + "2w")          # (batches of up to 1024 run on the two-wave build's kernel)
         if not w: continue
         src = os.path.relpath(f, ROOT)
         want = prof.get("kernel_source_sha256")
@@ -308,12 +308,13 @@ def main():
     single_dev = os.environ.get("MPCX_BENCH_SINGLE_DEVICE") == "1"   # rehearsal of the N>1 path on a 1-GPU box (gloo)
     if single_dev:
         local_rank = 0
+    have_gpu = torch.cuda.is_available()
+    if have_gpu: torch.cuda.set_device(local_rank)       # before the process group: RCCL binds its communicator to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if (single_dev or not torch.cuda.is_available()) else "nccl")
-    if not torch.cuda.is_available():
+        dist.init_process_group("gloo" if (single_dev or not have_gpu) else "nccl")
+    if not have_gpu:
         raise SystemExit("bench.py needs an MI355X: libmpcx has no CPU fallback")
-    torch.cuda.set_device(local_rank)
     workload = args.workload or (DEFAULT_SINGLE if world == 1 else DEFAULT_MULTI)
 
     run = Runner(workload, rank, world, local_rank)
