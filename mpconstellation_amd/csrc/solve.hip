@@ -77,7 +77,10 @@ constexpr int RHS_LD = RHS_N + 1, CMB_LD = 33;   // LDS strides of newton_blocks
 constexpr int NCH = 8;        // channel 0: rhs, 1: dtf, 2: vt multiplier, 3..7: terminal rank-1 terms
 constexpr int NBD = 7;        // border unknowns
 constexpr int NTERM = 5;
-constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = 1e9, kMuInit = 1.0, kMuInitClean = 0.01, kCleanRadius = 3.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0, kMuErr = 1e-6;
+#ifndef MPCX_REFINE_TW
+#define MPCX_REFINE_TW 1e10     // (1e9 until round 3: profiles/r03/refine_threshold.txt)
+#endif
+constexpr double kBoundRelax = 1e-8, kBoundPush = 1e-4, kKappaSigma = 100.0, kGammaNbhd = 1e-8, kAlphaFloor = 0.25, kDwFirst = 1e-4, kDwMin = 1e-20, kDwMax = 1e40, kTermCap = 1e4, kStageCap = 1e8, kRefineTw = MPCX_REFINE_TW, kMuInit = 1.0, kMuInitClean = 0.01, kCleanRadius = 3.0, kSigma = 0.1, kFbAlpha = 0.1, kFbBoost = 10.0, kMuErr = 1e-6;
 constexpr int kFbN = 8;
 
 struct SolveOpts {
