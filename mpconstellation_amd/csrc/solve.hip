@@ -1066,7 +1066,7 @@ struct Scratch {   // LDS working set of the recursion (and, between recursions,
     double stage_pad[32 * (NB_N + RHS_LD) - 1129 > 0 ? 32 * (NB_N + RHS_LD) - 1129 : 1];   // newton_blocks stages 32 Newton + 32 rhs records here
 };
 
-static_assert(sizeof(Scratch) >= 32 * (NB_N + RHS_LD) * sizeof(double) && sizeof(Scratch) >= TR_N * CMB_LD * sizeof(double), "newton_blocks stages 32 Newton and right-hand-side records in the recursion's scratch");
+static_assert(sizeof(Scratch) >= 32 * (NB_N + RHS_LD) * sizeof(double) && sizeof(Scratch) >= TR_N * CMB_LD * sizeof(double) && sizeof(Scratch) >= 64 * RHS_LD * sizeof(double), "newton_blocks stages 32 Newton and right-hand-side records in the recursion's scratch");
 
 template <int N>
 __device__ __forceinline__ double dotN(const double *a, int sa, const double *b, int sb)
@@ -2509,16 +2509,46 @@ __device__ __noinline__ bool border_solve_shared(SatData &sd, GridSync &g, doubl
 // refinement pass solves for small corrections of all border unknowns and thereby removes the cancellation error the
 // first pass's combination of O(1) channel trajectories into an O(1e-8) direction leaves in dx_K (which a terminal
 // weight of 1e16 would turn into an O(1) error of the new multipliers).
-__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
+// stg: LDS staging area (the recursion's scratch, idle here) of 64 right-hand-side records: they leave as coalesced blocks
+// (straight from the node lanes they were 24 eight-byte stores per node, each to its own cache line: this phase was as long
+// as a factorisation on problems that refine in most iterations -- the stiff terminal windows of OptimalController's options).
+__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double *stg, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
 {
     const int K = s.K;
     double gtf_part = 0.0;
     const double dtf = s.drg[G_TF];
-    for (int k = lane; k < K; k += 64) {
+    // terminal-node completion terms (the rank-1 terms and the AL shift): from the direction at node K-1, known up front
+    double gin[NTERM], rvt_x;
+    {
+        const auto dK = s.drn(K - 1);
+        double av = 0.0;
+        for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
+        rvt_rhs = -sd.cv - av;
+        rvt_x = rvt_rhs;            // what the x_K row's shift -gam * rvt_x * a_vt uses (the same value for the equality)
+        if (sd.linvt) {
+            // the tangential pair as a terminal rank-1 term: gam is its capped share, zeta_vt its border unknown
+            const double wex = sd.w_vt - sd.gam;
+            const bool on = wex > 0.0;
+            rvt_x = -(sd.gh_vt * (sd.gam / sd.w_vt) + sd.gam * av + (on ? sd.zeta_vt : 0.0)) / sd.gam;
+            rvt_rhs = on ? -(av - sd.zeta_vt / wex + sd.gh_vt / sd.w_vt) : 0.0;
+        }
+        for (int t = 0; t < NTERM; ++t) {   // coefficient of a_t in the x_K row: gh share + win a.dx + zeta
+            double adx = 0.0;
+            for (int i = 0; i < 7; ++i) adx += sd.ta[t][i] * dK[I_X + i];
+            const double wex = sd.tw[t] - sd.twin[t];
+            const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
+            const bool on = wex > 0.0;
+            gin[t] = sd.tgh[t] * share + sd.twin[t] * adx + (on ? sd.zeta[t] : 0.0);
+            gex[t] = on ? (adx - sd.zeta[t] / wex + sd.tgh[t] / sd.tw[t]) * wex : 0.0;
+        }
+    }
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      double *rec = stg + lane * RHS_LD;
+      if (k < K) {
         cgf64 *nb = s.nb + (size_t)k * NB_N;
         const auto ns = s.nsn(k);
         const auto p = s.itn(k), d = s.drn(k);
-        gf64 *rec = s.ch + (size_t)k * CH_N + C_RHS;
         double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -2617,42 +2647,28 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, int lan
             }
             gtf_part -= sl;
         }
+        if (k == K - 1) {
+            // terminal-node completion: the rank-1 terms and the AL shift; its rho / aff slots are zero as in the first record
+            for (int t = 0; t < NTERM; ++t)
+                for (int i = 0; i < 7; ++i) gx[i] += gin[t] * sd.ta[t][i];
+            for (int i = 0; i < 7; ++i) gx[i] -= sd.gam * rvt_x * sd.avt[i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { rec[R_RHO + i] = 0.0; rec[R_AFF + i] = 0.0; }
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) rec[R_GX + i] = gx[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) rec[R_GU + i] = gu[i];
+      }
+      WG_SYNC();
+      {
+          const int nr = ((K - k0 < 64) ? K - k0 : 64) * RHS_N;
+          gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
+          for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[kl * RHS_LD + i]; }
+      }
+      WG_SYNC();
     }
     gtf_rhs = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
-    const auto dK = s.drn(K - 1);
-    double av = 0.0;
-    for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
-    rvt_rhs = -sd.cv - av;
-    double rvt_x = rvt_rhs;     // what the x_K row's shift -gam * rvt_x * a_vt uses (the same value for the equality)
-    if (sd.linvt) {
-        // the tangential pair as a terminal rank-1 term: gam is its capped share, zeta_vt its border unknown
-        const double wex = sd.w_vt - sd.gam;
-        const bool on = wex > 0.0;
-        rvt_x = -(sd.gh_vt * (sd.gam / sd.w_vt) + sd.gam * av + (on ? sd.zeta_vt : 0.0)) / sd.gam;
-        rvt_rhs = on ? -(av - sd.zeta_vt / wex + sd.gh_vt / sd.w_vt) : 0.0;
-    }
-    double gin[NTERM];          // coefficient of a_t in the x_K row: gh share + win a.dx + zeta
-    for (int t = 0; t < NTERM; ++t) {
-        double adx = 0.0;
-        for (int i = 0; i < 7; ++i) adx += sd.ta[t][i] * dK[I_X + i];
-        const double wex = sd.tw[t] - sd.twin[t];
-        const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-        const bool on = wex > 0.0;
-        gin[t] = sd.tgh[t] * share + sd.twin[t] * adx + (on ? sd.zeta[t] : 0.0);
-        gex[t] = on ? (adx - sd.zeta[t] / wex + sd.tgh[t] / sd.tw[t]) * wex : 0.0;
-    }
-    WG_SYNC();
-    // terminal-node rhs completion: the rank-1 terms and the AL shift
-    if (lane == 0) {
-        gf64 *rec = s.ch + (size_t)(K - 1) * CH_N + C_RHS;
-        for (int t = 0; t < NTERM; ++t)
-            for (int i = 0; i < 7; ++i) rec[R_GX + i] += gin[t] * sd.ta[t][i];
-        for (int i = 0; i < 7; ++i) rec[R_GX + i] -= sd.gam * rvt_x * sd.avt[i];
-    }
     WG_SYNC();
 }
 
@@ -3121,7 +3137,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 bool okl = riccati_factor(s, sd, w, lane, true, passes > 1);     // (a local breakdown is reported through the border's reduction)
                 bool ok = true;
                 for (int pass = 0; pass < passes && ok; ++pass) {
-                    if (okl && pass > 0) { reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gex); sweep_backward(s, sd, w, 0, 1, lane); }
+                    if (okl && pass > 0) { reduced_residual(s, sd, (double *)&w, lane, gtf_rhs, rvt_rhs, gex); sweep_backward(s, sd, w, 0, 1, lane); }
                     if (okl) {
                         sweep_forward(s, sd, w, 0, (pass == 0) ? NCH : 1, lane);
                         if (pass == 0) okl = border_factor_shared(sd, lane);
@@ -3172,7 +3188,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 for (int pass = 0; pass < passes && ok; ++pass) {
                     if (pass > 0) {
                         PT_BEGIN
-                        reduced_residual(s, sd, lane, gtf_rhs, rvt_rhs, gex);
+                        reduced_residual(s, sd, (double *)&w, lane, gtf_rhs, rvt_rhs, gex);
                         PT_END(5)
                     }
                     // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only

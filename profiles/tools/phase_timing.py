@@ -16,8 +16,11 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rep = lambda a: np.repeat(a[None], S, axis=0)
 import time
 args = (rep(d["A"]), rep(d["Bp"]), rep(d["Bn"]), rep(d["Sigma"]), rep(d["xi"]), rep(x), rep(u), [tf] * S, rep(cst), [np.linalg.norm(x[:3, -1])] * S)
-r = solve_batch(*args)
-t0 = time.perf_counter(); r = solve_batch(*args); wall = time.perf_counter() - t0
+import ast
+opts = ast.literal_eval(os.environ.get("OPTS", "{}"))          # e.g. OptimalController's set: OPTS='{"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}'
+if "r_des" in opts: args = args[:-1] + ([opts.pop("r_des")] * S,)
+r = solve_batch(*args, options=opts)
+t0 = time.perf_counter(); r = solve_batch(*args, options=opts); wall = time.perf_counter() - t0
 print(f"S {S}: host-pointer solve_batch wall {wall*1e3:.3f} ms (copies of {S*30*17*8/1e6:.1f} MB results included)")
 names = ["eval_res(E0,Emu,r0)", "newton_blocks", "riccati_factor", "sweep_bwd 8ch", "sweep_fwd 8ch+border", "reduced_residual",
          "start-up (terms, transposition, start point)", "border_solve+comb fwd", "finish_direction", "apply_step", "line-search evals", "-"]
