@@ -80,6 +80,34 @@ def test_solve_vs_oracle(golden_dir, name):
     assert abs(np.linalg.norm(h) / np.linalg.norm(res.X[0][:3, -1]) - P.vt_des) < 1e-7   # tangential speed = vt_des
 
 
+def test_clean_start_classification_matches_the_oracle(golden_dir):
+    """The start value of mu and the superlinear barrier rule depend on whether the start is "clean" (reference strictly
+    inside its stage constraints and the tf range, ending within 3 eps_r of r_des: DESIGN.md, "Solver algorithm").  Kernel
+    and oracle must classify alike on both sides of every criterion: same iteration counts, same solutions -- and the clean
+    starts are the short ones."""
+    from mpconstellation_amd import solve_batch
+    d, x, u, tf, cst = load(golden_dir, "tan_K30_tf1")
+    stage = {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")}
+    rK = float(np.linalg.norm(x[:3, -1])); eps = 0.01
+    umax = float(np.sqrt((u ** 2).sum(0).max()))
+    cases = [("clean", rK, {}, True),
+             ("radius 2.9 eps off", rK + 2.9 * eps, {}, True), ("radius 3.1 eps off", rK + 3.1 * eps, {}, False),
+             ("tf_bar on its bound", rK, {"tf_max": tf}, False), ("tf_bar inside", rK, {"tf_max": 1.01 * tf}, True),
+             ("thrust limit below the reference", rK, {"u_lim": [0, 0.9 * umax]}, False)]
+    iters = {}
+    for name, r_des, opts, clean in cases:
+        P, ref = oracle_solve(x, u, tf, cst, r_des, stage, options=dict(opts))
+        assert bool(ref["iterate"].clean) == clean, name
+        res = solve_batch(d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None],
+                          [tf], cst[None], [r_des], options=dict(opts), regularised=True)
+        assert ref["status"] == 0 and res.status[0] == 0, name
+        if ref["n_regularised"] == 0 and res.n_regularised[0] == 0:
+            assert abs(int(res.iters[0]) - ref["iters"]) <= 1, (name, res.iters[0], ref["iters"])
+            assert np.abs(res.X[0] - ref["X"]).max() < (5 * TOL if res.iters[0] == ref["iters"] else TOL_SOL), name
+        iters[name] = int(res.iters[0])
+    assert iters["clean"] < iters["tf_bar on its bound"] and iters["radius 2.9 eps off"] < iters["radius 3.1 eps off"] + 3
+
+
 def test_fused_step_batch_vs_oracle(golden_dir):
     """discretize + solve fused on the device for a ragged batch (different satellites, constants, r_des)."""
     from mpconstellation_amd import mpc_step_batch
