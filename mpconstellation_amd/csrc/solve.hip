@@ -3514,7 +3514,8 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     }
     a.nreg = ctx->nreg; ctx->nreg_S = S;
     // longest-first launch order from the previous solve's iteration counts (include/mpcx.h, MPCX_SOLVE_INDEX_ORDER)
-    const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER);
+    // (a batch the device holds at once has no order to choose: every satellite starts at time 0)
+    const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER) && S > ctx->n_slots;
     a.order = nullptr;
     if (adaptive) {
         // grow-only buffers (a smaller batch reuses them: no free / allocation, hence no implicit device synchronisation,
