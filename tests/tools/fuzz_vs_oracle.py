@@ -1,6 +1,6 @@
 """checking helper (GPU box): random satellites, horizons and option sets, device (mpc_step_batch through the C ABI) against the
 CPU oracle: status, iteration count, regularised iterations, |dX|, |dtf|.  The oracle is the checker here as in tests/.
-usage: python profiles/tools/fuzz_vs_oracle.py [n_problems] [seed]"""
+usage: python tests/tools/fuzz_vs_oracle.py [n_problems] [seed]      (lives under tests/: it uses oracle/ as the checker)"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
