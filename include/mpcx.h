@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 300
+#define MPCX_VERSION 301
 
 /* return codes */
 #define MPCX_OK 0
@@ -286,6 +286,21 @@ int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int3
                                     const double *tf, const double *consts, int flags, int ctrl_kind,
                                     const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
                                     double max_step, double *y_out, int32_t *status, int32_t *nsteps, void *stream);
+/*
+ * The same rollout that also returns Discretizer.extract_uk (linearize_discretize.py:393-411) of its controller: u_out
+ * [S][3][n_eval] = u_func(x_k, t_k) at every output point (control.py:66-84 for the tangential law, :104-142 for a
+ * sequence, the constant vector, zeros) -- the reference thrust u_bar that OptimalController.update (control.py:187,222)
+ * derives from the trajectory it has just computed.  u_out may be NULL (then it is mpcx_propagate_batch_ragged).
+ */
+int mpcx_propagate_thrust_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                       const double *tf, const double *consts, int flags, int ctrl_kind,
+                                       const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                       double max_step, double *y_out, double *u_out, int32_t *status, int32_t *nsteps);
+int mpcx_propagate_thrust_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                           const double *tf, const double *consts, int flags, int ctrl_kind,
+                                           const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                           double max_step, double *y_out, double *u_out, int32_t *status, int32_t *nsteps,
+                                           void *stream);
 /*
  * Replaces Discretizer.extract_uk (linearize_discretize.py:393-411) for a SequenceController played over its own horizon
  * (control.py:217-221, tf_sim = tf_u: end_tau = 1): the first-order hold (control.py:104-126) of table u [S][3][Ku]

@@ -87,6 +87,10 @@ _SIGS = {
                                               _dp, C.c_double, _dp, _ip, _ip]),
     "mpcx_propagate_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
                                                   _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "mpcx_propagate_thrust_batch_ragged": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _ip,
+                                                     _dp, C.c_double, _dp, _dp, _ip, _ip]),
+    "mpcx_propagate_thrust_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                                         _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpcx_resample_sequence_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
 }
 

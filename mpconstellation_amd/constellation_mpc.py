@@ -181,10 +181,10 @@ class ConstellationMPC:
         S = len(self.sats)
         y0 = self._y0() if y0 is None else y0
         K = int(self.base_res * self.horizon)
-        x, st, _ = self._timed("rollouts", propagate_batch, y0, self.horizon, self.consts,
-                               (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, False, False, 0.001, self.device)
+        # (thrust=True: extract_uk of the rollout's controller, control.py:187 / :222, comes back from the same launch)
+        x, st, _, u_bar = self._timed("rollouts", propagate_batch, y0, self.horizon, self.consts,
+                                      (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, False, False, 0.001, self.device, thrust=True)
         self._check(st)
-        u_bar = tangential_thrust(x, 0.5)                                  # extract_uk of the tangential controller
         tf_u = np.full(S, float(self.horizon))
         Ks = None                                                          # first iteration: K nodes for everybody
         self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
@@ -207,10 +207,9 @@ class ConstellationMPC:
                 break                 # (the reference re-rolls once more, control.py:227, and drops the result)
             # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
             Kn = (self.base_res * res.tf).astype(np.int32)
-            x, st, _ = self._timed("rollouts", propagate_batch, y0, tf_u, self.consts, (_ffi.CTRL_SEQUENCE, res.U, res.U.shape[2], 1.0),
-                                   Kn, False, False, 0.001, self.device, Kus=Ku)
+            x, st, _, u_bar = self._timed("rollouts", propagate_batch, y0, tf_u, self.consts, (_ffi.CTRL_SEQUENCE, res.U, res.U.shape[2], 1.0),
+                                          Kn, False, False, 0.001, self.device, Kus=Ku, thrust=True)     # (SequenceController(tf_sim = tf_u))
             self._check(st)
-            u_bar = foh_resample_ragged(res.U, Ku, Kn)                     # extract_uk of SequenceController(tf_sim = tf_u)
             Ks = Kn
         Kp = np.full(S, res.X.shape[2]) if Ks is None else Ks
         self.plan_K = Kp.astype(np.int32)

@@ -21,6 +21,7 @@ struct PropArgs {
     const double *ctrl_vec;   // CONSTANT: [S][3]; TANGENTIAL: [S] magnitudes; SEQUENCE: [S][3][Ku]
     const double *end_tau;    // SEQUENCE: [S]
     double *y_out;            // [S][7][n_eval]
+    double *u_out;            // [S][3][n_eval] or nullptr: the thrust law at the output points (Discretizer.extract_uk)
     int32_t *status, *nsteps;
 };
 
@@ -289,6 +290,24 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
                 const double orr = dense(fr, Kr, yr), ov = dense(fv, Kv, yv), om = dense(fm, Km, ym);
                 if (on) { yo[(size_t)comp * ld + ei] = orr; yo[(size_t)(3 + comp) * ld + ei] = ov; }
                 if (lane4 == 0) yo[(size_t)6 * ld + ei] = om;
+                if (a.u_out) {
+                    // extract_uk (linearize_discretize.py:393-411): u_func(x_k, t_k) at the output point -- the reference thrust
+                    // of the next linearisation, which the host would otherwise recompute from the trajectory it gets back
+                    double uo = 0.0;
+                    if (KIND == MPCX_CTRL_CONSTANT) uo = c.vc;
+                    else if (KIND == MPCX_CTRL_TANGENTIAL) {
+                        const double q2 = quad_sum(on ? orr * orr : 0.0), qv = quad_sum(on ? orr * ov : 0.0);
+                        const double wv = ov * q2 - orr * qv;
+                        uo = c.vc * (wv * rsq_fast(quad_sum(on ? wv * wv : 0.0)));
+                    } else if (KIND == MPCX_CTRL_SEQUENCE) {
+                        if (te <= c.end_tau) {                       // control.py:132-142, the hold as foh3 evaluates it (divisions)
+                            double o3[3];
+                            foh3(te / c.end_tau, a.ctrl_vec + (size_t)sat * 3 * a.Ku, c.Ku, a.Ku, o3, err);
+                            uo = comp == 0 ? o3[0] : (comp == 1 ? o3[1] : o3[2]);
+                        }
+                    }
+                    if (on) a.u_out[((size_t)sat * 3 + comp) * ld + ei] = uo;
+                }
                 ++ei;
             }
             t = t_new;
@@ -343,10 +362,11 @@ extern "C" int mpcx_resample_sequence_dev(mpcx_ctx *ctx, int S, int Ku, const in
     return MPCX_OK;
 }
 
-extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
-                                               const double *tf, const double *consts, int flags, int ctrl_kind,
-                                               const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
-                                               double max_step, double *y_out, int32_t *status, int32_t *nsteps, void *stream)
+extern "C" int mpcx_propagate_thrust_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                                      const double *tf, const double *consts, int flags, int ctrl_kind,
+                                                      const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                                      double max_step, double *y_out, double *u_out, int32_t *status,
+                                                      int32_t *nsteps, void *stream)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || n_eval < 1 || !(max_step > 0.0)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1, max_step>0");
@@ -354,7 +374,7 @@ extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval,
     if (ctrl_kind == MPCX_CTRL_SEQUENCE && (Ku < 2 || !end_tau || !ctrl_vec)) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: sequence needs Ku>=2, table and end_tau");
     if ((ctrl_kind == MPCX_CTRL_CONSTANT || ctrl_kind == MPCX_CTRL_TANGENTIAL) && !ctrl_vec) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: thrust parameters missing");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
-    PropArgs a{S, n_eval, flags, ctrl_kind, Ku, n_evals, Kus, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, status, nsteps};
+    PropArgs a{S, n_eval, flags, ctrl_kind, Ku, n_evals, Kus, max_step, y0, tf, consts, ctrl_vec, end_tau, y_out, u_out, status, nsteps};
     const dim3 grid((S + 15) / 16), block(64);            // 16 satellites (quads) per wave
     hipStream_t st = (hipStream_t)stream;
 #define MPCX_PROP_LAUNCH(KIND, FLAGS) hipLaunchKernelGGL((propagate_kernel<KIND, FLAGS>), grid, block, 0, st, a)
@@ -377,6 +397,15 @@ extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval,
     return MPCX_OK;
 }
 
+extern "C" int mpcx_propagate_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                               const double *tf, const double *consts, int flags, int ctrl_kind,
+                                               const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                               double max_step, double *y_out, int32_t *status, int32_t *nsteps, void *stream)
+{
+    return mpcx_propagate_thrust_batch_ragged_dev(ctx, S, n_eval, n_evals, y0, tf, consts, flags, ctrl_kind, ctrl_vec, Ku, Kus, end_tau,
+                                                  max_step, y_out, nullptr, status, nsteps, stream);
+}
+
 extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,
                                         const double *consts, int flags, int ctrl_kind, const double *ctrl_vec,
                                         int Ku, const double *end_tau, double max_step, double *y_out,
@@ -386,10 +415,10 @@ extern "C" int mpcx_propagate_batch_dev(mpcx_ctx *ctx, int S, int n_eval, const 
                                            max_step, y_out, status, nsteps, stream);
 }
 
-extern "C" int mpcx_propagate_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
-                                           const double *tf, const double *consts, int flags, int ctrl_kind,
-                                           const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
-                                           double max_step, double *y_out, int32_t *status, int32_t *nsteps)
+extern "C" int mpcx_propagate_thrust_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                                  const double *tf, const double *consts, int flags, int ctrl_kind,
+                                                  const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                                  double max_step, double *y_out, double *u_out, int32_t *status, int32_t *nsteps)
 {
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || n_eval < 1) return ctx_fail(ctx, MPCX_E_BADARG, "propagate: need S>=1, n_eval>=1");
@@ -404,14 +433,29 @@ extern "C" int mpcx_propagate_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, con
     double *de = (ctrl_kind == MPCX_CTRL_SEQUENCE && end_tau) ? ar.upload(end_tau, S) : nullptr;
     int32_t *dne = n_evals ? ar.upload(n_evals, S) : nullptr, *dku = Kus ? ar.upload(Kus, S) : nullptr;
     double *dy = ar.alloc<double>((size_t)S * 7 * n_eval);
+    double *du = u_out ? ar.alloc<double>((size_t)S * 3 * n_eval) : nullptr;
     int32_t *dst = ar.alloc<int32_t>(S), *dns = ar.alloc<int32_t>(S);
     if (ar.failed()) return ar.code();
-    if (n_evals) MPCX_HIP(ctx, hipMemsetAsync(dy, 0, (size_t)S * 7 * n_eval * sizeof(double), ctx->stream));   // the unused columns
-    int rc = mpcx_propagate_batch_ragged_dev(ctx, S, n_eval, dne, dy0, dtf, dc, flags, ctrl_kind, dv, Ku, dku, de, max_step, dy,
-                                             dst, dns, ctx->stream);
+    if (n_evals) {                                                                                             // the unused columns
+        MPCX_HIP(ctx, hipMemsetAsync(dy, 0, (size_t)S * 7 * n_eval * sizeof(double), ctx->stream));
+        if (du) MPCX_HIP(ctx, hipMemsetAsync(du, 0, (size_t)S * 3 * n_eval * sizeof(double), ctx->stream));
+    }
+    int rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, n_eval, dne, dy0, dtf, dc, flags, ctrl_kind, dv, Ku, dku, de, max_step, dy,
+                                                    du, dst, dns, ctx->stream);
     if (rc) return rc;
-    ar.download(y_out, dy, (size_t)S * 7 * n_eval); ar.download(status, dst, S); ar.download(nsteps, dns, S);
+    ar.download(y_out, dy, (size_t)S * 7 * n_eval);
+    if (du) ar.download(u_out, du, (size_t)S * 3 * n_eval);
+    ar.download(status, dst, S); ar.download(nsteps, dns, S);
     return ar.finish();
+}
+
+extern "C" int mpcx_propagate_batch_ragged(mpcx_ctx *ctx, int S, int n_eval, const int32_t *n_evals, const double *y0,
+                                           const double *tf, const double *consts, int flags, int ctrl_kind,
+                                           const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                           double max_step, double *y_out, int32_t *status, int32_t *nsteps)
+{
+    return mpcx_propagate_thrust_batch_ragged(ctx, S, n_eval, n_evals, y0, tf, consts, flags, ctrl_kind, ctrl_vec, Ku, Kus, end_tau,
+                                              max_step, y_out, nullptr, status, nsteps);
 }
 
 extern "C" int mpcx_propagate_batch(mpcx_ctx *ctx, int S, int n_eval, const double *y0, const double *tf,

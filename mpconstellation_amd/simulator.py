@@ -20,9 +20,11 @@ class OdeResult:
 
 
 def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0, slot=0,
-                    Kus=None):
+                    Kus=None, thrust=False):
     """y0 (S,7) normalised, tf (S,), consts (S,8); law = (kind, vec, Ku, end_tau) with per-satellite or
-    broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,).
+    broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,) -- and, with thrust=True, u (S,3,n_eval) as a
+    fourth value: the law evaluated at the output points, Discretizer.extract_uk of the rollout's own controller
+    (linearize_discretize.py:393-411), from the same launch.
     Ragged batches: n_eval may be an (S,) integer array -- satellite s is sampled at linspace(0, 1, n_eval[s]), y has
     max(n_eval) columns, zero past a satellite's count -- and Kus (S,) gives the columns in use of each satellite's
     thrust table (law SEQUENCE, table rows of length Ku)."""
@@ -48,6 +50,14 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
     y = np.empty((S, 7, n_eval)); status = np.zeros(S, dtype=np.int32); nsteps = np.zeros(S, dtype=np.int32)
     flags = (_ffi.FLAG_DRAG if include_drag else 0) | (_ffi.FLAG_J2 if include_J2 else 0)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
+    if thrust:
+        u = np.empty((S, 3, n_eval))
+        rc = lib.mpcx_propagate_thrust_batch_ragged(ctx, S, int(n_eval), None if n_evals is None else _ffi.iptr(n_evals), _ffi.dptr(y0),
+                                                    _ffi.dptr(tf), _ffi.dptr(consts), flags, kind, vec_p, int(Ku),
+                                                    None if Kus is None else _ffi.iptr(Kus), et_p, float(max_step), _ffi.dptr(y),
+                                                    _ffi.dptr(u), _ffi.iptr(status), _ffi.iptr(nsteps))
+        _ffi.check(rc, ctx, "mpcx_propagate_thrust_batch_ragged")
+        return y, status, nsteps, u
     if n_evals is None and Kus is None:
         rc = lib.mpcx_propagate_batch(ctx, S, int(n_eval), _ffi.dptr(y0), _ffi.dptr(tf), _ffi.dptr(consts), flags, kind,
                                       vec_p, int(Ku), et_p, float(max_step), _ffi.dptr(y), _ffi.iptr(status),
