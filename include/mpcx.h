@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 301
+#define MPCX_VERSION 302
 
 /* return codes */
 #define MPCX_OK 0
@@ -301,6 +301,19 @@ int mpcx_propagate_thrust_batch_ragged_dev(mpcx_ctx *ctx, int S, int n_eval, con
                                            const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
                                            double max_step, double *y_out, double *u_out, int32_t *status, int32_t *nsteps,
                                            void *stream);
+/*
+ * One SCP iteration of OptimalController.update (control.py:183-227) for S satellites in one call: the nonlinear rollout from
+ * y0 [S][7] over tf [S] under the given thrust law (arguments as mpcx_propagate_batch_ragged), sampled at K nodes (Ks[s] of
+ * them in a ragged batch) -- x_bar; the law at those nodes -- u_bar (extract_uk); the discretisation about (x_bar, u_bar,
+ * tf) and the solve (arguments and results as mpcx_mpc_step_batch_ragged).  x_bar and u_bar stay on the device; they are
+ * returned only when xbar_out [S][7][K] / ubar_out [S][3][K] are not NULL.  prop_status [S]: the rollout's MPCX_ST_* codes.
+ */
+int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *y0, const double *tf,
+                                    const double *consts, const double *r_des, int prop_flags, int ctrl_kind,
+                                    const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                    double prop_max_step, int disc_flags, double disc_max_step, const mpcx_solve_opts *opts,
+                                    double *xbar_out, double *ubar_out, double *X, double *U, double *NU, double *tf_out,
+                                    int32_t *status, int32_t *iters, double *kkt, int32_t *prop_status);
 /*
  * Replaces Discretizer.extract_uk (linearize_discretize.py:393-411) for a SequenceController played over its own horizon
  * (control.py:217-221, tf_sim = tf_u: end_tau = 1): the first-order hold (control.py:104-126) of table u [S][3][Ku]

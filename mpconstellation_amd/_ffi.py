@@ -91,6 +91,8 @@ _SIGS = {
                                                      _dp, C.c_double, _dp, _dp, _ip, _ip]),
     "mpcx_propagate_thrust_batch_ragged_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
                                                          _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "mpcx_scp_iteration_batch_ragged": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp,
+                                                  C.c_double, C.c_int, C.c_double, _po, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]),
     "mpcx_resample_sequence_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
 }
 

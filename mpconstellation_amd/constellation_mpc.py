@@ -19,9 +19,8 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _ffi
-from .constellation import tangential_thrust
 from .control import _check_solver_status
-from .optimizer import mpc_step_batch
+from .optimizer import mpc_step_batch, scp_iteration_batch
 from .satellite_scale import SatelliteScale
 from .simulator import propagate_batch
 
@@ -122,7 +121,7 @@ class ConstellationMPC:
         self._plan = None                                               # (X, U, NU) of the last plan, rows of length Kmax
         self._plan_lists = None
         # wall-clock seconds spent inside the batched device calls (host staging included), accumulated over the updates
-        self.timing = {"rollouts": 0.0, "discretize_solve": 0.0, "truth_propagation": 0.0}
+        self.timing = {"scp_iteration": 0.0, "truth_propagation": 0.0}     # seconds inside the library calls (rollout + discretize + solve; truth flight)
 
     def _timed(self, key, fn, *a, **kw):
         t0 = time.perf_counter()
@@ -181,36 +180,33 @@ class ConstellationMPC:
         S = len(self.sats)
         y0 = self._y0() if y0 is None else y0
         K = int(self.base_res * self.horizon)
-        # (thrust=True: extract_uk of the rollout's controller, control.py:187 / :222, comes back from the same launch)
-        x, st, _, u_bar = self._timed("rollouts", propagate_batch, y0, self.horizon, self.consts,
-                                      (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None), K, False, False, 0.001, self.device, thrust=True)
-        self._check(st)
+        # Every SCP iteration is ONE library call (scp_iteration_batch): the nonlinear rollout under the iteration's thrust law
+        # -- the tangential reference controller first (control.py:183-187), then the sequence just optimised, played over its
+        # own horizon and sampled at int(base_res * tf_u) nodes per satellite (control.py:217-227, simulator.py:38: a ragged
+        # batch) --, extract_uk at its nodes, discretisation and solve.  x_bar and u_bar never come to the host.
         tf_u = np.full(S, float(self.horizon))
-        Ks = None                                                          # first iteration: K nodes for everybody
+        law = (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None)
+        Ks = None; Kus = None                                              # first iteration: K nodes for everybody
         self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
         opts = {"eps_r": 0.000001, "eps_vr": 0.0000000000000001, "tf_max": self.horizon}     # control.py:192-197
         res = None
         for it in range(self.scp_iterations):
-            # one launch for the whole constellation; from the second iteration on it is ragged: the re-rollout of
-            # satellite s was sampled at int(base_res * tf_u[s]) nodes (control.py:227, simulator.py:38)
-            res = self._timed("discretize_solve", mpc_step_batch, x, u_bar, tf_u, self.consts, self.r_des, options=opts,
-                              device=self.device, Ks=Ks)
+            Krow = K if Ks is None else int(Ks.max())
+            res = self._timed("scp_iteration", scp_iteration_batch, y0, tf_u, self.consts, self.r_des, law, Krow, options=opts,
+                              Ks=Ks, Kus=Kus, device=self.device)
+            self._check(res.prop_status)
             self.last_status[it] = res.status
             _check_solver_status(res.status, self.strict)
             if self.verbose:
                 for j in range(S):
                     print(f"tf for optimizer: {res.tf[j]}")
                     print(f"Total virtual control effort: {np.abs(res.NU[j]).sum()}")
-            Ku = np.full(S, x.shape[2]) if Ks is None else Ks
             tf_u = res.tf.copy()
             if it == self.scp_iterations - 1:
                 break                 # (the reference re-rolls once more, control.py:227, and drops the result)
-            # nonlinear re-rollout under the optimised sequence over tf_u, sampled at int(base_res * tf_u) nodes
-            Kn = (self.base_res * res.tf).astype(np.int32)
-            x, st, _, u_bar = self._timed("rollouts", propagate_batch, y0, tf_u, self.consts, (_ffi.CTRL_SEQUENCE, res.U, res.U.shape[2], 1.0),
-                                          Kn, False, False, 0.001, self.device, Kus=Ku, thrust=True)     # (SequenceController(tf_sim = tf_u))
-            self._check(st)
-            Ks = Kn
+            Kus = np.full(S, Krow) if Ks is None else Ks                   # columns in use of the table the next rollout plays
+            Ks = (self.base_res * res.tf).astype(np.int32)                 # ... sampled at int(base_res * tf_u) nodes
+            law = (_ffi.CTRL_SEQUENCE, res.U, res.U.shape[2], 1.0)         # SequenceController(u_opt, tf_u, tf_sim = tf_u)
         Kp = np.full(S, res.X.shape[2]) if Ks is None else Ks
         self.plan_K = Kp.astype(np.int32)
         self._plan = (res.X, res.U, res.NU)                                # rows of length Kmax; U is the table the segment is flown with

@@ -3675,6 +3675,55 @@ extern "C" int mpcx_mpc_step_batch(mpcx_ctx *ctx, int S, int K, const double *xb
                                       status, iters, kkt);
 }
 
+// One SCP iteration of OptimalController.update (control.py:183-227) for S satellites, host buffers in and out: the nonlinear
+// rollout under the given thrust law sampled at the satellite's nodes (its thrust at those nodes = extract_uk), the
+// linearisation / discretisation about it and the solve -- x_bar and u_bar never leave the device.
+extern "C" int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *y0, const double *tf,
+                                               const double *consts, const double *r_des, int prop_flags, int ctrl_kind,
+                                               const double *ctrl_vec, int Ku, const int32_t *Kus, const double *end_tau,
+                                               double prop_max_step, int disc_flags, double disc_max_step,
+                                               const mpcx_solve_opts *opts, double *xbar_out, double *ubar_out, double *X, double *U,
+                                               double *NU, double *tf_out, int32_t *status, int32_t *iters, double *kkt,
+                                               int32_t *prop_status)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 3 || !opts || !prop_status) return ctx_fail(ctx, MPCX_E_BADARG, "scp_iteration: need S>=1, K>=3, options and prop_status");
+    if (opts->flags & (MPCX_SOLVE_FIXED_TF | MPCX_SOLVE_SHARED_TF)) return ctx_fail(ctx, MPCX_E_BADARG, "scp_iteration: free per-satellite tf only");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes(S, K));
+    if (!ws) return MPCX_E_NOMEM;
+    DeviceArena ar(ctx);
+    double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    size_t nv = 0;
+    if (ctrl_kind == MPCX_CTRL_CONSTANT) nv = (size_t)S * 3;
+    else if (ctrl_kind == MPCX_CTRL_TANGENTIAL) nv = S;
+    else if (ctrl_kind == MPCX_CTRL_SEQUENCE) nv = (size_t)S * 3 * Ku;
+    double *dv = (nv && ctrl_vec) ? ar.upload(ctrl_vec, nv) : nullptr;
+    double *de = (ctrl_kind == MPCX_CTRL_SEQUENCE && end_tau) ? ar.upload(end_tau, S) : nullptr;
+    int32_t *dKs = Ks ? ar.upload(Ks, S) : nullptr, *dKus = Kus ? ar.upload(Kus, S) : nullptr;
+    double *dx = ar.alloc<double>((size_t)S * 7 * K), *du = ar.alloc<double>((size_t)S * 3 * K);
+    double *dX = ar.alloc<double>((size_t)S * 7 * K), *dU = ar.alloc<double>((size_t)S * 3 * K), *dNU = ar.alloc<double>((size_t)S * 7 * K);
+    double *dtfo = ar.alloc<double>(S), *dk = ar.alloc<double>(S);
+    int32_t *dst = ar.alloc<int32_t>(S), *dit = ar.alloc<int32_t>(S), *dps = ar.alloc<int32_t>(S), *dpn = ar.alloc<int32_t>(S);
+    if (ar.failed()) return ar.code();
+    if (Ks) {                                                                                        // the unused columns
+        MPCX_HIP(ctx, hipMemsetAsync(dx, 0, (size_t)S * 7 * K * sizeof(double), ctx->stream));
+        MPCX_HIP(ctx, hipMemsetAsync(du, 0, (size_t)S * 3 * K * sizeof(double), ctx->stream));
+    }
+    int rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, K, dKs, dy0, dtf, dc, prop_flags, ctrl_kind, dv, Ku, dKus, de, prop_max_step,
+                                                    dx, du, dps, dpn, ctx->stream);
+    if (rc) return rc;
+    rc = mpcx_mpc_step_batch_ragged_dev(ctx, S, K, dKs, dx, du, dtf, dc, drd, disc_flags, disc_max_step, opts, dX, dU, dNU, dtfo, dst,
+                                        dit, dk, ws, ctx->stream);
+    if (rc) return rc;
+    if (xbar_out) ar.download(xbar_out, dx, (size_t)S * 7 * K);
+    if (ubar_out) ar.download(ubar_out, du, (size_t)S * 3 * K);
+    ar.download(X, dX, (size_t)S * 7 * K); ar.download(U, dU, (size_t)S * 3 * K); ar.download(NU, dNU, (size_t)S * 7 * K);
+    ar.download(tf_out, dtfo, S); ar.download(status, dst, S); ar.download(iters, dit, S); ar.download(kkt, dk, S);
+    ar.download(prop_status, dps, S);
+    return ar.finish();
+}
+
 extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,
                                 const double *Sigma, const double *xi, const double *xbar, const double *ubar,
                                 const double *tf, const double *consts, const double *r_des,

@@ -127,6 +127,51 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
         SolveResult(X, U, NU, held, status, iters, kkt, tfo, reg)
 
 
+def scp_iteration_batch(y0, tf, consts, r_des, law, K, options=None, Ks=None, Kus=None, include_J2=False, max_step=1e-2,
+                        prop_max_step=1e-3, device=0, slot=0, linear_vt=False, return_reference=False, **solver):
+    """One SCP iteration of OptimalController.update (control.py:183-227) for S satellites in ONE library call
+    (mpcx_scp_iteration_batch_ragged): the nonlinear rollout from y0 (S,7) over tf (S,) under `law` = (kind, vec, Ku, end_tau)
+    (simulator.propagate_batch's law tuple) sampled at K nodes -- Ks[s] of them in a ragged batch --, its controller's thrust
+    at those nodes (extract_uk), the discretisation about them and the solve.  The reference trajectory stays on the device
+    unless return_reference=True (then the result carries .xbar (S,7,K) and .ubar (S,3,K)).  Returns a SolveResult with the
+    extra attribute prop_status (S,)."""
+    solver = _solver_flags(solver, linear_vt, None, False)
+    y0 = _ffi.as_f64(y0); S = y0.shape[0]; K = int(K)
+    tf = _ffi.as_f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (S,)))
+    r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
+    consts = _ffi.as_f64(consts)
+    kind, vec, Ku, end_tau = law
+    vec_p = None; et_p = None
+    if kind == _ffi.CTRL_CONSTANT:
+        vec = _ffi.as_f64(np.broadcast_to(np.asarray(vec, dtype=np.float64).reshape(-1, 3), (S, 3))); vec_p = _ffi.dptr(vec)
+    elif kind == _ffi.CTRL_TANGENTIAL:
+        vec = _ffi.as_f64(np.broadcast_to(np.asarray(vec, dtype=np.float64).reshape(-1), (S,))); vec_p = _ffi.dptr(vec)
+    elif kind == _ffi.CTRL_SEQUENCE:
+        vec = np.asarray(vec, dtype=np.float64)
+        vec = _ffi.as_f64(np.broadcast_to(vec if vec.ndim == 3 else vec[None], (S, 3, Ku))); vec_p = _ffi.dptr(vec)
+        end_tau = _ffi.as_f64(np.broadcast_to(np.asarray(end_tau, dtype=np.float64), (S,))); et_p = _ffi.dptr(end_tau)
+    if Ks is not None: Ks = np.ascontiguousarray(np.broadcast_to(np.asarray(Ks), (S,)), dtype=np.int32)
+    if Kus is not None: Kus = np.ascontiguousarray(np.broadcast_to(np.asarray(Kus), (S,)), dtype=np.int32)
+    opts = _ffi.make_solve_opts(options, **solver)
+    X, U, NU, kkt, status, iters = _result_arrays(S, K, device, False)
+    tfo = np.empty(S); pst = np.zeros(S, dtype=np.int32)
+    xb = np.empty((S, 7, K)) if return_reference else None
+    ub = np.empty((S, 3, K)) if return_reference else None
+    lib = _ffi.load(); ctx = _ffi.context(device, slot)
+    import ctypes as C
+    rc = lib.mpcx_scp_iteration_batch_ragged(ctx, S, K, None if Ks is None else _ffi.iptr(Ks), _ffi.dptr(y0), _ffi.dptr(tf),
+                                             _ffi.dptr(consts), _ffi.dptr(r_des), 0, kind, vec_p, int(Ku),
+                                             None if Kus is None else _ffi.iptr(Kus), et_p, float(prop_max_step),
+                                             _ffi.FLAG_J2 if include_J2 else 0, float(max_step), C.byref(opts),
+                                             None if xb is None else _ffi.dptr(xb), None if ub is None else _ffi.dptr(ub),
+                                             _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
+                                             _ffi.iptr(iters), _ffi.dptr(kkt), _ffi.iptr(pst))
+    _ffi.check(rc, ctx, "mpcx_scp_iteration_batch_ragged")
+    res = SolveResult(X, U, NU, tfo, status, iters, kkt)
+    res.prop_status = pst; res.xbar = xb; res.ubar = ub
+    return res
+
+
 def solve_batch(A, Bp, Bn, Sigma, xi, xbar, ubar, tf, consts, r_des, options=None, device=0, linear_vt=False, fixed_tf=None,
                 regularised=False, shared_tf=False, **solver):
     """Solve only (dynamics already discretised, reference-shaped arrays with a leading satellite axis)."""

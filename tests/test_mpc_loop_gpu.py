@@ -218,3 +218,29 @@ def test_constellation_mpc_plan_vs_oracle_chain():
         assert mpc.plan_x[i].shape == r["X"].shape
         assert np.abs(mpc.plan_x[i] - r["X"]).max() < 5e-6 and np.abs(mpc.plan_u[i] - r["U"]).max() < 5e-5
         assert abs(mpc.plan_tf[i] - r["tf"]) < 5e-6
+
+
+def test_fused_scp_iteration_equals_its_three_calls():
+    """mpcx_scp_iteration_batch_ragged (rollout + extract_uk + discretize + solve in one call, x_bar / u_bar staying on the
+    device) against the same chain through the separate entry points: bit for bit, rectangular and ragged, tangential
+    reference law and sequence playback."""
+    from mpconstellation_amd import _ffi, mpc_step_batch, scp_iteration_batch
+    from mpconstellation_amd.simulator import propagate_batch
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch
+    S, K = 24, 30
+    y0, consts = normalize_batch(constellation_states(4096, first=500, count=S))
+    tf = np.linspace(0.8, 1.2, S)
+    law = (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None)
+    x, st, _, u = propagate_batch(y0, tf, consts, law, K, thrust=True)
+    r_des = np.linalg.norm(x[:, :3, -1], axis=1)
+    ref = mpc_step_batch(x, u, tf, consts, r_des)
+    one = scp_iteration_batch(y0, tf, consts, r_des, law, K, return_reference=True)
+    assert (one.prop_status == 0).all() and np.array_equal(one.xbar, x) and np.array_equal(one.ubar, u)
+    for f in ("X", "U", "NU", "tf", "status", "iters", "kkt"): assert np.array_equal(getattr(one, f), getattr(ref, f)), f
+    # second SCP iteration: the optimised sequence played over its own horizon, int(30 tf) nodes per satellite
+    Kn = (30 * ref.tf).astype(np.int32); law2 = (_ffi.CTRL_SEQUENCE, ref.U, K, 1.0)
+    x2, st2, _, u2 = propagate_batch(y0, ref.tf, consts, law2, Kn, Kus=np.full(S, K), thrust=True)
+    ref2 = mpc_step_batch(x2, u2, ref.tf, consts, r_des, Ks=Kn)
+    two = scp_iteration_batch(y0, ref.tf, consts, r_des, law2, int(Kn.max()), Ks=Kn, Kus=np.full(S, K))
+    assert two.xbar is None and (two.prop_status == 0).all() and (two.status == 0).all()
+    for f in ("X", "U", "NU", "tf", "status", "iters", "kkt"): assert np.array_equal(getattr(two, f), getattr(ref2, f)), f
