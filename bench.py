@@ -90,6 +90,8 @@ class Runner:
         self.d_st = torch.empty(S, **i32); self.d_it = torch.empty(S, **i32); self.d_dst = torch.empty(S, **i32)
         self.d_pst = torch.empty(S, **i32); self.d_pns = torch.empty(S, **i32); self.d_rst = torch.empty(S, **i32)
         self.base_res = K          # tf_bar = 1: K = int(base_res * tf) nodes (simulator.py:38)
+        self.d_Kn = [torch.empty(S, **i32) for _ in range(2)]        # node counts of the SCP iterations (alternating: the buffer
+        self.d_Knf = torch.empty(S, **t64)                           # an iteration reads stays untouched while the next is written)
         self.d_stage = torch.empty((S, K - 1, _ffi.STAGE_DOUBLES), **t64)
         self.d_ws = torch.empty(self.lib.mpcx_solve_workspace_bytes(S, K) // 8 + 8, **t64)
         self.opts = _ffi.make_solve_opts({})
@@ -125,14 +127,15 @@ class Runner:
                 # tf_u, sampled -- as the reference does, simulator.py:38 -- at int(base_res * tf_u) nodes, a different
                 # count for every satellite: the next iteration is a ragged launch (rows of length K, Kn[s] columns in
                 # use).  The new reference thrust is extract_uk of that sequence at the rollout's nodes.
-                self.d_Kn = (self.d_tfo * float(self.base_res)).to(torch.int32)          # int(base_res * tf_u)
-                ffi.check(lib.mpcx_propagate_batch_ragged_dev(ctx, S, K, p(self.d_Kn), p(self.d_y0), p(self.d_tfo), p(self.d_c), 0,
+                kn = self.d_Kn[it % 2]
+                torch.mul(self.d_tfo, float(self.base_res), out=self.d_Knf); kn.copy_(self.d_Knf)      # int(base_res * tf_u): copy_ truncates
+                ffi.check(lib.mpcx_propagate_batch_ragged_dev(ctx, S, K, p(kn), p(self.d_y0), p(self.d_tfo), p(self.d_c), 0,
                                                               ffi.CTRL_SEQUENCE, p(self.d_U), K, ks, p(self.d_one), 1e-3, p(self.d_x),
                                                               p(self.d_pst), p(self.d_pns), st), ctx, "propagate")
-                ffi.check(lib.mpcx_resample_sequence_dev(ctx, S, K, ks, p(self.d_U), K, p(self.d_Kn), p(self.d_u), p(self.d_rst), st),
+                ffi.check(lib.mpcx_resample_sequence_dev(ctx, S, K, ks, p(self.d_U), K, p(kn), p(self.d_u), p(self.d_rst), st),
                           ctx, "resample")
                 self.d_tf.copy_(self.d_tfo)
-                ks = p(self.d_Kn)
+                ks = p(kn)
 
     def solver_stats(self):
         status = self.d_st.cpu().numpy(); dstat = self.d_dst.cpu().numpy()
@@ -202,23 +205,39 @@ def roofline(workload, S, K, solve_ms, iters):
                          "frac": flops / (solve_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}}
 
 
-def host_pointer_rate(h, S, local_rank, reps=5):
+def host_pointer_rate(h, S, local_rank, reps=20):
     """the same step through the host-pointer entry point (numpy in / numpy out): H2D of the inputs and D2H of the results
     through the context's pinned staging inside the timed region -- the PCIe-inclusive figure of SURVEY 8(d), reported
     beside `value`, never as `value`"""
     from mpconstellation_amd import mpc_step_batch, _ffi
 
+    import gc
+    pauses = []
+    t_gc = [0.0]
+
+    def on_gc(phase, info):
+        if phase == "start": t_gc[0] = time.perf_counter()
+        else: pauses.append((time.perf_counter() - t_gc[0]) * 1e3)
+
     def timed(f):
-        # two untimed calls: the first grows the context's staging pools and workspace, the second still runs 4-5x slow on
-        # this pool (first reuse of the fresh page-locked chunks; measured, see calls_ms of earlier rounds) -- like the
-        # warm-up steps of the main measurement they are not part of the steady state
+        # two untimed calls (the first grows the context's staging pools and workspace), then `reps` timed ones; every call
+        # is listed, with median and max beside the mean so that a stall can neither hide nor pass for the steady state.
+        # Python's cyclic garbage collector is watched during the timed calls: with torch imported a full (generation 2)
+        # collection of this process takes tens of milliseconds and lands inside whichever call triggers it
+        # (profiles/r04/host_stall.txt).
         warm = []
         for _ in range(2):
             t0 = time.perf_counter(); f(); warm.append((time.perf_counter() - t0) * 1e3)
         ms = []
-        for _ in range(reps):
-            t0 = time.perf_counter(); f(); ms.append((time.perf_counter() - t0) * 1e3)
-        return float(np.mean(ms)) * 1e-3, {"timed": [round(v, 3) for v in ms], "warmup": [round(v, 3) for v in warm]}
+        pauses.clear(); gc.callbacks.append(on_gc)
+        try:
+            for _ in range(reps):
+                t0 = time.perf_counter(); f(); ms.append((time.perf_counter() - t0) * 1e3)
+        finally:
+            gc.callbacks.remove(on_gc)
+        return float(np.mean(ms)) * 1e-3, {"timed": [round(v, 3) for v in ms], "warmup": [round(v, 3) for v in warm],
+                                           "median": round(float(np.median(ms)), 3), "max": round(float(np.max(ms)), 3),
+                                           "python_gc_pauses_ms": [round(v, 2) for v in pauses if v >= 0.5]}
     dt, calls = timed(lambda: mpc_step_batch(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], device=local_rank))
     # the same with the caller's arrays in page-locked memory (mpcx_host_alloc): DMA straight from / to them
     hp = {k: _ffi.pinned_copy(h[k], local_rank) for k in ("xbar", "ubar", "tfbar", "consts", "r_des")}
@@ -329,7 +348,8 @@ def main():
         S_total = S * world
         value = S_total * args.steps / elapsed
         out = {
-            "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve per SCP iteration)",
+            "metric": "satellite-MPC-steps/sec (whole constellation; 1 step = discretize + constraint terms + solve per SCP iteration; inputs "
+                      "and results resident in HBM -- value_pcie is the same step with H2D of the inputs and D2H of the results inside)",
             "value": value, "unit": "satellite-MPC-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 302
+#define MPCX_VERSION 400
 
 /* return codes */
 #define MPCX_OK 0
@@ -125,7 +125,9 @@ typedef struct {
  * few satellites per wave slot the launch ends when the slowest slot does).  Results never depend on the launch
  * order.  The counts are the library's own copy, written and read on the stream of the calls: consecutive solves on
  * one context must be enqueued on the same stream (or be ordered by the caller).  This flag keeps the plain index
- * order. */
+ * order.  With it, solves of one context may be in flight on different streams at once: every launch has its own work
+ * queue (up to 64 launches of a context in flight) and works in the caller's workspace; the regularisation record
+ * (mpcx_solve_regularised) is then that of whichever solve wrote last. */
 #define MPCX_SOLVE_INDEX_ORDER 1
 /* Tangential velocity as the linearised pair max_tan_vel_rule / min_tan_vel_rule (optimizer.py:471-489,
  * |Vt_lin(x_K) - Vc_lin(r_K)| <= eps_vt), which the reference keeps commented out at :575-576, instead of the quartic
@@ -151,14 +153,20 @@ typedef struct {
 #define MPCX_SOLVE_SHARED_TF 8
 
 /* Batches of at most 1024 satellites (no more than one per SIMD of an MI355X) are solved by a kernel with TWO waves per
- * satellite that share the factorisation of every interior-point iteration; its results agree with the one-wave kernel
- * larger batches use to rounding (1e-13 .. 1e-11 on the solutions, same iteration counts), not bit for bit.  This flag
- * keeps the one-wave kernel for small batches too: a satellite's result is then bit for bit what any larger batch gives it. */
+ * satellite that share the factorisation of every interior-point iteration.  Its results are bit for bit those of the
+ * one-wave kernel larger batches use (both are compiled with -ffp-contract=on: the same expressions round alike): a
+ * satellite's result does not depend on the size of the batch it is solved in.  This flag keeps the one-wave kernel for
+ * small batches too (measurements, tests). */
 #define MPCX_SOLVE_ONE_WAVE 16
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
+/* Workspace of the _dev solves / fused steps.  The plain queries are device-independent upper bounds (one slot per
+ * satellite); the _ctx queries return what a launch on the context's device touches -- one slot per persistent workgroup,
+ * min(S, workgroups resident at once: 2048 on MI355X), 0.44 GB instead of 1.8 GB at S = 8192, K = 30 -- and are enough. */
 size_t mpcx_solve_workspace_bytes(int S, int K);
 size_t mpcx_mpc_step_workspace_bytes(int S, int K);
+size_t mpcx_solve_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K);
+size_t mpcx_mpc_step_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K);
 
 /*
  * Replaces Optimizer.get_constraint_terms (optimizer.py:80-170) + the NLP transcription and

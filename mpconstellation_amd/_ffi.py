@@ -7,7 +7,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmpcx.so")
+LIB_PATH = os.environ.get("MPCX_LIB") or os.path.join(HERE, "libmpcx.so")      # (MPCX_LIB: another build of the same library, for A/B measurements)
 
 STATUS_TEXT = {
     0: "ok", 1: "satellite mass <= 0", 2: "RK45 step size underflow",
@@ -65,6 +65,8 @@ _SIGS = {
     "mpcx_default_solve_opts": (None, [_po]),
     "mpcx_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mpcx_mpc_step_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mpcx_solve_workspace_bytes_ctx": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "mpcx_mpc_step_workspace_bytes_ctx": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "mpcx_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int] + [_dp] * 10 + [_po, _dp, _dp, _dp, _dp, _ip, _ip, _dp]),
     "mpcx_solve_regularised": (C.c_int, [_vp, C.c_int, _ip]),
     "mpcx_solve_regularised_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),

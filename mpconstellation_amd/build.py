@@ -8,7 +8,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmpcx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -O2: measured 1.7 % faster than -O3 on solve_kernel (A/B on one box, profiles/tools/ab_timing.py); -Os is 20 % slower
-FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread"]
+# -ffp-contract=on: a*b+c is fused where the SOURCE writes it in one expression, never across statements.  hipcc's default
+# (fast) lets the optimiser fuse across statements, and it did so differently in the two compilations of solve.hip
+# (solve_kernel / solve_kernel2w: same expressions, results 1e-13 apart); with `on` the two kernels are bit-identical
+# (profiles/r04/two_wave_check.txt) at the same speed (A/B on one box: 1.362 vs 1.382 ms at S64, 5.675 vs 5.678 at S4096).
+FLAGS = ["--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread"]
 
 
 def sources():

@@ -37,7 +37,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->prev_iters = nullptr; c->order = nullptr; c->pred_hist = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
     c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
     c->copier = nullptr;
-    c->counter = nullptr; c->n_slots = prop.multiProcessorCount * 8;
+    c->counter = nullptr; c->launch_seq = 0; c->n_slots = prop.multiProcessorCount * 8;
     c->red = nullptr; c->red_cap = 0; c->coop_max = 0;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;

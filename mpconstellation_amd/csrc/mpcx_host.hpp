@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -127,7 +129,8 @@ struct mpcx_ctx {
     // regularisation counts of the last solve ([S][2] int32, include/mpcx.h: mpcx_solve_regularised)
     int32_t *nreg;
     int nreg_cap, nreg_S;
-    int32_t *counter;         // work-queue counter of the solver's persistent workgroups
+    int32_t *counter;         // ring of work-queue counters of the solver's persistent workgroups (one per launch in flight)
+    unsigned launch_seq;      // solves launched so far: selects the counter
     int n_slots;              // single-wave workgroups of solve_kernel the device holds at once (compute units x 8)
     double *red;              // shared-tf launches: reduction slots + arrival counter + abort flag
     int red_cap, coop_max;    // coop_max: workgroups of solve_shared_kernel resident at once (0: not asked yet, -1: unsupported)
@@ -173,13 +176,56 @@ inline void *ctx_workspace(mpcx_ctx *ctx, size_t bytes)
     return p;
 }
 
+// Diagnostic of the host-pointer path (MPCX_HOST_TRACE=<ms> in the environment): a call that takes longer than <ms>
+// milliseconds reports on stderr where its time went -- host copies into the staging pool, enqueueing, waiting for each
+// transfer's event, copy-out, the final stream synchronisation.  Off (one getenv per process) it costs a branch per mark.
+inline double host_trace_threshold_ms()
+{
+    static const double t = [] { const char *e = getenv("MPCX_HOST_TRACE"); return e ? atof(e) : -1.0; }();
+    return t;
+}
+struct HostTrace {
+    enum { CAP = 96 };
+    const char *name[CAP];
+    double t[CAP];
+    int n;
+    bool on;
+    HostTrace() : n(0), on(host_trace_threshold_ms() >= 0.0) { mark("enter"); }
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(const char *what) { if (on && n < CAP) { name[n] = what; t[n] = now(); ++n; } }
+    void report(const char *call)
+    {
+        if (!on || n < 2 || t[n - 1] - t[0] < host_trace_threshold_ms()) return;
+        fprintf(stderr, "[mpcx host trace] %s: %.3f ms:", call, t[n - 1] - t[0]);
+        for (int i = 1; i < n; ++i) fprintf(stderr, " %s %.3f", name[i], t[i] - t[i - 1]);
+        fprintf(stderr, "\n");
+    }
+};
+
 // Bump allocator over the two pools for the duration of one host-pointer call.
 class DeviceArena {
   public:
-    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0), dirty_(false) { pool_reset(c->pool_dev); pool_reset(c->pool_host); }
+    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0), dirty_(false)
+    {
+        pool_reset(c->pool_dev); pool_reset(c->pool_host);
+        for (auto &e : dev_ev_) e = nullptr;
+        if (trace.on) for (auto &e : dev_ev_) if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        dev_mark(0);
+    }
+    HostTrace trace;
+    // tracing only: device-side time stamps on the context's stream -- 0 call start, 1 uploads queued (kernels follow),
+    // 2 first download queued (kernels done), 3 last download queued -- so that a slow call can be split into transfer in,
+    // kernels and transfer out AS THE DEVICE SAW THEM, beside the host's view of the same call
+    hipEvent_t dev_ev_[4];
+    int dev_stage_ = 0;
+    void dev_mark(int i) { if (trace.on && dev_ev_[i]) (void)hipEventRecord(dev_ev_[i], ctx_->stream); }
     // A call that returns early (an error after its first transfer was queued) leaves copies from / to the staging pools in
     // flight; the next call resets the pools and would overwrite them.  The stream is drained before that can happen.
-    ~DeviceArena() { if (dirty_) (void)hipStreamSynchronize(ctx_->stream); }
+    ~DeviceArena()
+    {
+        if (dirty_) (void)hipStreamSynchronize(ctx_->stream);
+        if (trace.on) for (auto &e : dev_ev_) if (e) (void)hipEventDestroy(e);
+    }
     DeviceArena(const DeviceArena &) = delete;
     DeviceArena &operator=(const DeviceArena &) = delete;
     template <typename T> T *alloc(size_t n)
@@ -202,15 +248,22 @@ class DeviceArena {
         T *d = alloc<T>(n);
         if (!d) return nullptr;
         dirty_ = true;
+        trace.mark("up:alloc");
         if (is_pinned(h)) {
+            trace.mark("up:attr");
             hipError_t e = hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
+            trace.mark("up:enq");
             if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
             return d;
         }
+        trace.mark("up:attr");
         void *pin = pool_take(ctx_->pool_host, n * sizeof(T));
         if (!pin) { code_ = ctx_fail(ctx_, MPCX_E_NOMEM, "pinned staging allocation failed"); return nullptr; }
+        trace.mark("up:take");
         ctx_copier(ctx_)->copy(pin, h, n * sizeof(T));
+        trace.mark("up:copy");
         hipError_t e = hipMemcpyAsync(d, pin, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
+        trace.mark("up:enq");
         if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         return d;
     }
@@ -218,8 +271,11 @@ class DeviceArena {
     {
         if (code_ || !h) return;
         dirty_ = true;
+        if (dev_stage_ == 0) { dev_mark(2); dev_stage_ = 1; }
+        trace.mark("kernels");
         if (is_pinned(h)) {
             hipError_t e = hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx_->stream);
+            trace.mark("down:enq");
             if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
             return;
         }
@@ -241,22 +297,34 @@ class DeviceArena {
             }
         }
         out_.push_back({h, pin, n * sizeof(T), ev});
+        trace.mark("down:enq");
     }
     // wait for the stream, then hand the downloads to the caller's buffers
     int finish()
     {
         if (code_) return code_;
+        dev_mark(3);
         HostCopier *cp = ctx_copier(ctx_);
         for (const auto &o : out_) {                         // (stream order: an event's transfer done = all earlier ones done)
             if (!o.ev) continue;
             hipError_t e = hipEventSynchronize(o.ev);
+            trace.mark("fin:event");
             if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
             cp->copy(o.dst, o.src, o.bytes);
+            trace.mark("fin:copy");
         }
         hipError_t e = hipStreamSynchronize(ctx_->stream);
+        trace.mark("fin:sync");
         if (e != hipSuccess) return ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         dirty_ = false;
         for (const auto &o : out_) if (!o.ev) memcpy(o.dst, o.src, o.bytes);
+        trace.mark("fin:small");
+        if (trace.on && trace.t[trace.n - 1] - trace.t[0] >= host_trace_threshold_ms() && dev_ev_[0] && dev_ev_[2] && dev_ev_[3]) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventElapsedTime(&a, dev_ev_[0], dev_ev_[2]); (void)hipEventElapsedTime(&b, dev_ev_[2], dev_ev_[3]);
+            fprintf(stderr, "[mpcx host trace] device view: uploads + kernels %.3f ms, downloads %.3f ms\n", a, b);
+        }
+        trace.report("host-pointer call");
         return MPCX_OK;
     }
     bool failed() const { return code_ != 0; }

@@ -1264,7 +1264,7 @@ __device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double
 // Q_uu^-1 -> P_k -- and the operand prefetch; role 1 takes everything else off that chain: its own (redundant) LDL^T for
 // X2, the blocks G and Minv the sweeps need, the fused backward sweep of the node before (k+1, whose matrices sit complete
 // in another operand buffer) and all stores to the factor record.  Every element is computed by the same expressions as in
-// the one-wave form (results agree to rounding: 3e-14).  ~7 750 -> ~4 800 cycles per node for a wave that is alone on its
+// the one-wave form (bit-identical results: the library is built with -ffp-contract=on).  ~7 750 -> ~4 800 cycles per node for a wave that is alone on its
 // SIMD (64 satellites on a 1024-SIMD chip: the small-batch regime of BASELINE configs[1]).
 __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scratch &w, int lane, int role, bool keep_pt)
 {
@@ -2926,7 +2926,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     const int Kmax = a.K;
     const int K = a.Ks ? a.Ks[sat] : Kmax;        // (wave-uniform: one satellite per workgroup)
     if (K < 3 || K > Kmax) {                      // ragged batch with a node count the solver cannot take
+        // defined results all the same (as on the INFEASIBLE exit): the reference rows back, no virtual control, tf_bar
+        cgf64 *xb = (cgf64 *)a.xbar + (size_t)sat * 7 * Kmax, *ub = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
+        for (int e = lane; e < 7 * Kmax; e += 64) { a.X[(size_t)sat * 7 * Kmax + e] = xb[e]; a.NU[(size_t)sat * 7 * Kmax + e] = 0.0; }
+        for (int e = lane; e < 3 * Kmax; e += 64) a.U[(size_t)sat * 3 * Kmax + e] = ub[e];
         if (lane == 0) {
+            a.tf_out[sat] = (a.o.fixed_tf && !SHARED) ? 0.0 : a.tfbar[sat];
             a.status[sat] = MPCX_ST_BADK; a.iters[sat] = 0; a.kkt[sat] = 0.0;
             if (a.nreg) { a.nreg[2 * sat] = 0; a.nreg[2 * sat + 1] = -1; }
         }
@@ -3387,6 +3392,7 @@ int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t s
 #define MPCX_TWO_WAVE_MAX 1024      // two waves per satellite pay up to one satellite per SIMD (profiles/r03/batch_size_sweep.txt)
 #endif
 constexpr int kTwoWaveMax = MPCX_TWO_WAVE_MAX;
+constexpr int kCounterRing = 64;    // work-queue counters per context: solves in flight at once on different streams
 
 static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
 {
@@ -3490,6 +3496,13 @@ extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
     return (size_t)S * ws_doubles(K) * sizeof(double);
 }
 
+// what a solve on THIS context's device touches: one slot per persistent workgroup, min(S, workgroups resident at once)
+extern "C" size_t mpcx_solve_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K)
+{
+    const int slots = (ctx && S > ctx->n_slots) ? ctx->n_slots : S;
+    return (size_t)slots * ws_doubles(K) * sizeof(double);
+}
+
 extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *stage, const double *xbar,
                                            const double *ubar, const double *tf, const double *consts,
                                            const double *r_des, const mpcx_solve_opts *opts, double *X, double *U,
@@ -3566,12 +3579,16 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
         ctx->order_valid = 0;
         return MPCX_OK;
     }
-    if (!ctx->counter) MPCX_HIP(ctx, hipMalloc((void **)&ctx->counter, sizeof(int32_t)));
-    MPCX_HIP(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(int32_t), (hipStream_t)stream));
-    a.counter = ctx->counter;
+    // the launch's own work-queue counter: one of a ring, so that two solves of one context enqueued on different streams
+    // do not share (and reset) one queue -- each queue position must go to exactly one workgroup of ITS launch
+    if (!ctx->counter) MPCX_HIP(ctx, hipMalloc((void **)&ctx->counter, kCounterRing * sizeof(int32_t)));
+    a.counter = ctx->counter + (ctx->launch_seq++ % kCounterRing);
+    MPCX_HIP(ctx, hipMemsetAsync(a.counter, 0, sizeof(int32_t), (hipStream_t)stream));
+    // (the workspace is the caller's: slot b of THIS call's buffer)
     const int slots = S < ctx->n_slots ? S : ctx->n_slots;
-    // small batches -- at most one satellite per two SIMDs -- go to the two-wave build (solve2w.hip): a second wave per
-    // satellite shares the factorisation; results are bit for bit the one-wave kernel's (MPCX_SOLVE_ONE_WAVE keeps that)
+    // small batches -- at most one satellite per SIMD -- go to the two-wave build (solve2w.hip): a second wave per
+    // satellite shares the factorisation; results are bit for bit the one-wave kernel's (-ffp-contract=on, build.py;
+    // tests/test_full_size_gpu.py::test_two_wave_small_batch_kernel).  MPCX_SOLVE_ONE_WAVE keeps the one-wave kernel.
     if (S <= kTwoWaveMax && !(opts->flags & MPCX_SOLVE_ONE_WAVE)) {
         if (mpcx2w_launch(&a, sizeof a, slots, (hipStream_t)stream) != 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: two-wave launch failed");
     } else
@@ -3639,6 +3656,12 @@ extern "C" size_t mpcx_mpc_step_workspace_bytes(int S, int K)
            mpcx_solve_workspace_bytes(S, K);
 }
 
+extern "C" size_t mpcx_mpc_step_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K)
+{
+    return ((size_t)S * (K - 1) * MPCX_STAGE_DOUBLES + ((size_t)S + 1) / 2 + 1) * sizeof(double) +
+           mpcx_solve_workspace_bytes_ctx(ctx, S, K);
+}
+
 extern "C" int mpcx_mpc_step_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *xbar, const double *ubar,
                                           const double *tf, const double *consts, const double *r_des, int flags,
                                           double max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU,
@@ -3647,7 +3670,7 @@ extern "C" int mpcx_mpc_step_batch_ragged(mpcx_ctx *ctx, int S, int K, const int
     if (!ctx) return MPCX_E_BADARG;
     if (S < 1 || K < 3 || !opts) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_step: need S>=1, K>=3 and options");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
-    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes(S, K));
+    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes_ctx(ctx, S, K));
     if (!ws) return MPCX_E_NOMEM;
     DeviceArena ar(ctx);
     double *dx = ar.upload(xbar, (size_t)S * 7 * K), *du = ar.upload(ubar, (size_t)S * 3 * K);
@@ -3690,7 +3713,7 @@ extern "C" int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, cons
     if (S < 1 || K < 3 || !opts || !prop_status) return ctx_fail(ctx, MPCX_E_BADARG, "scp_iteration: need S>=1, K>=3, options and prop_status");
     if (opts->flags & (MPCX_SOLVE_FIXED_TF | MPCX_SOLVE_SHARED_TF)) return ctx_fail(ctx, MPCX_E_BADARG, "scp_iteration: free per-satellite tf only");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
-    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes(S, K));
+    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes_ctx(ctx, S, K));
     if (!ws) return MPCX_E_NOMEM;
     DeviceArena ar(ctx);
     double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf = ar.upload(tf, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
@@ -3747,7 +3770,7 @@ extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, co
                 r[98 + i] = xi[(size_t)s * 7 * (K - 1) + (size_t)i * (K - 1) + k];
             }
         }
-    void *ws = ctx_workspace(ctx, mpcx_solve_workspace_bytes(S, K));
+    void *ws = ctx_workspace(ctx, mpcx_solve_workspace_bytes_ctx(ctx, S, K));
     if (!ws) return MPCX_E_NOMEM;
     DeviceArena ar(ctx);
     double *dst_ = ar.upload(st.data(), st.size());

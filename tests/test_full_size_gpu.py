@@ -110,36 +110,29 @@ def test_satellites_are_independent_units():
         first, count = shard_block(S, 8, rank)
         xb, ub, cb, rb = workload(S, K, first, count)
         assert np.array_equal(xb, xbar[first:first + count])
-        # (flags=16, MPCX_SOLVE_ONE_WAVE: the 256-satellite block through the same one-wave kernel as the 2048 batch; batches of
-        #  up to 1024 otherwise run on the two-wave kernel, which agrees with it to rounding, not bit for bit: see below)
-        part = mpc_step_batch(xb, ub, np.ones(count), cb, rb, flags=16)
+        # (the 256-satellite block runs on the two-wave kernel, the 2048 batch on the one-wave kernel: one set of bits)
+        part = mpc_step_batch(xb, ub, np.ones(count), cb, rb)
         assert np.array_equal(part.X, whole.X[first:first + count]) and np.array_equal(part.tf, whole.tf[first:first + count])
 
 
 def test_two_wave_small_batch_kernel():
     """Batches of up to 1024 satellites run on the two-wave kernel (solve2w.hip: a second wave per satellite shares the
-    factorisation).  It must give what the one-wave kernel gives (MPCX_SOLVE_ONE_WAVE = 16) -- same iteration counts (see below), same
-    statuses, solutions equal to rounding -- on the benchmark constellation at K = 30 and 100, on OptimalController's
-    option set (stiff terminal windows: refinement passes) and at the shortest horizon; and like the one-wave kernel it
-    must not care who shares the batch (bit for bit between a batch of 64, its reversal and single-satellite calls)."""
+    factorisation).  It must give BIT FOR BIT what the one-wave kernel gives (MPCX_SOLVE_ONE_WAVE = 16; both are compiled
+    with -ffp-contract=on, build.py: no fusion across statements, so the same source expressions round alike in the two
+    compilations) -- on the benchmark constellation at K = 30 and 100, on OptimalController's option set (stiff terminal
+    windows: refinement passes), with a thrust limit below the reference thrust (regularised iterations) and at the
+    shortest horizon; and like the one-wave kernel it must not care who shares the batch (a batch of 64, its reversal and
+    single-satellite calls)."""
     from mpconstellation_amd import mpc_step_batch
-    for S, K, opts in ((64, 30, {}), (48, 100, {}), (1024, 30, {}), (128, 30, {"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}), (5, 3, {})):
+    for S, K, opts in ((64, 30, {}), (48, 100, {}), (1024, 30, {}), (128, 30, {"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}),
+                       (64, 30, {"u_lim": [0, 0.3]}), (5, 3, {})):
         xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
         tf = np.ones(S)
         one = mpc_step_batch(xbar, ubar, tf, consts, r_des, options=opts, flags=16, regularised=True)
         two = mpc_step_batch(xbar, ubar, tf, consts, r_des, options=opts, regularised=True)
-        assert (two.status == 0).all() and np.array_equal(one.status, two.status)
-        # a satellite whose convergence test sits on the threshold at some iterate may stop one iteration apart (seen: 1 of
-        # 512); the others: same counts, solutions equal to rounding (observed 3e-14 .. 3e-11)
-        same = one.iters == two.iters
-        assert np.abs(one.iters - two.iters).max() <= 1 and same.mean() >= 0.98
-        assert np.array_equal(one.n_regularised[same], two.n_regularised[same])
-        if not opts:
-            assert np.abs(one.X - two.X)[same].max() < 1e-9 and np.abs(one.U - two.U)[same].max() < 1e-8 and np.abs(one.tf - two.tf)[same].max() < 1e-10
-        # (the stiff option set passes through iterations whose barrier weights lie between 1e9 and the refinement threshold
-        #  1e10: their unrefined directions carry the kernels' rounding differences into the flat directions of the
-        #  objective -- 2e-6 observed, the tolerance of any two converged solves; with the threshold at 1e9 it was 3e-11)
-        assert np.abs(one.X - two.X).max() < 5e-6 and np.abs(one.tf - two.tf).max() < 5e-6      # (the stated tolerance between two converged solves)
+        assert np.isin(two.status, (0, 7)).all()
+        for f in ("X", "U", "NU", "tf", "kkt", "status", "iters", "n_regularised", "first_regularised"):
+            assert np.array_equal(getattr(one, f), getattr(two, f)), (S, K, opts, f)
     xbar, ubar, consts, r_des = workload(4096, 30, first=0, count=64)
     tf = np.ones(64)
     two = mpc_step_batch(xbar, ubar, tf, consts, r_des)
@@ -197,7 +190,7 @@ def test_config3_full_size_scp_loop():
     S, K = run.S, run.K
     assert (status == 0).all() and kkt.max() <= 1e-8 and iters.max() <= 40
     X = run.d_X.cpu().numpy(); U = run.d_U.cpu().numpy(); NU = run.d_NU.cpu().numpy(); tfo = run.d_tfo.cpu().numpy()
-    Kn = run.d_Kn.cpu().numpy()
+    Kn = run.d_Kn[0].cpu().numpy()
     assert (run.d_pst.cpu().numpy() == 0).all() and (run.d_rst.cpu().numpy() == 0).all()    # re-rollout and resampling succeeded
     assert Kn.min() >= 80 and Kn.max() <= 99 and len(np.unique(Kn)) > 3                       # a genuinely ragged batch
     h = run.host
@@ -268,7 +261,7 @@ def test_config4_every_rank_block():
             ref = N.solve(P)
             assert ref["status"] == 0
             assert np.abs(X[s] - ref["X"]).max() < 5e-6 and np.abs(U[s] - ref["U"]).max() < 5e-6 and abs(tfo[s] - ref["tf"]) < 5e-6
-        res = mpc_step_batch(h["xbar"][pick], h["ubar"][pick], np.ones(len(pick)), h["consts"][pick], h["r_des"][pick], flags=16)
+        res = mpc_step_batch(h["xbar"][pick], h["ubar"][pick], np.ones(len(pick)), h["consts"][pick], h["r_des"][pick])
         assert np.array_equal(res.X, X[pick]) and np.array_equal(res.tf, tfo[pick])
         if rank == 3:                                      # the block's inputs are what the generator gives for these indices
             xb, ub, cs, rd = workload(65536, K, first=first, count=count)
