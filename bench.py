@@ -59,6 +59,7 @@ class Runner:
         from mpconstellation_amd.sharding import shard_block
         self.torch, self.ffi = torch, _ffi
         self.lib = _ffi.load(); self.ctx = _ffi.context(local_rank)
+        self.stream = torch.cuda.current_stream().cuda_stream
         S, K, n_scp = WORKLOADS[workload]
         self.S, self.K, self.n_scp = S, K, n_scp
         S_total = S * world

@@ -77,6 +77,13 @@ int mpcx_create(int device, mpcx_ctx **out);
 void mpcx_destroy(mpcx_ctx *ctx);
 const char *mpcx_last_error(const mpcx_ctx *ctx); /* ctx may be NULL: last create error */
 int mpcx_synchronize(mpcx_ctx *ctx, void *stream);
+/* The stream the HOST-POINTER entry points of this context work on (a context handle per (device, stream)).  A
+ * context starts with a private non-blocking stream, so that contexts of different host threads overlap (one per device, or
+ * several per device).  A process that drives the device through a stream of its own -- PyTorch's, say -- may hand that
+ * stream in instead: the context's calls are then ordered with the rest of that stream's work.  stream: a hipStream_t, NULL
+ * for the device's default stream, MPCX_STREAM_PRIVATE for a new private stream.  The old stream is drained first. */
+#define MPCX_STREAM_PRIVATE ((void *)(intptr_t)-1)
+int mpcx_set_stream(mpcx_ctx *ctx, void *stream);
 /* Page-locked host memory for the arrays a caller hands to the host-pointer entry points again and again (the reference
  * keeps x_bar / u_bar / results in numpy arrays, optimizer.py:13-39, 192-217; a numpy array can live in such a buffer).
  * Arrays in page-locked memory are transferred by DMA straight from / to the caller's buffer; pageable ones go through the
@@ -322,6 +329,27 @@ int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *
                                     double prop_max_step, int disc_flags, double disc_max_step, const mpcx_solve_opts *opts,
                                     double *xbar_out, double *ubar_out, double *X, double *U, double *NU, double *tf_out,
                                     int32_t *status, int32_t *iters, double *kkt, int32_t *prop_status);
+/*
+ * OptimalController.update (control.py:170-235) for S satellites in ONE call -- and, optionally, the segment flight of
+ * Simulator.run_segment (simulator.py:58-65) that follows it -- with everything between the first input and the last result
+ * resident in HBM: the reference rollout from y0 [S][7] over tf0 [S] (the horizon) under ConstantTangentialThrustController
+ * (ref_thrust; control.py:178-180) sampled at K = int(base_res * horizon) nodes, then n_scp x [ extract_uk, discretise, solve ]
+ * (:183-213) with, between two iterations, the nonlinear re-rollout under SequenceController(u_opt, tf_u, tf_u) sampled at
+ * int(base_res * tf_u) nodes per satellite (:217-227, simulator.py:38: the node counts are computed on the device and the
+ * next iteration is a ragged launch; the plan's thrust is consumed in place as the rollout's table).
+ * Results: the last iteration's plan X [S][7][K], U [S][3][K], NU [S][7][K] (rows of length K, Ks_out[s] columns in use, zeros
+ * behind them), tf_out [S] = tf_u, Ks_out [S]; status, iters [n_scp][S]: every iteration's solver outcome; kkt [S]: the last
+ * iteration's; prop_status [S]: the first failure among the rollouts (MPCX_ST_*).
+ * Segment flight (y_sim != NULL): from y0 over sim_tf under the truth model sim_flags (MPCX_FLAG_DRAG | MPCX_FLAG_J2) with
+ * SequenceController(u_opt, tf_u, tf_sim = sim_interval) (end_tau = tf_u / sim_interval, control.py:102,217),
+ * y_sim [S][7][sim_n_eval] = sol.y at linspace(0, 1, sim_n_eval), sim_status [S].
+ */
+int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, double base_res, const double *y0, const double *tf0,
+                          const double *consts, const double *r_des, double ref_thrust, double prop_max_step, int disc_flags,
+                          double disc_max_step, const mpcx_solve_opts *opts, double *X, double *U, double *NU, double *tf_out,
+                          int32_t *Ks_out, int32_t *status, int32_t *iters, double *kkt, int32_t *prop_status, double sim_tf,
+                          double sim_interval, int sim_n_eval, int sim_flags, double sim_max_step, double *y_sim,
+                          int32_t *sim_status);
 /*
  * Replaces Discretizer.extract_uk (linearize_discretize.py:393-411) for a SequenceController played over its own horizon
  * (control.py:217-221, tf_sim = tf_u: end_tau = 1): the first-order hold (control.py:104-126) of table u [S][3][Ku]

@@ -50,6 +50,7 @@ _SIGS = {
     "mpcx_destroy": (None, [_vp]),
     "mpcx_last_error": (C.c_char_p, [_vp]),
     "mpcx_synchronize": (C.c_int, [_vp, _vp]),
+    "mpcx_set_stream": (C.c_int, [_vp, _vp]),
     "mpcx_host_alloc": (_vp, [_vp, C.c_size_t]),
     "mpcx_host_free": (None, [_vp, _vp]),
     "mpcx_discretize_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
@@ -95,6 +96,9 @@ _SIGS = {
                                                          _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpcx_scp_iteration_batch_ragged": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp,
                                                   C.c_double, C.c_int, C.c_double, _po, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]),
+    "mpcx_mpc_update_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int,
+                                        C.c_double, _po, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp, _ip, C.c_double, C.c_double, C.c_int, C.c_int,
+                                        C.c_double, _dp, _ip]),
     "mpcx_resample_sequence_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
 }
 
@@ -134,6 +138,17 @@ def context(device=0, slot=0):
                                 f"{lib.mpcx_last_error(None).decode()}")
             _ctxs[device] = h
         return _ctxs[device]
+
+
+STREAM_PRIVATE = C.c_void_p(-1)
+
+
+def set_stream(stream, device=0, slot=0):
+    """Run the host-pointer entry points of this context on `stream` (a hipStream_t as an integer, e.g.
+    torch.cuda.current_stream().cuda_stream; None / 0: the device's default stream; STREAM_PRIVATE: a private stream again).
+    For processes that also drive the device through another stream: include/mpcx.h, mpcx_set_stream."""
+    lib = load(); ctx = context(device, slot)
+    check(lib.mpcx_set_stream(ctx, stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream or 0)), ctx, "mpcx_set_stream")
 
 
 class _PinnedOwner:

@@ -41,6 +41,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->red = nullptr; c->red_cap = 0; c->coop_max = 0;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;
+    c->own_stream = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         snprintf(g_create_err, sizeof g_create_err, "hipStreamCreate failed");
@@ -65,8 +66,21 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     pool_free(ctx->pool_dev); pool_free(ctx->pool_host);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     delete ctx->copier;
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int mpcx_set_stream(mpcx_ctx *ctx, void *stream)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // nothing of this context is left on the old stream
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (stream == MPCX_STREAM_PRIVATE) {
+        MPCX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    } else ctx->stream = (hipStream_t)stream;                          // (NULL: the device's default stream)
+    return MPCX_OK;
 }
 
 extern "C" const char *mpcx_last_error(const mpcx_ctx *ctx) { return ctx ? ctx->err : g_create_err; }

@@ -118,6 +118,7 @@ inline void pool_free(StagePool &pl)
 struct mpcx_ctx {
     int device;
     hipStream_t stream;       // stream used by the host-pointer entry points
+    bool own_stream;          // created by the library (mpcx_create / MPCX_STREAM_PRIVATE), not handed in by mpcx_set_stream
     char err[512];
     // grow-only device workspace reused by the solver / fused step (never freed between calls)
     void *ws;
@@ -211,6 +212,10 @@ class DeviceArena {
         for (auto &e : dev_ev_) e = nullptr;
         if (trace.on) for (auto &e : dev_ev_) if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         dev_mark(0);
+        // tracing only: how long the stream takes to execute the call's first packet -- a marker alone, polled: bench.py's
+        // slow warm-up calls (40 ms against 8.8 ms) spend their extra time HERE, before any work of the call runs; the
+        // device work (device view below) and the waits for it are as fast as in the steady state (profiles/r04/host_wait.txt)
+        if (trace.on && dev_ev_[0]) { while (hipEventQuery(dev_ev_[0]) == hipErrorNotReady) {} trace.mark("q:first-marker"); }
     }
     HostTrace trace;
     // tracing only: device-side time stamps on the context's stream -- 0 call start, 1 uploads queued (kernels follow),

@@ -3747,6 +3747,117 @@ extern "C" int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, cons
     return ar.finish();
 }
 
+namespace MPCX_NS {
+// Node counts of the next SCP iteration: Simulator.run samples a rollout over tf at int(base_res * tf) points (simulator.py:38;
+// control.py:227 passes tf_u), computed where tf_u lives.  The counts are clamped to the row length only in the sense that a
+// count outside 3..K makes that satellite's next solve report MPCX_ST_BADK.
+__global__ void node_count_kernel(int S, double base_res, const double *tf, int32_t *Kn)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) Kn[i] = (int32_t)(base_res * tf[i]);
+}
+__global__ void fill_f64_kernel(int n, double v, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+__global__ void scale_f64_kernel(int n, const double *a, double d, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] / d;
+}
+}  // namespace MPCX_NS
+
+// OptimalController.update (control.py:170-235) for S satellites as ONE call, everything between the first input and the
+// last result resident in HBM (include/mpcx.h).
+extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, double base_res, const double *y0, const double *tf0,
+                                     const double *consts, const double *r_des, double ref_thrust, double prop_max_step,
+                                     int disc_flags, double disc_max_step, const mpcx_solve_opts *opts, double *X, double *U,
+                                     double *NU, double *tf_out, int32_t *Ks_out, int32_t *status, int32_t *iters, double *kkt,
+                                     int32_t *prop_status, double sim_tf, double sim_interval, int sim_n_eval, int sim_flags,
+                                     double sim_max_step, double *y_sim, int32_t *sim_status)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    if (S < 1 || K < 3 || n_scp < 1 || !opts || !y0 || !tf0 || !consts || !r_des || !X || !U || !NU || !tf_out || !Ks_out || !status ||
+        !iters || !kkt || !prop_status || !(base_res > 0.0))
+        return ctx_fail(ctx, MPCX_E_BADARG, "mpc_update: need S>=1, K>=3, n_scp>=1, base_res>0, options and all arrays");
+    if (opts->flags & (MPCX_SOLVE_FIXED_TF | MPCX_SOLVE_SHARED_TF)) return ctx_fail(ctx, MPCX_E_BADARG, "mpc_update: free per-satellite tf only");
+    if (y_sim && (sim_n_eval < 1 || !(sim_tf > 0.0) || !(sim_interval > 0.0) || !sim_status))
+        return ctx_fail(ctx, MPCX_E_BADARG, "mpc_update: segment flight needs sim_tf>0, sim_interval>0, sim_n_eval>=1, sim_status");
+    MPCX_HIP(ctx, hipSetDevice(ctx->device));
+    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes_ctx(ctx, S, K));
+    if (!ws) return MPCX_E_NOMEM;
+    DeviceArena ar(ctx);
+    hipStream_t st = ctx->stream;
+    double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf0 = ar.upload(tf0, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
+    const size_t n7 = (size_t)S * 7 * K, n3 = (size_t)S * 3 * K;
+    double *dx = ar.alloc<double>(n7), *du = ar.alloc<double>(n3);                      // reference trajectory / thrust of the iteration
+    double *dX = ar.alloc<double>(n7), *dNU = ar.alloc<double>(n7);
+    double *dU[2] = {ar.alloc<double>(n3), ar.alloc<double>(n3)};                       // plan thrust: iteration i writes dU[i & 1], the next rollout plays it
+    double *dtfu[2] = {ar.alloc<double>(S), ar.alloc<double>(S)};                       // tf_u of the iterations, alternating
+    double *dmag = ar.alloc<double>(S), *done = ar.alloc<double>(S), *dk = ar.alloc<double>(S), *dend = ar.alloc<double>(S);
+    int32_t *dKn[2] = {ar.alloc<int32_t>(S), ar.alloc<int32_t>(S)};                     // node counts, alternating
+    int32_t *dst = ar.alloc<int32_t>((size_t)n_scp * S), *dit = ar.alloc<int32_t>((size_t)n_scp * S);
+    int32_t *dps = ar.alloc<int32_t>(S), *dpn = ar.alloc<int32_t>(S), *dps2 = ar.alloc<int32_t>(S);
+    double *dys = y_sim ? ar.alloc<double>((size_t)S * 7 * sim_n_eval) : nullptr;
+    int32_t *dss = y_sim ? ar.alloc<int32_t>(S) : nullptr;
+    if (ar.failed()) return ar.code();
+    const dim3 gS((S + 255) / 256), b256(256);
+    hipLaunchKernelGGL(fill_f64_kernel, gS, b256, 0, st, S, ref_thrust, dmag);
+    hipLaunchKernelGGL(fill_f64_kernel, gS, b256, 0, st, S, 1.0, done);
+    MPCX_HIP(ctx, hipMemsetAsync(dps, 0, sizeof(int32_t) * S, st));
+    const double *tf_cur = dtf0;
+    const int32_t *Ks = nullptr;            // node counts of the current iteration (nullptr: K for everybody)
+    int rc = MPCX_OK;
+    for (int it = 0; it < n_scp && rc == MPCX_OK; ++it) {
+        double *Uw = dU[it & 1], *tfw = dtfu[it & 1];
+        if (Ks) {                                                                         // ragged rows: the unused columns
+            MPCX_HIP(ctx, hipMemsetAsync(dx, 0, n7 * sizeof(double), st));
+            MPCX_HIP(ctx, hipMemsetAsync(du, 0, n3 * sizeof(double), st));
+        }
+        // control.py:178-180 / :217-227: rollout under the tangential reference law, then under the sequence just optimised,
+        // played over its own horizon (end_tau = 1) and sampled at int(base_res * tf_u) nodes; u_bar = extract_uk (:188)
+        if (it == 0)
+            rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, K, nullptr, dy0, tf_cur, dc, 0, MPCX_CTRL_TANGENTIAL, dmag, 0, nullptr, nullptr,
+                                                        prop_max_step, dx, du, dps2, dpn, st);
+        else
+            rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, K, Ks, dy0, tf_cur, dc, 0, MPCX_CTRL_SEQUENCE, dU[(it - 1) & 1], K,
+                                                        it >= 2 ? dKn[(it - 1) & 1] : nullptr, done, prop_max_step, dx, du, dps2, dpn, st);
+        if (rc) break;
+        merge_status_kernel_launch(S, dps2, dps, st);                                    // (any rollout's failure is the update's)
+        rc = mpcx_mpc_step_batch_ragged_dev(ctx, S, K, Ks, dx, du, tf_cur, dc, drd, disc_flags, disc_max_step, opts, dX, Uw, dNU, tfw,
+                                            dst + (size_t)it * S, dit + (size_t)it * S, dk, ws, st);
+        if (rc) break;
+        tf_cur = tfw;
+        if (it + 1 < n_scp) {
+            int32_t *kn = dKn[(it + 1) & 1];
+            hipLaunchKernelGGL(node_count_kernel, gS, b256, 0, st, S, base_res, tfw, kn);
+            Ks = kn;
+        }
+    }
+    if (rc) return rc;
+    MPCX_HIP(ctx, hipGetLastError());
+    const double *Uplan = dU[(n_scp - 1) & 1];
+    if (y_sim) {
+        // Simulator.run_segment (simulator.py:58-65): fly sim_tf under the truth model with SequenceController(u_opt, tf_u,
+        // tf_sim = sim_interval): end_tau = tf_u / sim_interval (control.py:102), the plan's table with its own column count
+        // (end_tau as the host computes it: a division, not a product with the reciprocal)
+        hipLaunchKernelGGL(scale_f64_kernel, gS, b256, 0, st, S, tf_cur, sim_interval, dend);
+        hipLaunchKernelGGL(fill_f64_kernel, gS, b256, 0, st, S, sim_tf, dmag);           // (dmag is free again: the flight time per satellite)
+        rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, sim_n_eval, nullptr, dy0, dmag, dc, sim_flags, MPCX_CTRL_SEQUENCE, Uplan, K, Ks, dend,
+                                                    sim_max_step, dys, nullptr, dss, dpn, st);
+        if (rc) return rc;
+    }
+    ar.download(X, dX, n7); ar.download(U, (const double *)Uplan, n3); ar.download(NU, dNU, n7);
+    ar.download(tf_out, tf_cur, S);
+    if (Ks) ar.download(Ks_out, Ks, S);
+    else for (int i = 0; i < S; ++i) Ks_out[i] = K;                                      // (a single iteration: K nodes for everybody)
+    ar.download(status, dst, (size_t)n_scp * S); ar.download(iters, dit, (size_t)n_scp * S); ar.download(kkt, dk, S);
+    ar.download(prop_status, dps, S);
+    if (y_sim) { ar.download(y_sim, dys, (size_t)S * 7 * sim_n_eval); ar.download(sim_status, dss, S); }
+    return ar.finish();
+}
+
 extern "C" int mpcx_solve_batch(mpcx_ctx *ctx, int S, int K, const double *A, const double *Bp, const double *Bn,
                                 const double *Sigma, const double *xi, const double *xbar, const double *ubar,
                                 const double *tf, const double *consts, const double *r_des,

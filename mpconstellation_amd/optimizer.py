@@ -86,14 +86,29 @@ def _tf_io(S, fixed_tf):
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
                    linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, shared_tf=False,
-                   **solver):
+                   devices=None, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Ks (S,) int: a ragged batch -- satellite s has Ks[s] <= K nodes in the first columns of its rows (what the reference's
     second SCP iteration poses: int(base_res * tf_u) nodes per satellite, control.py:227); result columns past a
     satellite's count are zero.
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
-    returns the results in page-locked buffers that the next call of the same shape overwrites."""
+    returns the results in page-locked buffers that the next call of the same shape overwrites.
+    devices=[d0, d1, ...]: the satellites are dealt out in contiguous blocks to these devices (sharding.sharded_call: one
+    host thread and context per device, no exchange between them) and the blocks' results joined; satellites are
+    independent units, so every satellite gets bit for bit what a single-device call gives it."""
+    if devices is not None and len(devices) > 1:
+        if shared_tf or fixed_tf is not None or pinned_results:
+            raise ValueError("devices=[...]: independent per-satellite problems only (no shared / fixed tf, no pinned_results)")
+        from .sharding import sharded_call, join_results
+        xbar = _ffi.as_f64(xbar); S = xbar.shape[0]
+        bc = lambda a: _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)))
+        Ksb = None if Ks is None else np.ascontiguousarray(np.broadcast_to(np.asarray(Ks), (S,)), dtype=np.int32)
+        fn = lambda x, u, t, c, r, k, device, slot: mpc_step_batch(x, u, t, c, r, options, include_J2, max_step, device, slot, linear_vt,
+                                                                   None, False, uniform_steps, regularised, k, False, None, **solver)
+        return join_results(sharded_call(fn, devices, [xbar, _ffi.as_f64(ubar), bc(tf), _ffi.as_f64(consts), bc(r_des), Ksb]))
+    if devices is not None and len(devices) == 1:
+        device = int(devices[0])
     solver = _solver_flags(solver, linear_vt, fixed_tf, shared_tf)
     xbar = _ffi.as_f64(xbar); ubar = _ffi.as_f64(ubar)
     S, _, K = xbar.shape
@@ -169,6 +184,61 @@ def scp_iteration_batch(y0, tf, consts, r_des, law, K, options=None, Ks=None, Ku
     _ffi.check(rc, ctx, "mpcx_scp_iteration_batch_ragged")
     res = SolveResult(X, U, NU, tfo, status, iters, kkt)
     res.prop_status = pst; res.xbar = xb; res.ubar = ub
+    return res
+
+
+class UpdateResult(SolveResult):
+    """mpc_update_batch's result: the last SCP iteration's plan (rows of length K, Ks[s] columns in use), every iteration's
+    status / iteration counts (n_scp, S), the rollouts' status and -- when the segment was flown -- its trajectory."""
+
+
+def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None, ref_thrust=0.5, include_J2=False, max_step=1e-2,
+                     prop_max_step=1e-3, device=0, slot=0, linear_vt=False, fly=None, devices=None, **solver):
+    """OptimalController.update (control.py:170-235) for S satellites in ONE library call (mpcx_mpc_update_batch): the tangential
+    reference rollout over `horizon` sampled at K = int(base_res * horizon) nodes, n_scp x (extract_uk, discretise, solve) with
+    the nonlinear re-rollout under the optimised sequence -- sampled at int(base_res * tf_u) nodes per satellite -- between
+    two iterations; nothing but the final plan crosses PCIe.
+    fly = (tf, interval, n_eval, include_drag, include_J2[, max_step]): also Simulator.run_segment's flight (simulator.py:58-65)
+    of the plan over tf under the truth model, SequenceController(u_opt, tf_u, tf_sim = interval), from the same start states;
+    the result then carries y_sim (S,7,n_eval) and sim_status.
+    devices=[d0, d1, ...]: contiguous blocks of satellites on several devices at once (see mpc_step_batch)."""
+    if devices is not None and len(devices) > 1:
+        from .sharding import sharded_call, join_results
+        y0 = _ffi.as_f64(y0); S = y0.shape[0]
+        bc = lambda a: _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)))
+        fn = lambda y, h, c, r, device, slot: mpc_update_batch(y, h, c, r, base_res, n_scp, options, ref_thrust, include_J2, max_step,
+                                                               prop_max_step, device, slot, linear_vt, fly, None, **solver)
+        return join_results(sharded_call(fn, devices, [y0, bc(horizon), _ffi.as_f64(consts), bc(r_des)]))
+    if devices is not None and len(devices) == 1:
+        device = int(devices[0])
+    solver = _solver_flags(solver, linear_vt, None, False)
+    y0 = _ffi.as_f64(y0); S = y0.shape[0]
+    horizon = _ffi.as_f64(np.broadcast_to(np.asarray(horizon, dtype=np.float64), (S,)))
+    K = int(base_res * float(horizon[0]))
+    if not (horizon == horizon[0]).all():
+        raise ValueError("mpc_update_batch: one horizon for the whole batch (the row length K = int(base_res * horizon))")
+    r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
+    consts = _ffi.as_f64(consts)
+    opts = _ffi.make_solve_opts(options, **solver)
+    X, U, NU, kkt, _, _ = _result_arrays(S, K, device, False)
+    status = np.zeros((n_scp, S), dtype=np.int32); iters = np.zeros((n_scp, S), dtype=np.int32)
+    tfo = np.empty(S); Ks = np.zeros(S, dtype=np.int32); pst = np.zeros(S, dtype=np.int32)
+    y_sim = sst = None; sim = (0.0, 0.0, 0, 0, 1e-3)
+    if fly is not None:
+        tf_sim, interval, n_eval, drag, j2 = fly[:5]
+        sim = (float(tf_sim), float(interval), int(n_eval), (_ffi.FLAG_DRAG if drag else 0) | (_ffi.FLAG_J2 if j2 else 0),
+               float(fly[5]) if len(fly) > 5 else 1e-3)
+        y_sim = np.empty((S, 7, sim[2])); sst = np.zeros(S, dtype=np.int32)
+    lib = _ffi.load(); ctx = _ffi.context(device, slot)
+    import ctypes as C
+    rc = lib.mpcx_mpc_update_batch(ctx, S, K, int(n_scp), float(base_res), _ffi.dptr(y0), _ffi.dptr(horizon), _ffi.dptr(consts),
+                                   _ffi.dptr(r_des), float(ref_thrust), float(prop_max_step), _ffi.FLAG_J2 if include_J2 else 0,
+                                   float(max_step), C.byref(opts), _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo),
+                                   _ffi.iptr(Ks), _ffi.iptr(status), _ffi.iptr(iters), _ffi.dptr(kkt), _ffi.iptr(pst), sim[0], sim[1],
+                                   sim[2], sim[3], sim[4], None if y_sim is None else _ffi.dptr(y_sim), None if sst is None else _ffi.iptr(sst))
+    _ffi.check(rc, ctx, "mpcx_mpc_update_batch")
+    res = UpdateResult(X, U, NU, tfo, status, iters, kkt)
+    res.Ks = Ks; res.prop_status = pst; res.y_sim = y_sim; res.sim_status = sst
     return res
 
 

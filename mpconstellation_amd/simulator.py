@@ -20,15 +20,40 @@ class OdeResult:
 
 
 def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0, slot=0,
-                    Kus=None, thrust=False):
+                    Kus=None, thrust=False, devices=None):
     """y0 (S,7) normalised, tf (S,), consts (S,8); law = (kind, vec, Ku, end_tau) with per-satellite or
     broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,) -- and, with thrust=True, u (S,3,n_eval) as a
     fourth value: the law evaluated at the output points, Discretizer.extract_uk of the rollout's own controller
     (linearize_discretize.py:393-411), from the same launch.
     Ragged batches: n_eval may be an (S,) integer array -- satellite s is sampled at linspace(0, 1, n_eval[s]), y has
     max(n_eval) columns, zero past a satellite's count -- and Kus (S,) gives the columns in use of each satellite's
-    thrust table (law SEQUENCE, table rows of length Ku)."""
+    thrust table (law SEQUENCE, table rows of length Ku).
+    devices=[d0, d1, ...]: contiguous blocks of satellites on several devices at once (sharding.sharded_call)."""
     y0 = _ffi.as_f64(y0); S = y0.shape[0]
+    if devices is not None and len(devices) > 1:
+        from .sharding import sharded_call
+        kind, vec, Ku, end_tau = law
+        bc = lambda a, shape: None if a is None else _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))
+        if kind == _ffi.CTRL_CONSTANT: vec = bc(np.asarray(vec, dtype=np.float64).reshape(-1, 3), (S, 3))
+        elif kind == _ffi.CTRL_TANGENTIAL: vec = bc(np.asarray(vec, dtype=np.float64).reshape(-1), (S,))
+        elif kind == _ffi.CTRL_SEQUENCE:
+            vec = np.asarray(vec, dtype=np.float64); vec = bc(vec if vec.ndim == 3 else vec[None], (S, 3, Ku)); end_tau = bc(end_tau, (S,))
+        else: vec = None
+        if kind != _ffi.CTRL_SEQUENCE: end_tau = None
+        ne = np.ascontiguousarray(np.broadcast_to(np.asarray(n_eval), (S,)), dtype=np.int32) if np.ndim(n_eval) > 0 else None
+        ku = None if Kus is None else np.ascontiguousarray(np.broadcast_to(np.asarray(Kus), (S,)), dtype=np.int32)
+        nmax = int(ne.max()) if ne is not None else int(n_eval)
+
+        def fn(y, t, c, v, e, n, k, device, slot):
+            out = propagate_batch(y, t, c, (kind, v, Ku, e), n_eval if n is None else n, include_drag, include_J2, max_step, device, slot, k, thrust)
+            if n is not None and out[0].shape[2] < nmax:       # (a block's rows are as long as ITS longest satellite)
+                pad = lambda a: np.concatenate([a, np.zeros(a.shape[:2] + (nmax - a.shape[2],))], axis=2)
+                out = (pad(out[0]), out[1], out[2]) + ((pad(out[3]),) if thrust else ())
+            return out
+        parts = sharded_call(fn, devices, [y0, bc(tf, (S,)), _ffi.as_f64(consts), vec, end_tau, ne, ku])
+        return tuple(np.concatenate([p[i] for p in parts], axis=0) for i in range(len(parts[0])))
+    if devices is not None and len(devices) == 1:
+        device = int(devices[0])
     n_evals = None
     if np.ndim(n_eval) > 0:
         n_evals = np.ascontiguousarray(np.broadcast_to(np.asarray(n_eval), (S,)), dtype=np.int32)
@@ -73,7 +98,7 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
 
 class Simulator:
     def __init__(self, sats=[], controller=Controller(), scale=SatelliteScale(), base_res=100, include_drag=True,
-                 include_J2=True, verbose=False, device=0):
+                 include_J2=True, verbose=False, device=0, devices=None):
         self.sim_data = {}
         self.sim_time = {}
         self.sats = sats
@@ -85,6 +110,7 @@ class Simulator:
         self.scale = scale
         self.verbose = verbose
         self.device = device
+        self.devices = devices        # several devices: the satellites are dealt out in contiguous blocks (sharding.sharded_call)
 
     # ---- batched rollout of all satellites (one kernel) ----
     def _rollout(self, sats, tf):
@@ -92,7 +118,7 @@ class Simulator:
         y0 = np.stack([self.scale.normalize_state(s.get_state_vector()) for s in sats])
         law = self._device_law()
         y, status, nsteps = propagate_batch(y0, tf, np.tile(const, (len(sats), 1)), law, self.eval_points,
-                                            self.include_drag, self.include_J2, 0.001, self.device)
+                                            self.include_drag, self.include_J2, 0.001, self.device, devices=self.devices)
         if (status == 1).any():
             raise Exception("ERROR: INVALID SATELLITE MASS")           # simulator.py:135-136
         if (status != 0).any():

@@ -104,28 +104,42 @@ def test_constellation_generator_and_sharding(golden_dir):
         assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
 
 
-def test_concurrent_jobs_never_share_a_context():
-    """ConstellationMPC runs its node-count groups concurrently on separate contexts; a context is not thread-safe
-    (include/mpcx.h), so with more jobs than slots (17 here, 8 slots) no two calls in flight may hold the same slot."""
+def test_sharded_call_blocks_contexts_and_join():
+    """The multi-device path of the drop-in API (ConstellationMPC / mpc_step_batch / mpc_update_batch with devices=[...]):
+    contiguous blocks in device order, one context (device, slot) per entry of the device list -- a device named twice gets
+    two slots --, no two calls in flight on one context (a context is not thread-safe, include/mpcx.h), the calls really
+    concurrent, the blocks' results joined along the satellite axis (axis 1 for an update's per-iteration records)."""
     import threading
     import time
-    from mpconstellation_amd import constellation_mpc as cm
-    lock = threading.Lock(); busy = set(); seen = []; clashes = []
+    from mpconstellation_amd.sharding import device_contexts, sharded_call, join_results, shard_block
+    assert device_contexts([0, 1, 0, 0, 1]) == [(0, 0), (1, 0), (0, 1), (0, 2), (1, 1)]
+    lock = threading.Lock(); busy = set(); clashes = []; peak = [0]
 
-    def fake_call(i, device=0, slot=0):
-        with lock:
-            if slot in busy: clashes.append((i, slot))
-            busy.add(slot); seen.append(slot)
-        time.sleep(0.01 * (1 + i % 3))
-        with lock:
-            busy.discard(slot)
-        return i
+    class Res:
+        pass
 
-    out = cm._concurrently(fake_call, [(i,) for i in range(17)], 0)
-    assert out == list(range(17))                            # results in job order
-    assert not clashes
-    assert set(seen) <= set(range(1, cm.MAX_SLOTS + 1)) and len(set(seen)) > 1
-    assert cm._concurrently(fake_call, [(5,)], 0) == [5]     # a single job runs on the caller's own context (slot 0)
+    def fake_call(x, k, scale, device=0, slot=0):
+        with lock:
+            if (device, slot) in busy: clashes.append((device, slot))
+            busy.add((device, slot)); peak[0] = max(peak[0], len(busy))
+        time.sleep(0.05)
+        with lock:
+            busy.discard((device, slot))
+        r = Res(); r.X = x * scale; r.Ks = np.full(x.shape[0], 7 if k is None else k[0]); r.g_tf = None
+        r.status = np.full((2, x.shape[0]), 10 * device + slot, dtype=np.int32); r.where = (device, slot)
+        return r
+
+    x = np.arange(11 * 3, dtype=np.float64).reshape(11, 3)
+    parts = sharded_call(fake_call, [0, 0, 1], [x, None], 2.0)
+    assert not clashes and peak[0] == 3                        # three contexts, all in flight together
+    assert [p.where for p in parts] == [(0, 0), (0, 1), (1, 0)]
+    assert [p.X.shape[0] for p in parts] == [shard_block(11, 3, r)[1] for r in range(3)] == [4, 4, 3]
+    j = join_results(parts)
+    assert np.array_equal(j.X, 2.0 * x) and j.g_tf is None and j.Ks.shape == (11,)
+    assert j.status.shape == (2, 11) and j.status[0].tolist() == [0] * 4 + [1] * 4 + [10] * 3
+    # more devices than satellites: the empty blocks are skipped; a single block runs on the caller's thread
+    parts = sharded_call(fake_call, [0, 1, 2, 3], [x[:2], np.array([5, 6])], 1.0)
+    assert [p.where for p in parts] == [(0, 0), (1, 0)] and join_results(parts).Ks.tolist() == [5, 6]
 
 
 def test_foreign_thrust_laws_and_unknown_options_are_rejected():
@@ -225,7 +239,7 @@ def test_shared_tf_root_reports_a_missing_bracket():
 def test_ragged_foh_resampling_matches_the_scalar_reference_formula():
     """ConstellationMPC's extract_uk for a whole ragged batch (foh_resample_ragged) against SequenceController.u_FOH
     (control.py:104-126, Python float floor division), satellite by satellite, bit for bit."""
-    from mpconstellation_amd.constellation_mpc import foh_resample_ragged, foh_resample
+    from foh_reference import foh_resample_ragged
     from mpconstellation_amd.control import SequenceController
     rng = np.random.default_rng(0)
     S, Kmax = 40, 37
@@ -237,4 +251,3 @@ def test_ragged_foh_resampling_matches_the_scalar_reference_formula():
         f = SequenceController(u=u[s][:, :Ku[s]], tf_u=1.3, tf_sim=1.3).get_u_func()
         ref = np.column_stack([f(None, tq) for tq in np.linspace(0, 1, n[s])])
         assert np.array_equal(ref, out[s][:, :n[s]]) and not out[s][:, n[s]:].any()
-    assert np.array_equal(foh_resample(u, 29), foh_resample_ragged(u, np.full(S, Kmax), np.full(S, 29)))

@@ -175,9 +175,10 @@ def test_constellation_mpc_equals_single_satellite_loops():
     """the MPC loop for several satellites at once (per-satellite scales, batched planning
     and flying) gives every satellite what the reference's structure -- one OptimalController + one Simulator per
     satellite (control.py:162, simulator.py:58-60) -- gives it.  OptimalController.update is the one-satellite case of
-    ConstellationMPC.update, so this checks the batching itself (grouping by node count, concurrent contexts, result
-    scatter): a satellite's plan and flown trajectory do not depend on who shares its batch, bit for bit.  (Against
-    the CPU oracle: test_constellation_mpc_plan_vs_oracle_chain, test_scp_update_vs_oracle_chain.)"""
+    ConstellationMPC.update, so this checks the batching itself (ragged launches, the segment flight riding in the update's
+    call against the Simulator's own rollout of the sequence controller): a satellite's plan and flown trajectory do not
+    depend on who shares its batch, bit for bit.  (Against the CPU oracle: test_constellation_mpc_plan_vs_oracle_chain,
+    test_scp_update_vs_oracle_chain.)"""
     from mpconstellation_amd import Satellite, SatelliteScale, Simulator, OptimalController, ConstellationMPC
     r0 = np.array([5371.4806, -4133.1393, 1399.9594]) * 1000; v0 = np.array([4.6921, 4.9848, -3.2752]) * 1000
     make = lambda: [Satellite(r0, v0 * (1 + 0.01 * i), 12200.0) for i in range(3)]
@@ -244,3 +245,71 @@ def test_fused_scp_iteration_equals_its_three_calls():
     two = scp_iteration_batch(y0, ref.tf, consts, r_des, law2, int(Kn.max()), Ks=Kn, Kus=np.full(S, K))
     assert two.xbar is None and (two.prop_status == 0).all() and (two.status == 0).all()
     for f in ("X", "U", "NU", "tf", "status", "iters", "kkt"): assert np.array_equal(getattr(two, f), getattr(ref2, f)), f
+
+
+def test_update_in_one_call_equals_one_call_per_iteration():
+    """mpcx_mpc_update_batch -- OptimalController.update (control.py:170-235) as ONE library call, node counts
+    int(base_res * tf_u) computed on the device, the plan's thrust consumed in place, the segment flight riding along --
+    against the same update as one call per SCP iteration with the plan crossing PCIe in between (the verbose path, which
+    prints control.py:208-209's lines) and the flight as its own call: bit for bit, plans, statuses, flown trajectories."""
+    import contextlib, io
+    from mpconstellation_amd import Satellite, ConstellationMPC
+    from mpconstellation_amd.constellation import constellation_states
+    st = constellation_states(4096)[[3, 500, 1234, 2222, 4000]]
+    make = lambda: [Satellite(s[:3].copy(), s[3:6].copy(), float(s[6])) for s in st]
+    kw = dict(base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=50)
+    a = ConstellationMPC(make(), **kw)
+    b = ConstellationMPC(make(), verbose=True, **kw)
+    for seg in range(2):
+        a.run_segment(1)
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            b.run_segment(1)
+        assert out.getvalue().count("tf for optimizer") == 2 * 5
+        assert (a.last_status == 0).all() and np.array_equal(a.last_status, b.last_status)
+        assert np.array_equal(a.plan_K, b.plan_K) and np.array_equal(a.plan_tf, b.plan_tf)
+        assert len(set(a.plan_K.tolist())) > 1                               # really a ragged second iteration
+        for i in range(5):
+            assert np.array_equal(a.plan_x[i], b.plan_x[i]) and np.array_equal(a.plan_u[i], b.plan_u[i]) and np.array_equal(a.plan_nu[i], b.plan_nu[i])
+            assert a.plan_x[i].shape == (7, a.plan_K[i])
+        # rows of length K, zeros behind a satellite's last node
+        X = a._plan[0]
+        assert X.shape[2] == int(30 * (2 - seg)) and all((X[i, :, a.plan_K[i]:] == 0).all() for i in range(5))
+    for sa, sb in zip(a.sats, b.sats):
+        assert np.array_equal(a.sim_data[sa.id], b.sim_data[sb.id]) and np.array_equal(sa.get_state_vector(), sb.get_state_vector())
+    assert a.sim_data[a.sats[0].id].shape == (7, 100) and a.horizon == 1.0
+    assert a.sim_time[a.sats[0].id] is not a.sim_time[a.sats[1].id]           # an array per id, as the reference keeps them
+
+
+def test_several_devices_from_the_api():
+    """devices=[...] on the drop-in API (north star: satellites shard across the GPUs of a node behind the reference's API; the
+    reference loops over its constellation serially, simulator.py:41,58): contiguous blocks, one host thread and one context
+    per entry of the device list, results joined.  Rehearsed on this one-GPU box with devices=[0, 0] and [0, 0, 0] -- separate
+    contexts and streams on the same device, calls in flight together -- against the single-device call, bit for bit
+    (2 x 4096 satellites: each block on the one-wave kernel; an uneven split of 2051: blocks on the two-wave kernel against a
+    whole on the one-wave kernel); and the closed loop with the constellation dealt out to three contexts."""
+    from mpconstellation_amd import Satellite, ConstellationMPC, mpc_step_batch, mpc_update_batch, propagate_batch, _ffi
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch
+    from test_full_size_gpu import workload
+    for S, devs in ((8192, [0, 0]), (2051, [0, 0, 0])):
+        xbar, ubar, consts, r_des = workload(8192, 30, first=0, count=S)
+        tf = np.ones(S)
+        one = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+        many = mpc_step_batch(xbar, ubar, tf, consts, r_des, devices=devs)
+        assert (many.status == 0).all()
+        for f in ("X", "U", "NU", "tf", "status", "iters", "kkt"): assert np.array_equal(getattr(one, f), getattr(many, f)), (S, f)
+    # the closed loop: update + flight for 7 satellites on three contexts (blocks of 3, 2, 2)
+    st = constellation_states(4096)[[1, 100, 900, 1500, 2500, 3100, 4090]]
+    make = lambda: [Satellite(s[:3].copy(), s[3:6].copy(), float(s[6])) for s in st]
+    kw = dict(base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=40)
+    a = ConstellationMPC(make(), **kw); b = ConstellationMPC(make(), devices=[0, 0, 0], **kw)
+    a.run_segments(tf=2, num_segments=2); b.run_segments(tf=2, num_segments=2)
+    assert (b.last_status == 0).all() and b.last_status.shape == (2, 7) and np.array_equal(a.last_status, b.last_status)
+    for i, (sa, sb) in enumerate(zip(a.sats, b.sats)):
+        assert np.array_equal(a.plan_x[i], b.plan_x[i]) and np.array_equal(a.sim_data[sa.id], b.sim_data[sb.id])
+    # ragged rollouts through several contexts: rows padded to the longest satellite of the whole batch
+    y0, consts = normalize_batch(st)
+    n = np.array([30, 12, 25, 30, 7, 19, 28])
+    law = (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None)
+    y1 = propagate_batch(y0, 1.0, consts, law, n, thrust=True)
+    y3 = propagate_batch(y0, 1.0, consts, law, n, thrust=True, devices=[0, 0, 0])
+    for p, q in zip(y1, y3): assert np.array_equal(p, q)

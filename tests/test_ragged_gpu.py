@@ -53,6 +53,9 @@ def test_ragged_node_counts_out_of_range(golden_dir):
         res = mpc_step_batch(x, u, tf, cst, r_des, Ks=k2)
         assert res.status[1] == 9 and (np.delete(res.status, 1) == 0).all()
         assert np.array_equal(np.delete(res.X, 1, axis=0), np.delete(ref.X, 1, axis=0))
+        # the rejected satellite's rows are defined all the same: the reference handed back, no virtual control, tf_bar
+        assert np.array_equal(res.X[1], x[1]) and np.array_equal(res.U[1], u[1]) and not res.NU[1].any() and res.tf[1] == tf[1]
+        assert res.iters[1] == 0 and res.kkt[1] == 0.0
 
 
 def test_ragged_propagation_equals_rectangular_calls(golden_dir):

@@ -262,3 +262,49 @@ def test_page_locked_arrays_give_the_same_result(golden_dir):
     keep = b.X.copy()
     c = mpc_step_batch(px, pu, pt, pc, pr, pinned_results=True)
     assert c.X is b.X and np.array_equal(c.X, keep)
+
+
+def test_two_solves_of_one_context_on_two_streams():
+    """include/mpcx.h, MPCX_SOLVE_INDEX_ORDER: with the plain launch order a context keeps no state between solves, and two
+    _dev calls of ONE context may be in flight on different streams -- every launch has its own work-queue counter (a
+    shared one would hand each queue position to only one of the two kernels and leave satellites unsolved).  Two fused
+    steps of 4096 satellites enqueued back to back on two streams against the same steps run one after the other."""
+    import ctypes as C
+    import torch
+    from mpconstellation_amd import _ffi
+    from test_full_size_gpu import workload
+    lib = _ffi.load(); ctx = _ffi.context(0)
+    S, K = 4096, 30
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    sets = []
+    for first in (0, 4096):
+        xbar, ubar, consts, r_des = workload(8192, K, first=first, count=S)
+        sets.append(dict(x=T(xbar), u=T(ubar), tf=T(np.ones(S)), c=T(consts), rd=T(r_des)))
+    opts = _ffi.make_solve_opts({}, flags=_ffi.SOLVE_INDEX_ORDER)
+    nws = lib.mpcx_mpc_step_workspace_bytes_ctx(ctx, S, K) // 8 + 8
+    assert nws * 8 <= lib.mpcx_mpc_step_workspace_bytes(S, K) + 64                      # (the ctx-aware query: slots, not satellites)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def run(streams):
+        outs = []
+        for d, st in zip(sets, streams):
+            o = dict(X=torch.empty((S, 7, K), dtype=torch.float64, device=dev), U=torch.empty((S, 3, K), dtype=torch.float64, device=dev),
+                     NU=torch.empty((S, 7, K), dtype=torch.float64, device=dev), tf=torch.empty(S, dtype=torch.float64, device=dev),
+                     kkt=torch.empty(S, dtype=torch.float64, device=dev), st=torch.full((S,), -1, dtype=torch.int32, device=dev),
+                     it=torch.empty(S, dtype=torch.int32, device=dev), ws=torch.empty(nws, dtype=torch.float64, device=dev))
+            outs.append(o)
+        torch.cuda.synchronize()
+        for d, o, st in zip(sets, outs, streams):
+            _ffi.check(lib.mpcx_mpc_step_batch_dev(ctx, S, K, p(d["x"]), p(d["u"]), p(d["tf"]), p(d["c"]), p(d["rd"]), 0, 1e-2, C.byref(opts),
+                                                   p(o["X"]), p(o["U"]), p(o["NU"]), p(o["tf"]), p(o["st"]), p(o["it"]), p(o["kkt"]), p(o["ws"]),
+                                                   C.c_void_p(st.cuda_stream)), ctx, "mpc_step_dev")
+        torch.cuda.synchronize()
+        return [{k: v.cpu().numpy() for k, v in o.items() if k != "ws"} for o in outs]
+    s0 = torch.cuda.current_stream()
+    serial = run([s0, s0])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    overlapped = run([s1, s2])
+    for a, b in zip(serial, overlapped):
+        assert (b["st"] == 0).all()
+        for k in a: assert np.array_equal(a[k], b[k]), k
