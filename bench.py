@@ -167,12 +167,12 @@ def measure(runner, steps, warmup, world):
     return elapsed, solve_ms
 
 
-def measured_traffic(workload, kernel="solve_kernel"):
-    """HBM bytes per launch from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/rNN/
-    pmc_traffic.json) -- a counter measurement of an earlier run on another box, echoed here; it is reported only when
-    the kernel sources are byte for byte the ones that were profiled (the profile records their hashes), with its origin."""
+def _committed_counters(fname, workload, kernel):
+    """One kernel's entry of the newest committed counter summary profiles/rNN/<fname> that holds the workload -- a counter
+    measurement of an earlier run on another box, echoed here; it is reported only when the kernel sources are byte for byte
+    the ones that were profiled (the profile records their hashes) and the build flags the same, with its origin."""
     import hashlib
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", fname)), reverse=True):
         prof = json.load(open(f))
         ks = prof.get("workloads", {}).get(workload, {})
         w = ks.get(kernel) or ks.get(kernel + "2w")          # (batches of up to 1024 run on the two-wave build's kernel)
@@ -182,17 +182,37 @@ def measured_traffic(workload, kernel="solve_kernel"):
         if not want:
             return None, f"{src}: no source hashes recorded (profile of an earlier round), not reported"
         for name, h in want.items():
-            if hashlib.sha256(open(os.path.join(ROOT, "mpconstellation_amd", "csrc", name), "rb").read()).hexdigest() != h:
+            path = os.path.join(ROOT, "mpconstellation_amd", "csrc", name)
+            if not os.path.exists(path) or hashlib.sha256(open(path, "rb").read()).hexdigest() != h:
                 return None, f"{src}: {name} changed since it was profiled, not reported"
-        return w["hbm_bytes_per_launch"], f"{src} (same kernel sources, counters of that profiling run)"
+        if prof.get("build_flags"):
+            from mpconstellation_amd import build as _b
+            if prof["build_flags"] != " ".join(_b.FLAGS):
+                return None, f"{src}: build flags changed since it was profiled, not reported"
+        return w, f"{src} (same kernel sources, counters of that profiling run)"
     return None, "no committed profile holds this workload"
+
+
+def measured_traffic(workload, kernel="solve_kernel"):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/rNN/pmc_traffic.json)"""
+    w, src = _committed_counters("pmc_traffic.json", workload, kernel)
+    return (w["hbm_bytes_per_launch"] if w else None), src
+
+
+def measured_fp64_flop(workload, kernel="solve_kernel"):
+    """fp64 operations one launch EXECUTES, 64 lanes per wave instruction, from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64
+    passes (profiles/rNN/pmc_sq.json: 64 x (2 FMA + MUL + ADD)); idle lanes of a wave instruction count as executed"""
+    w, src = _committed_counters("pmc_sq.json", workload, kernel)
+    return (w.get("fp64_flop_64lanes") if w else None), src
 
 
 def roofline(workload, S, K, solve_ms, iters):
     B = algorithmic_bytes(K)
     achieved = S * B / (solve_ms * 1e-3) / 1e9           # dominant kernel: solve_kernel, one launch = S satellites
-    flops = FLOP_PER_NODE_ITER * K * float(iters.sum())   # of the last solve_kernel launch on this rank
+    useful = FLOP_PER_NODE_ITER * K * float(iters.sum())  # of the last solve_kernel launch on this rank
     traffic, traffic_source = measured_traffic(workload)
+    executed, flop_source = measured_fp64_flop(workload)
+    tf = lambda fl: None if fl is None else fl / (solve_ms * 1e-3) / 1e12
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": "mpcx::solve_kernel", "kernel_ms": solve_ms,
             "algorithmic_bytes_per_satellite": B,
@@ -200,10 +220,13 @@ def roofline(workload, S, K, solve_ms, iters):
                     "launch; duration = HIP events around solve_kernel on its launch stream; traffic = FETCH_SIZE+WRITE_SIZE of "
                     "profiles/ (workspace traffic: the kernel is bound by the latency / issue rate of one wave per satellite, not by "
                     "its algorithmic HBM bytes)",
-            # what actually limits the kernel: fp64 vector arithmetic of ~18 kflop per node and interior-point
-            # iteration against the 78.6 TFLOP/s fp64 vector peak
-            "valu_f64": {"achieved": flops / (solve_ms * 1e-3) / 1e12, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (solve_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS}}
+            # what actually limits the kernel: fp64 vector arithmetic against the 78.6 TFLOP/s fp64 vector peak.  `achieved` =
+            # the operations the launch EXECUTES by the committed SQ counters (64 lanes per wave instruction) / this run's kernel
+            # time; `useful` = the ~18 kflop per node and interior-point iteration of the algorithm
+            "valu_f64": {"achieved": tf(executed), "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if executed is None else tf(executed) / F64_VALU_PEAK_TFLOPS, "source": flop_source,
+                         "useful": {"achieved": tf(useful), "frac": tf(useful) / F64_VALU_PEAK_TFLOPS,
+                                    "note": "18 kflop per node and iteration x the iterations of the last launch"}}}
 
 
 def host_pointer_rate(h, S, local_rank, reps=20):
@@ -420,8 +443,9 @@ def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n, dev_res=None):
     import oracle_lib as O
     O.build()                                             # the C half, once, before the workers load it
     n = min(n, xbar.shape[0])
-    # one single-threaded worker per host core of this GPU's share of the box (16 of the node's cores per GPU on the
-    # benchmark pool; MPCX_CPU_WORKERS overrides), never more than the process may run on
+    # one single-threaded worker per host core of this GPU's share of the box: the benchmark pool gives a one-GPU job 16 of
+    # the node's cores (its rule for worker pools; nproc is reported beside it, MPCX_CPU_WORKERS overrides), never more than
+    # the process may run on
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MPCX_CPU_WORKERS", "16")))
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[var] = "1"                            # inherited by the spawned workers: no BLAS thread pools inside them
@@ -438,7 +462,14 @@ def cpu_baseline(xbar, ubar, tfbar, consts, r_des, n, dev_res=None):
             if r[0] == 0 and dev_res[3][i] == 0:
                 ex.append(np.abs(dev_res[0][i] - r[1]).max()); eu.append(np.abs(dev_res[1][i] - r[2]).max())
                 et.append(abs(dev_res[2][i] - r[3]))
-    base = {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": cores, "kind": "port",
+    ref_timing = None
+    rt = os.path.join(ROOT, "tests", "golden", "reference_cpu_timing.json")
+    if os.path.exists(rt):
+        j = json.load(open(rt))
+        ref_timing = {"where": "build container, not this box (the reference cannot travel; tests/golden/time_reference.py)",
+                      "host": j.get("host"), "nproc": j.get("nproc"), "seconds_per_satellite": j.get("results"),
+                      "what": j.get("what"), "not_timed": j.get("not_timed")}
+    base = {"value": n / dt, "unit": "satellite-MPC-steps/s", "cores": cores, "kind": "port", "reference_discretize": ref_timing,
             "sample": f"first {n} satellites of the workload, oracle/ (C discretize + numpy IPM), one single-threaded worker process "
                       f"per host core of this GPU's share ({cores} of nproc = {os.cpu_count()}), {ok}/{n} converged, "
                       f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds"}

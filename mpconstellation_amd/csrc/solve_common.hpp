@@ -1,0 +1,24 @@
+// solve_common.hpp -- the includes and the two-build switch shared by solve.hip and solve2w.hip
+#pragma once
+#include <cstddef>
+#include <hip/hip_runtime.h>
+#include "mpcx_device.hpp"
+#include "solve_layout.hpp"
+
+// Compiled twice: by solve.hip as it stands (namespace mpcx, solve_kernel: one wave per satellite, every barrier of a phase
+// function is that wave's) and by solve2w.hip with MPCX_TWO_WAVE defined (namespace mpcx2w: the small-batch kernel whose
+// workgroups have a second wave that shares the factorisation, riccati_factor2).  In the two-wave build the phase functions
+// still run on the first wave alone, so their "workgroup barriers" must not be hardware barriers (the second wave never
+// executes them): WG_SYNC() is then the memory fence only, and the real two-wave barriers are spelled WG_BARRIER().
+#ifdef MPCX_TWO_WAVE
+#define MPCX_NS mpcx2w
+#define WG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define MPCX_NS mpcx
+#define WG_SYNC() __syncthreads()
+#endif
+#define WG_BARRIER() __syncthreads()
+
+#include "solve_phases.hpp"
+#include "solve_riccati.hpp"
+#include "solve_driver.hpp"

@@ -383,7 +383,7 @@ class Optimizer:
     def __init__(self, x_bar, u_bar, nu_bar, tf, d, f, scale, verbose=True, shared_tf=None):
         """Same arguments as the reference (optimizer.py:13-39).  With more than one satellite the
         reference couples all of them through a single tf variable (:287): that is the default here too
-        (solve_shared_tf: batched device solves at fixed tf inside a scalar root search on the host);
+        (solve_shared_tf: the whole NLP as ONE cooperative device launch, MPCX_SOLVE_SHARED_TF);
         pass shared_tf=False to solve the satellites as independent problems (own tf each, one device call)."""
         self.x_bar, self.u_bar, self.nu_bar = x_bar, u_bar, nu_bar
         self.tf, self.d, self.f, self.scale = tf, d, f, scale
@@ -402,43 +402,54 @@ class Optimizer:
         return {**DEFAULT_OPTIONS, **options}
 
     def get_constraint_terms(self):
-        """Host-side mirror of optimizer.py:80-170 (same keys, same per-satellite lists), including the
-        expression forms of :121-125 as written.  The device recomputes these terms inside the solve."""
-        keys = ['rbar_hat', 'ubar_hat', 'rf_hat', 'Vc', 'DrVc', 'DrVc_rbar', 'Vt', 'DrVt_DvVt', 'DrVt_DvVt_bar',
-                'Vr', 'DrVr_DvVr', 'DrVr_DvVr_bar', 'Vn', 'DrVn_DvVn', 'DrVn_DvVn_bar']
-        out = {k: [] for k in keys}
-        I = np.eye(3)
-        for i in range(self._N):
-            r = self.x_bar[i][0:3, -1]; v = self.x_bar[i][3:6, -1]
-            rv = np.concatenate([r, v])
-            rn = np.linalg.norm(r); h = np.cross(r, v); hn = np.linalg.norm(h)
-            r_hat = r / rn; h_hat = h / hn; t_hat = np.cross(h_hat, r_hat)
-            Dr_h = ((hn ** -1 * I) - (hn ** -3 * np.outer(h, h))) @ (-self.skew(v))
-            Dv_h = (hn ** -1 * I) - (hn ** -3 * np.outer(h, h)) @ (self.skew(r))
-            Dr_r = (rn ** -1 * I) - (rn ** -3 * np.outer(r, r))
-            Dr_t = (-self.skew(r_hat) @ Dr_h) + (self.skew(h_hat) @ Dr_r)
-            Dv_t = -self.skew(r_hat) @ Dv_h
-            rb = self.x_bar[i][0:3, :-1]
+        """The dictionary of optimizer.py:80-170 (same keys, one list entry per satellite), computed for all satellites at once
+        as array expressions on the stacked terminal states -- the Jacobians of the unit vectors r_hat, h_hat, t_hat as (N,3,3)
+        stacks, incl. the expression form of Dv_h_hat as the reference evaluates it (:122: only h h^T / |h|^3 is multiplied by
+        skew(r)).  Checked against dictionaries the reference itself produced (tests/golden ct_*, 1e-13).  The solver does not
+        read this dictionary: the device builds the same terms (mpcx_constraint_terms, constraint_terms_batch above)."""
+        N = self._N
+        xK = np.stack([np.asarray(x, dtype=np.float64)[0:6, -1] for x in self.x_bar])                # (N,6) terminal r, v
+        r, v = xK[:, 0:3], xK[:, 3:6]
+        eye = np.eye(3)[None]
+
+        def cross_matrix(a):                      # (N,3) -> (N,3,3), cross_matrix(a) @ b = a x b
+            z = np.zeros(len(a))
+            return np.stack([np.stack([z, -a[:, 2], a[:, 1]], -1), np.stack([a[:, 2], z, -a[:, 0]], -1),
+                             np.stack([-a[:, 1], a[:, 0], z], -1)], -2)
+        unit_jac = lambda a, n: eye / n[:, None, None] - a[:, :, None] * a[:, None, :] / n[:, None, None] ** 3      # d(a/|a|)/da
+        rn = np.linalg.norm(r, axis=1); h = np.cross(r, v); hn = np.linalg.norm(h, axis=1)
+        r_hat = r / rn[:, None]; h_hat = h / hn[:, None]; t_hat = np.cross(h_hat, r_hat)
+        hh = h[:, :, None] * h[:, None, :] / hn[:, None, None] ** 3
+        Dr_h = unit_jac(h, hn) @ (-cross_matrix(v))
+        Dv_h = eye / hn[:, None, None] - hh @ cross_matrix(r)                                        # (as written, :122)
+        Dr_r = unit_jac(r, rn)
+        Dr_t = -cross_matrix(r_hat) @ Dr_h + cross_matrix(h_hat) @ Dr_r
+        Dv_t = -cross_matrix(r_hat) @ Dv_h
+        left = lambda M: np.einsum("ni,nij->nj", v, M)                                               # v^T M per satellite
+        grads = {"t": np.concatenate([left(Dr_t), t_hat + left(Dv_t)], axis=1),
+                 "r": np.concatenate([left(Dr_r), r_hat], axis=1),
+                 "n": np.concatenate([left(Dr_h), h_hat + left(Dv_h)], axis=1)}
+        mu = self.const.MU
+        DrVc = (-0.5 * mu ** 0.5) * rn[:, None] ** (-5 / 2) * r
+        per_sat = {'rf_hat': r_hat, 'Vc': np.sqrt(mu / rn), 'DrVc': DrVc, 'DrVc_rbar': np.einsum("ni,ni->n", DrVc, r),
+                   'Vt': np.einsum("ni,ni->n", v, t_hat), 'DrVt_DvVt': grads["t"], 'DrVt_DvVt_bar': np.einsum("ni,ni->n", grads["t"], xK),
+                   'Vr': np.einsum("ni,ni->n", v, r_hat), 'DrVr_DvVr': grads["r"], 'DrVr_DvVr_bar': np.einsum("ni,ni->n", grads["r"], xK),
+                   'Vn': np.einsum("ni,ni->n", v, h_hat), 'DrVn_DvVn': grads["n"], 'DrVn_DvVn_bar': np.einsum("ni,ni->n", grads["n"], xK)}
+        out = {k: [a[i] for i in range(N)] for k, a in per_sat.items()}
+        # per-node unit vectors of the reference trajectory / thrust (:129-138; the mask of ubar_hat as the reference has it:
+        # columns with |u| <= eps are the ones divided, the others stay zero)
+        out['rbar_hat'] = []; out['ubar_hat'] = []
+        for x, u in zip(self.x_bar, self.u_bar):
+            rb = np.asarray(x, dtype=np.float64)[0:3, :-1]
             out['rbar_hat'].append(rb / np.linalg.norm(rb, axis=0))
-            ub = self.u_bar[i]; un = np.linalg.norm(ub, axis=0)
-            uh = np.zeros(ub.shape); m = un <= np.finfo(float).eps
+            ub = np.asarray(u, dtype=np.float64); un = np.linalg.norm(ub, axis=0)
+            uh = np.zeros(ub.shape); tiny = un <= np.finfo(float).eps
             with np.errstate(all='ignore'):
-                uh[:, m] = ub[:, m] / un[m]
+                uh[:, tiny] = ub[:, tiny] / un[tiny]
             out['ubar_hat'].append(uh)
-            out['rf_hat'].append(r_hat)
-            out['Vc'].append(np.sqrt(self.const.MU / rn))
-            DrVc = (-1 / 2) * (self.const.MU ** 0.5) * (rn ** (-5 / 2)) * r
-            out['DrVc'].append(DrVc); out['DrVc_rbar'].append(np.dot(DrVc, r))
-            out['Vt'].append(np.dot(v, t_hat))
-            g = np.concatenate([np.dot(v, Dr_t), np.dot(t_hat, I) + np.dot(v, Dv_t)])
-            out['DrVt_DvVt'].append(g); out['DrVt_DvVt_bar'].append(np.dot(g, rv))
-            out['Vr'].append(np.dot(v, r_hat))
-            g = np.concatenate([np.dot(v, Dr_r), np.dot(r_hat, I)])
-            out['DrVr_DvVr'].append(g); out['DrVr_DvVr_bar'].append(np.dot(g, rv))
-            out['Vn'].append(np.dot(v, h_hat))
-            g = np.concatenate([np.dot(v, Dr_h), np.dot(h_hat, I) + np.dot(v, Dv_h)])
-            out['DrVn_DvVn'].append(g); out['DrVn_DvVn_bar'].append(np.dot(g, rv))
-        return out
+        keys = ['rbar_hat', 'ubar_hat', 'rf_hat', 'Vc', 'DrVc', 'DrVc_rbar', 'Vt', 'DrVt_DvVt', 'DrVt_DvVt_bar',
+                'Vr', 'DrVr_DvVr', 'DrVr_DvVr_bar', 'Vn', 'DrVn_DvVn', 'DrVn_DvVn_bar']                # (the reference's key order)
+        return {k: out[k] for k in keys}
 
     def solve_OPT(self, input_options={}, **solver):
         """Transcribe-and-solve replacement (optimizer.py:219-613).  Extra keyword arguments are solver
@@ -482,19 +493,3 @@ class Optimizer:
 
     def get_solved_nu(self, s):
         return self.result.NU[s].copy()
-
-    @staticmethod
-    def plot_normalized_thrust(x, u):
-        """Thrust in the RTN frame (optimizer.py:47-77); needs matplotlib."""
-        import matplotlib.pyplot as plt
-        u_rtn = np.zeros(u.shape)
-        for i in range(u.shape[1]):
-            r = x[0:3, i]; v = x[3:6, i]
-            r_hat = r / np.linalg.norm(r); h = np.cross(r, v); h_hat = h / np.linalg.norm(h)
-            R = np.vstack([r_hat, np.cross(h_hat, r_hat), h_hat])
-            u_rtn[:, i] = R @ u[:, i]
-        fig, ax = plt.subplots()
-        t = np.linspace(0, 1, u.shape[1])
-        for row, lab in zip(u_rtn, "rtn"):
-            ax.plot(t, row, label=lab)
-        ax.set_title('Normalized Thrust Commands'); plt.legend(); plt.show()

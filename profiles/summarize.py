@@ -47,11 +47,23 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
             short = k.split("::")[-1]
             f_kb, w_kb = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
             traffic["workloads"][w][short] = {"fetch_KB": f_kb, "write_KB": w_kb, "hbm_bytes_per_launch": (f_kb + w_kb) * 1024.0}
+import hashlib
+# the kernel sources these counters belong to: bench.py reports them only for exactly this code (the C entry points --
+# solve_api.hip, api.hip, mpcx_host.hpp -- are not kernel sources: editing them leaves the profiles valid)
+KERNEL_SOURCES = ("solve.hip", "solve2w.hip", "solve_common.hpp", "solve_layout.hpp", "solve_phases.hpp", "solve_riccati.hpp",
+                  "solve_driver.hpp", "discretize.hip", "mpcx_device.hpp")
+source_hashes = {f: hashlib.sha256(open(os.path.join(root, "..", "mpconstellation_amd", "csrc", f), "rb").read()).hexdigest()
+                 for f in KERNEL_SOURCES}
+build_flags = None
+try:
+    sys.path.insert(0, os.path.join(root, ".."))
+    from mpconstellation_amd import build as _b
+    build_flags = " ".join(_b.FLAGS)
+except Exception:
+    pass
 if traffic["workloads"]:
-    import hashlib
-    # the kernel sources these counters belong to: bench.py reports the traffic only for exactly this code
-    traffic["kernel_source_sha256"] = {f: hashlib.sha256(open(os.path.join(root, "..", "mpconstellation_amd", "csrc", f), "rb").read()).hexdigest()
-                                       for f in ("solve.hip", "discretize.hip", "mpcx_device.hpp")}
+    traffic["kernel_source_sha256"] = source_hashes
+    traffic["build_flags"] = build_flags
     traffic["round"] = rnd
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
@@ -78,6 +90,9 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
                 v["fp64_flop_64lanes"] = 64.0 * (2 * v["SQ_INSTS_VALU_FMA_F64"] + v.get("SQ_INSTS_VALU_MUL_F64", 0) + v.get("SQ_INSTS_VALU_ADD_F64", 0))
         sq["workloads"][w] = keep
 if sq["workloads"]:
+    sq["kernel_source_sha256"] = source_hashes
+    sq["build_flags"] = build_flags
+    sq["round"] = rnd
     json.dump(sq, open(os.path.join(dst, "pmc_sq.json"), "w"), indent=1)
     print(json.dumps(sq["workloads"], indent=1))
 print(json.dumps(traffic["workloads"], indent=1))
