@@ -45,7 +45,8 @@ class ConstellationMPC:
         # (satellite_scale.py:46-100: r / r0, v / v0, m / m0 and back)
         self._f = np.array([[sc._r0, sc._v0, sc._m0] for sc in self.scales]).reshape(len(self.sats), 3)
         self._seg_y, self._seg_t, self._sim_cache = [], [], None       # flown segments (S,7,n) / (n,), and the dict view of them
-        self.last_status = None
+        self.last_status = None           # (scp_iterations, S): every solve's MPCX_ST_* code of the last update
+        self.last_iters = None            # ... and its interior-point iteration count
         self.plan_tf, self.plan_K = None, None
         self._plan = None                                               # (X, U, NU) of the last plan, rows of length Kmax
         self._plan_lists = None
@@ -125,7 +126,7 @@ class ConstellationMPC:
             res = self._timed("update", mpc_update_batch, y0, float(self.horizon), self.consts, self.r_des, self.base_res,
                               n_scp=self.scp_iterations, options=opts, device=self.device, fly=fly, devices=self.devices)
             self._check(res.prop_status)
-            self.last_status = res.status
+            self.last_status = res.status; self.last_iters = res.iters
             for it in range(self.scp_iterations):
                 _check_solver_status(res.status[it], self.strict)
             flown = (res.y_sim, res.sim_status) if fly is not None else None
@@ -143,13 +144,13 @@ class ConstellationMPC:
         tf_u = np.full(S, float(self.horizon))
         law = (_ffi.CTRL_TANGENTIAL, np.array([0.5]), 0, None)
         Ks = None; Kus = None                                              # first iteration: K nodes for everybody
-        self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32)
+        self.last_status = np.zeros((self.scp_iterations, S), dtype=np.int32); self.last_iters = np.zeros_like(self.last_status)
         res = None
         for it in range(self.scp_iterations):
             res = self._timed("update", scp_iteration_batch, y0, tf_u, self.consts, self.r_des, law, K, options=opts,
                               Ks=Ks, Kus=Kus, device=self.device)
             self._check(res.prop_status)
-            self.last_status[it] = res.status
+            self.last_status[it] = res.status; self.last_iters[it] = res.iters
             _check_solver_status(res.status, self.strict)
             for j in range(S):
                 print(f"tf for optimizer: {res.tf[j]}")
