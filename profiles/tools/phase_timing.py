@@ -5,7 +5,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from mpconstellation_amd import build as b
 lib = "/tmp/libmpcx_timing.so"
-subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DMPCX_PHASE_TIMING", "-o", lib] + b.sources())
+import glob
+srcs = sorted(glob.glob(os.path.join(os.environ["SRC"], "*.hip"))) if os.environ.get("SRC") else b.sources()      # (SRC: another source tree, for an A/B)
+subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DMPCX_PHASE_TIMING", "-o", lib] + srcs)
 from mpconstellation_amd import _ffi
 _ffi.LIB_PATH = lib
 from mpconstellation_amd import solve_batch
@@ -19,8 +21,9 @@ args = (rep(d["A"]), rep(d["Bp"]), rep(d["Bn"]), rep(d["Sigma"]), rep(d["xi"]), 
 import ast
 opts = ast.literal_eval(os.environ.get("OPTS", "{}"))          # e.g. OptimalController's set: OPTS='{"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}'
 if "r_des" in opts: args = args[:-1] + ([opts.pop("r_des")] * S,)
-r = solve_batch(*args, options=opts)
-t0 = time.perf_counter(); r = solve_batch(*args, options=opts); wall = time.perf_counter() - t0
+flags = int(os.environ.get("FLAGS", "0"))        # 16: the one-wave kernel for small batches too
+r = solve_batch(*args, options=opts, flags=flags)
+t0 = time.perf_counter(); r = solve_batch(*args, options=opts, flags=flags); wall = time.perf_counter() - t0
 print(f"S {S}: host-pointer solve_batch wall {wall*1e3:.3f} ms (copies of {S*30*17*8/1e6:.1f} MB results included)")
 names = ["eval_res(E0,Emu,r0)", "newton_blocks", "riccati_factor", "sweep_bwd 8ch", "sweep_fwd 8ch+border", "reduced_residual",
          "start-up (terms, transposition, start point)", "border_solve+comb fwd", "finish_direction", "apply_step", "line-search evals", "-"]
