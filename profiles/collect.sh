@@ -5,7 +5,7 @@
 #   3. two passes of 8 SQ counters each: instruction mix / fp64 operation counts, and wait / active cycles
 # Raw output goes to gpurun_out/prof/<round>/ ; profiles/summarize.py turns it into the committed summaries.
 set -e
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof/$ROUND
 mkdir -p "$OUT"
