@@ -175,7 +175,8 @@ def _committed_counters(fname, workload, kernel):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", fname)), reverse=True):
         prof = json.load(open(f))
         ks = prof.get("workloads", {}).get(workload, {})
-        w = ks.get(kernel) or ks.get(kernel + "2w")          # (batches of up to 1024 run on the two-wave build's kernel)
+        # (batches of up to 1024 run on the two-wave build's kernel, of up to one satellite per compute unit on the LDS-resident one)
+        w = ks.get(kernel) or ks.get(kernel + "_lds") or ks.get(kernel + "2w")
         if not w: continue
         src = os.path.relpath(f, ROOT)
         want = prof.get("kernel_source_sha256")

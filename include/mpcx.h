@@ -165,6 +165,11 @@ typedef struct {
  * satellite's result does not depend on the size of the batch it is solved in.  This flag keeps the one-wave kernel for
  * small batches too (measurements, tests). */
 #define MPCX_SOLVE_ONE_WAVE 16
+/* Batches of at most one satellite per compute unit (256 on an MI355X) whose horizon's working set fits (K <= 30) are solved
+ * with that working set -- iterate, direction, Newton and factor records, channel vectors: 134 KB at K = 30 -- held in the
+ * compute unit's LDS instead of the global workspace (same kernel otherwise, same bits).  This flag keeps them on the
+ * global-workspace kernel (measurements, tests). */
+#define MPCX_SOLVE_NO_LDS 32
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 /* Workspace of the _dev solves / fused steps.  The plain queries are device-independent upper bounds (one slot per

@@ -187,6 +187,45 @@ def pinned_copy(a, device=0):
     return out
 
 
+class _ResultPool:
+    """Result arrays of the batched wrappers, recycled.  A large numpy array is a fresh anonymous mapping: the first write to
+    each of its pages is a page fault, and for the 17 MB a 4096-satellite step returns those faults are 1.8 ms of a 8.8 ms call on
+    average and 3-5 ms now and then -- every call, because numpy unmaps the arrays of the previous results
+    when the caller drops them.  take() hands out an array of the pool when NOBODY else holds a reference to it any more (the
+    previous results have been dropped: reference count of the pooled object = the pool's own) and a new one otherwise, so a
+    caller that keeps its results keeps them untouched.  A few arrays per shape, a few shapes."""
+    PER_SHAPE, SHAPES = 3, 24
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._pool = {}          # (shape, dtype) -> [arrays]
+
+    def take(self, shape, dtype=np.float64):
+        import sys
+        key = (tuple(int(n) for n in shape), np.dtype(dtype).str)
+        nbytes = int(np.prod(key[0])) * np.dtype(dtype).itemsize
+        if nbytes < (1 << 20):                                   # small arrays come from malloc's own free lists: nothing to gain
+            return np.empty(shape, dtype=dtype)
+        with self._lock:
+            lst = self._pool.get(key)
+            if lst is None:
+                if len(self._pool) >= self.SHAPES:
+                    self._pool.pop(next(iter(self._pool)))
+                lst = self._pool[key] = []
+            else:
+                self._pool[key] = self._pool.pop(key)            # (most recently used last)
+            for i in range(len(lst)):
+                if sys.getrefcount(lst[i]) == 2:                 # the list's reference and getrefcount's argument: nobody else
+                    return lst[i]
+            a = np.empty(shape, dtype=dtype)
+            if len(lst) < self.PER_SHAPE:
+                lst.append(a)
+            return a
+
+
+result_pool = _ResultPool()
+
+
 def check(rc, ctx, what):
     if rc != 0:
         raise MpcxError(f"{what} failed ({rc}): {load().mpcx_last_error(ctx).decode()}")
@@ -205,7 +244,7 @@ def iptr(a):
 
 
 SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
-SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF = 1, 2, 4, 8          # mpcx_solve_opts.flags (include/mpcx.h)
+SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF, SOLVE_ONE_WAVE, SOLVE_NO_LDS = 1, 2, 4, 8, 16, 32      # mpcx_solve_opts.flags (include/mpcx.h)
 
 
 def check_solver_keywords(solver):

@@ -180,7 +180,14 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     // small batches -- at most one satellite per SIMD -- go to the two-wave build (solve2w.hip): a second wave per
     // satellite shares the factorisation; results are bit for bit the one-wave kernel's (-ffp-contract=on, build.py;
     // tests/test_full_size_gpu.py::test_two_wave_small_batch_kernel).  MPCX_SOLVE_ONE_WAVE keeps the one-wave kernel.
-    if (S <= kTwoWaveMax && !(opts->flags & MPCX_SOLVE_ONE_WAVE)) {
+    // at most one satellite per compute unit: the LDS-resident build (solve_lds.hip), if the horizon's working set fits
+    int lds = 1;
+    if (S <= ctx->n_slots / 8 && !(opts->flags & (MPCX_SOLVE_ONE_WAVE | MPCX_SOLVE_NO_LDS))) {
+        lds = mpcxl_launch(&a, sizeof a, slots, (hipStream_t)stream);
+        if (lds < 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: LDS-resident launch failed");
+    }
+    if (lds == 0) {
+    } else if (S <= kTwoWaveMax && !(opts->flags & MPCX_SOLVE_ONE_WAVE)) {
         if (mpcx2w_launch(&a, sizeof a, slots, (hipStream_t)stream) != 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: two-wave launch failed");
     } else
         mpcx_launch::solve(a, slots, (hipStream_t)stream);

@@ -11,7 +11,11 @@
 // still run on the first wave alone, so their "workgroup barriers" must not be hardware barriers (the second wave never
 // executes them): WG_SYNC() is then the memory fence only, and the real two-wave barriers are spelled WG_BARRIER().
 #ifdef MPCX_TWO_WAVE
+#ifdef MPCX_WS_LDS
+#define MPCX_NS mpcxl          // (solve_lds.hip: the two-wave kernel with its working set in LDS)
+#else
 #define MPCX_NS mpcx2w
+#endif
 #define WG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define MPCX_NS mpcx

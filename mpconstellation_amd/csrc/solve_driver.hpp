@@ -2,6 +2,10 @@
 // iteration that calls the phases of solve_phases.hpp and solve_riccati.hpp) and the kernels' LDS working set.
 #pragma once
 
+#ifdef MPCX_WS_LDS
+extern __shared__ double mpcx_ws_lds[];      // the workgroup's dynamic LDS: the satellite's working set (sat_view)
+#endif
+
 namespace MPCX_NS {
 #ifdef MPCX_PHASE_TIMING
 #define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, pt0_ = 0; unsigned pc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; \
@@ -28,6 +32,33 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     s.ubar = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
     const int KP = padded_nodes(K);
     s.KP = KP;
+#ifdef MPCX_WS_LDS
+    // LDS-resident build: iterate, candidate, direction, r-hat, Newton / factor / channel records and the globals are carved
+    // from the workgroup's dynamic LDS (lds_ws_doubles(K): 134 KB at K = 30); the stage copy, the Newton scalars and the channel
+    // trajectories keep their places in the slot's global workspace (whose layout is the other builds')
+    wf64 *wl = (wf64 *)mpcx_ws_lds;
+    s.ws = wl;
+    s.it = wl; wl += (size_t)KP * IT_N;
+    s.dr = wl; wl += (size_t)KP * IT_N;
+    s.itB = wl; wl += (size_t)KP * IT_N;
+    s.rbh = wl; wl += (size_t)KP * 3;
+    s.nb = wl; wl += (size_t)K * NB_N;
+    s.fac = wl; wl += (size_t)K * FAC_N;
+    s.ch = wl; wl += (size_t)K * CH_N;
+    s.itg = wl; wl += GL_N;
+    s.drg = wl; wl += GL_N;
+    s.itgB = wl; wl += GL_N;
+    s.sink = wl;
+    s.o_fac = (int)(KP * (3 * IT_N + 3) + K * NB_N);
+    s.o_ch = s.o_fac + K * FAC_N; s.o_sink = s.o_ch + K * CH_N + 3 * GL_N;
+    gf64 *ws = (gf64 *)a.ws + (size_t)slot * a.ws_stride;
+    s.wsg = ws;
+    s.nbs = ws + (size_t)KP * 3 * IT_N;
+    s.stT = s.nbs + (size_t)KP * NS_N;
+    const int o_ch_g = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N) + K * FAC_N;
+    s.o_traj = o_ch_g + K * CH_N; s.o_sinkg = s.o_traj + K * NCH * TR_N + 3 * GL_N;
+    s.traj = ws + s.o_traj;
+#else
     gf64 *ws = (gf64 *)a.ws + (size_t)slot * a.ws_stride;
     s.ws = ws;
     s.it = ws; ws += (size_t)KP * IT_N;
@@ -48,6 +79,7 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     //  base) back into a second pointer and emit a branch with one store per path)
     s.o_fac = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N);
     s.o_ch = s.o_fac + K * FAC_N; s.o_traj = s.o_ch + K * CH_N; s.o_sink = s.o_traj + K * NCH * TR_N + 3 * GL_N;
+#endif
     return s;
 }
 
@@ -461,7 +493,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
         n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
-        { gf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
+        { wf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
         if (SHARED) { gs[0] = gst[0]; gs[1] = gst[1]; gz[0] = gzt[0]; gz[1] = gzt[1]; }
         r0 = rt;
         r0.sq = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;

@@ -21,3 +21,6 @@ void divide_f64(int n, const double *a, double d, double *out, hipStream_t st);
 
 // solve2w.hip: the two-wave small-batch kernel (SolveArgs handed over as bytes: the struct is compiled into both units)
 int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);
+// solve_lds.hip: the same kernel with the satellite's working set in LDS (at most one satellite per compute unit at a time);
+// returns 1 without launching when the working set of the call's node count does not fit
+int mpcxl_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);

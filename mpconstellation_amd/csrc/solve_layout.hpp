@@ -74,6 +74,9 @@ struct SolveArgs {
     size_t ws_stride;
 };
 
+// what the LDS-resident build (solve_lds.hip) keeps of it in LDS: everything but the stage copy, the Newton scalars and
+// the channel trajectories
+__host__ __device__ inline size_t lds_ws_doubles(int K);
 // padded node count: leading dimension of the field-major arrays (rows start on 128-byte boundaries)
 __host__ __device__ inline int padded_nodes(int K) { return (K + 15) & ~15; }
 
@@ -82,6 +85,12 @@ __host__ __device__ inline size_t ws_doubles(int K)
     const size_t KP = (size_t)padded_nodes(K);
     const size_t n = KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + (size_t)K * (NB_N + FAC_N + CH_N + NCH * TR_N) + 3 * GL_N + 64;
     return (n + 15) & ~(size_t)15;
+}
+
+__host__ __device__ inline size_t lds_ws_doubles(int K)
+{
+    const size_t KP = (size_t)padded_nodes(K);
+    return KP * (3 * IT_N + 3) + (size_t)K * (NB_N + FAC_N + CH_N) + 3 * GL_N + 64;
 }
 
 constexpr int GR_SUM = 6, GR_MAX = 3, GR_MIN = 3, GR_N = GR_SUM + GR_MAX + GR_MIN;      // launch-wide reductions of the shared-tf mode (solve_riccati.hpp: grid_reduce)

@@ -234,6 +234,22 @@ __device__ double structural_violation(const double *x0, int K, const SatData &s
 // against lgkmcnt and would make every LDS wait drain the node-ahead prefetch.
 typedef __attribute__((address_space(1))) double gf64;
 typedef const gf64 cgf64;
+// wf64: the arrays of the satellite's workspace that the LDS-RESIDENT build keeps in LDS -- iterate, candidate, direction,
+// Newton records, factor records, channel vectors (solve_lds.hip: MPCX_WS_LDS; batches of at most one satellite per compute
+// unit, whose 160 KB of LDS then hold 134 KB of workspace at K = 30) -- and that live in the global workspace like the rest
+// (stage copy, Newton scalars, channel trajectories: gf64) in the other two builds, where wf64 IS gf64.
+#ifdef MPCX_WS_LDS
+typedef __attribute__((address_space(3))) double wf64;
+#else
+typedef gf64 wf64;
+#endif
+typedef const wf64 cwf64;
+// the byte type of a pointer's address space (Col, ustore: base + byte offset)
+template <typename T> struct as_bytes { typedef __attribute__((address_space(1))) char type; };
+#ifdef MPCX_WS_LDS
+template <> struct as_bytes<wf64> { typedef __attribute__((address_space(3))) char type; };
+template <> struct as_bytes<cwf64> { typedef __attribute__((address_space(3))) char type; };
+#endif
 
 // Field-major view of one node's record: element i of node k lives at base[i * ld + k].  The node-parallel phases
 // (one lane per node) read and write the same field of consecutive nodes in consecutive lanes, so every access is
@@ -243,9 +259,13 @@ typedef const gf64 cgf64;
 template <typename T>
 __device__ __forceinline__ T *wave_uniform(T *p)
 {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (T *)(((unsigned long long)hi << 32) | lo);
+    if constexpr (sizeof(T *) == 4) {                     // (an LDS pointer: one 32-bit register)
+        return (T *)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)p);
+    } else {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (T *)(((unsigned long long)hi << 32) | lo);
+    }
 }
 
 template <typename T>
@@ -255,8 +275,8 @@ struct Col {
     int ld;
     __device__ __forceinline__ T &operator[](int i) const
     {
-        typedef __attribute__((address_space(1))) char gchar;
-        return *(T *)((gchar *)base + (unsigned)((i * ld + k) * 8));
+        typedef typename as_bytes<T>::type bchar;
+        return *(T *)((bchar *)base + (unsigned)((i * ld + k) * 8));
     }
     __device__ __forceinline__ Col operator+(int off) const { return Col{base, k + off * ld, ld}; }
     __device__ __forceinline__ Col node(int dk) const { return Col{base, k + dk, ld}; }   // same fields, node k + dk
@@ -272,22 +292,40 @@ __device__ __forceinline__ void ustore(gf64 *ubase, int e, double v)
     typedef __attribute__((address_space(1))) char gchar;
     *(gf64 *)((gchar *)ubase + (unsigned)(e * 8)) = v;
 }
+#ifdef MPCX_WS_LDS
+__device__ __forceinline__ void ustore(wf64 *ubase, int e, double v)
+{
+    typedef __attribute__((address_space(3))) char lchar;
+    *(wf64 *)((lchar *)ubase + (unsigned)(e * 8)) = v;
+}
+#define WS_GLOBAL(s) ((s).wsg)      // base of the arrays that stay in the global workspace (channel trajectories) ...
+#define SINK_GLOBAL(s) ((s).o_sinkg) // ... and the offset of the sink that belongs to it
+#else
+#define WS_GLOBAL(s) ((s).ws)
+#define SINK_GLOBAL(s) ((s).o_sink)
+#endif
 
 struct Sat {
     int K, KP;
     int ldk;                      // row length of xbar / ubar (= K unless the batch is ragged)
     cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
-    gf64 *it, *dr, *nbs, *stT, *rbh;            // field-major [field][KP]: iterate, direction, Newton scalars, stage copy, r-hat
-    gf64 *itg, *drg, *nb, *fac, *ch, *traj;     // globals; record-per-node arrays read by the recursion (one wave, one record)
-    gf64 *itB, *itgB;                           // the candidate iterate of the line search (swapped with it, itg on acceptance)
-    gf64 *sink;                                 // 64 doubles nobody reads: target of the lanes a branch-free store leaves idle
-    gf64 *ws;                                   // base of the satellite's workspace and the element offsets of the arrays the
+    wf64 *it, *dr, *rbh;                        // field-major [field][KP]: iterate, direction, r-hat
+    gf64 *nbs, *stT;                            // ... Newton scalars, stage copy (global in every build)
+    wf64 *itg, *drg, *nb, *fac, *ch;            // globals; record-per-node arrays read by the recursion (one wave, one record)
+    gf64 *traj;                                 // ... the channels' trajectories (global in every build)
+    wf64 *itB, *itgB;                           // the candidate iterate of the line search (swapped with it, itg on acceptance)
+    wf64 *sink;                                 // 64 doubles nobody reads: target of the lanes a branch-free store leaves idle
+    wf64 *ws;                                   // base of the satellite's workspace and the element offsets of the arrays the
     int o_fac, o_ch, o_traj, o_sink;            // recursions store to (plain integers: see ustore)
-    __device__ Col<gf64> itn(int k) const { return Col<gf64>{wave_uniform(it), k, KP}; }
-    __device__ Col<gf64> itBn(int k) const { return Col<gf64>{wave_uniform(itB), k, KP}; }
-    __device__ Col<gf64> drn(int k) const { return Col<gf64>{wave_uniform(dr), k, KP}; }
+#ifdef MPCX_WS_LDS
+    gf64 *wsg;                                  // base of the global part (o_traj, o_sinkg count from here; o_fac, o_ch, o_sink from ws in LDS)
+    int o_sinkg;
+#endif
+    __device__ Col<wf64> itn(int k) const { return Col<wf64>{wave_uniform(it), k, KP}; }
+    __device__ Col<wf64> itBn(int k) const { return Col<wf64>{wave_uniform(itB), k, KP}; }
+    __device__ Col<wf64> drn(int k) const { return Col<wf64>{wave_uniform(dr), k, KP}; }
     __device__ Col<gf64> nsn(int k) const { return Col<gf64>{wave_uniform(nbs), k, KP}; }
-    __device__ Col<gf64> rbn(int k) const { return Col<gf64>{wave_uniform(rbh), k, KP}; }
+    __device__ Col<wf64> rbn(int k) const { return Col<wf64>{wave_uniform(rbh), k, KP}; }
     // stage blocks for the node-parallel phases (field-major copy) ...
     __device__ Col<cgf64> At(int k) const { return Col<cgf64>{wave_uniform((cgf64 *)stT), k, KP}; }
     __device__ Col<cgf64> Bnt(int k) const { return At(k) + 49; }
@@ -313,6 +351,9 @@ __device__ __forceinline__ Sat uniform_view(const Sat &v)
     s.itg = wave_uniform(v.itg); s.drg = wave_uniform(v.drg); s.nb = wave_uniform(v.nb); s.fac = wave_uniform(v.fac);
     s.ch = wave_uniform(v.ch); s.traj = wave_uniform(v.traj); s.itB = wave_uniform(v.itB); s.itgB = wave_uniform(v.itgB);
     s.sink = wave_uniform(v.sink); s.ws = wave_uniform(v.ws);
+#ifdef MPCX_WS_LDS
+    s.wsg = wave_uniform(v.wsg); s.o_sinkg = __builtin_amdgcn_readfirstlane(v.o_sinkg);
+#endif
     s.o_fac = __builtin_amdgcn_readfirstlane(v.o_fac); s.o_ch = __builtin_amdgcn_readfirstlane(v.o_ch);
     s.o_traj = __builtin_amdgcn_readfirstlane(v.o_traj); s.o_sink = __builtin_amdgcn_readfirstlane(v.o_sink);
     return s;
@@ -348,7 +389,7 @@ __device__ __forceinline__ L1Dir l1_dir(double nu, double tt, double stp, double
 
 // iterate + a * direction for one field, branch-free: both loads always issue (so they can all be in flight
 // together); at a == 0 the direction value, which may be stale, is replaced by 0.
-__device__ __forceinline__ double trial_value(const Col<gf64> &p, const Col<gf64> &d, int off, double a, bool z)
+__device__ __forceinline__ double trial_value(const Col<wf64> &p, const Col<wf64> &d, int off, double a, bool z)
 {
     const double dv = d[off], pv = p[off];
     return fma(a, z ? 0.0 : dv, pv);
@@ -397,7 +438,8 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                         zsum += fabs(z_); pmin = fmin(pmin, s_ * z_); pmax = fmax(pmax, s_ * z_); psum += s_ * z_; }
 #define TRIAL(P, D, off) trial_value(P, D, off, a, z)
     for (int k = NODE_OF(lane); k < K; k += 32) {
-        const auto p = s.itn(k), d = s.drn(k), w = s.itBn(k), nsv = s.nsn(k);
+        const auto p = s.itn(k), d = s.drn(k), w = s.itBn(k);
+        const auto nsv = s.nsn(k);
         const bool has_prev = (k >= 1), dyn = (k <= K - 2);
         // ---- chunk 0 (both halves, accounted by half 0): states, thrust, ball slacks, objective gradient ----
         double x[7], u[3], gx[7], gu[3], un[3];
@@ -650,7 +692,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
     for (int k0 = 0; k0 < K; k0 += 32) {
       const int k = k0 + NODE_OF(lane);
       if (k < K) {
-        const auto p = s.itn(k), ns = s.nsn(k);
+        const auto p = s.itn(k);
+        const auto ns = s.nsn(k);
         const auto rb = s.rbn(k);
         double *nb = stg + NODE_OF(lane) * NB_N;
         double *rhs = stg + 32 * NB_N + NODE_OF(lane) * RHS_LD;      // (odd stride: the 32 node lanes hit different banks)
@@ -849,11 +892,11 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
       WG_SYNC();
       {
           const int ne = ((K - k0 < 32) ? K - k0 : 32) * NB_N;
-          gf64 *dst = s.nb + (size_t)k0 * NB_N;
+          wf64 *dst = s.nb + (size_t)k0 * NB_N;
           for (int e = lane; e < ne; e += 64) dst[e] = stg[e];
           // ... and the right-hand-side records (24 contiguous doubles inside each node's channel record)
           const int nr = ((K - k0 < 32) ? K - k0 : 32) * RHS_N;
-          gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
+          wf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
           for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[32 * NB_N + kl * RHS_LD + i]; }
       }
       WG_SYNC();
@@ -903,8 +946,9 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
     double sol[NBD];
 #pragma unroll
     for (int j = 0; j < NBD; ++j) sol[j] = sd.sol[j];
-    gf64 *dr = wave_uniform(s.dr);
-    cgf64 *it = wave_uniform((cgf64 *)s.it), *traj = wave_uniform((cgf64 *)s.traj);
+    wf64 *dr = wave_uniform(s.dr);
+    cwf64 *it = wave_uniform((cwf64 *)s.it);
+    cgf64 *traj = wave_uniform((cgf64 *)s.traj);
     // Rounds of 32 nodes.  The trajectories are read in their own order (node, channel, component: contiguous), the
     // combination goes through LDS (stg: the recursion's scratch, [component][node of the round]) and leaves in the
     // direction's field-major order, consecutive lanes on consecutive nodes: written straight from the reading lanes
@@ -1001,7 +1045,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
       const int k = k0 + lane;
       double *rec = stg + lane * RHS_LD;
       if (k < K) {
-        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cwf64 *nb = s.nb + (size_t)k * NB_N;
         const auto ns = s.nsn(k);
         const auto p = s.itn(k), d = s.drn(k);
         double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
@@ -1118,7 +1162,7 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
       WG_SYNC();
       {
           const int nr = ((K - k0 < 64) ? K - k0 : 64) * RHS_N;
-          gf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
+          wf64 *ch = s.ch + (size_t)k0 * CH_N + C_RHS;
           for (int e = lane; e < nr; e += 64) { const int kl = e / RHS_N, i = e - kl * RHS_N; ch[(size_t)kl * CH_N + i] = stg[kl * RHS_LD + i]; }
       }
       WG_SYNC();

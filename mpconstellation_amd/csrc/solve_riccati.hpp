@@ -102,7 +102,7 @@ __device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, i
     const int K = s.K;
     const bool dyn = (k <= K - 2);
     if (c == 0) {
-        cgf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
+        cwf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
         ci.gx = ch[R_GX + r];
         if (r < 3) ci.gu = ch[R_GU + r];
         if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
@@ -119,10 +119,16 @@ struct ChanRaw { double gx, gu, rho, aff; };
 __device__ __forceinline__ ChanRaw chan_fetch(const Sat &s, int k, int c, int rr, int r3)
 {
     const int K = s.K;
-    cgf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
-    cgf64 *pa = (c == 1) ? s.Sig(k < K - 2 ? k : K - 2) + rr : ch + R_AFF + rr;
+    cwf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
     ChanRaw cr;
+#ifdef MPCX_WS_LDS
+    // (the right-hand-side record is in LDS, Sigma in the global stage record: two loads and a select)
+    const double sg = s.Sig(k < K - 2 ? k : K - 2)[rr], af = ch[R_AFF + rr];
+    cr.gx = ch[R_GX + rr]; cr.gu = ch[R_GU + r3]; cr.rho = ch[R_RHO + rr]; cr.aff = (c == 1) ? sg : af;
+#else
+    cgf64 *pa = (c == 1) ? s.Sig(k < K - 2 ? k : K - 2) + rr : ch + R_AFF + rr;
     cr.gx = ch[R_GX + rr]; cr.gu = ch[R_GU + r3]; cr.rho = ch[R_RHO + rr]; cr.aff = *pa;
+#endif
     return cr;
 }
 
@@ -142,7 +148,7 @@ __device__ __forceinline__ ChanIn chan_mask(const ChanRaw &cr, int c, int r, boo
 // P_k += om v v^T  -- the weight enters only through 1/ex, nothing of size ex is ever formed (condensed into the
 // blocks, 1e14 r r^T would leave no digit of the trust-region curvature 2 w_tr in the other directions).  Position term
 // first, thrust ball second (on the once-updated quantities).  Same arithmetic as the oracle's riccati_factor.
-__device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, gf64 *fac, int lane)
+__device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, wf64 *fac, int lane)
 {
     double Qi[9];
     (void)inv3_spd(w.Quu, Qi);
@@ -293,10 +299,17 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
     auto fetch = [&](int k) {
         cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
         cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
-        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cwf64 *nb = s.nb + (size_t)k * NB_N;
+#ifdef MPCX_WS_LDS
+        // (stage records in global memory, the Newton record in LDS: the lane's second element comes from one or the other)
+        cgf64 *pg = (e1 < 70) ? stk + e1 : stm + (e1 < 91 ? e1 : 70);
+        const double g1 = *pg, l1 = nb[wx1];
+        pre[0] = stk[lane]; pre[1] = (e1 < 91) ? g1 : l1; pre[2] = nb[src2];
+#else
         cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
         cgf64 *p2 = nb + src2;
         pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
+#endif
     };
     auto ops_slot = [](int e) -> int {
         if (e < 49) return (int)offsetof(StageOps, F) + 8 * ((e / 7) * FS + e % 7);
@@ -659,10 +672,17 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     auto fetch = [&](int k) {
         cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
         cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
-        cgf64 *nb = s.nb + (size_t)k * NB_N;
+        cwf64 *nb = s.nb + (size_t)k * NB_N;
+#ifdef MPCX_WS_LDS
+        // (stage records in global memory, the Newton record in LDS: the lane's second element comes from one or the other)
+        cgf64 *pg = (e1 < 70) ? stk + e1 : stm + (e1 < 91 ? e1 : 70);
+        const double g1 = *pg, l1 = nb[wx1];
+        pre[0] = stk[lane]; pre[1] = (e1 < 91) ? g1 : l1; pre[2] = nb[src2];
+#else
         cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
         cgf64 *p2 = nb + src2;
         pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
+#endif
     };
     // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7 | SX 8]
     auto ops_slot = [](int e) -> int {
@@ -710,7 +730,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
     const bool p6_qyy = p6_on && p6_j < 7, p6_quy = p6_on && p6_i < 7 && p6_j >= 7, p6_quu = p6_on && p6_i >= 7;
     for (int k = K - 1; k >= 0; --k) {
         StageOps &o = w.ops[k & 1];
-        gf64 *fac = s.fac + (size_t)k * FAC_N;
+        wf64 *fac = s.fac + (size_t)k * FAC_N;
         FT_DECL
         if (k >= 1) fetch(k - 1);
         const bool dyn = (k <= K - 2);
@@ -915,11 +935,33 @@ struct SweepPre { double v[6]; };
 
 // (PT: the backward sweep of a refinement pass reads Pt; the forward sweep does not, and outside refinement the
 //  factorisation does not even write it -- its 49 doubles, three of the record's 12.5 cache lines, are not fetched then)
+#ifdef MPCX_WS_LDS
+// LDS-resident build: the factor record and the Newton record ARE in LDS -- the sweeps read them where they lie (FAC_AT, D_AT
+// below); only the node's global operands, A (head of stage record k) and Bpm (B_kp of record k-1), are fetched one node ahead
+// and staged in the double-buffered copy.
 template <bool PT>
 __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
 {
     const int K = s.K;
-    cgf64 *fac = s.fac + (size_t)k * FAC_N;
+    cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
+    cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
+    pre.v[4] = stk[lane];
+    pre.v[5] = stm[70 + (lane < 21 ? lane : 0)];
+}
+
+__device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int lane, const SweepPre &pre)
+{
+    f[F_A + lane] = (k <= K - 2) ? pre.v[4] : 0.0;
+    if (lane < 21) f[F_BPM + lane] = (k >= 1) ? pre.v[5] : 0.0;
+}
+#define FAC_AT(s, f, k) ((s).fac + (size_t)(k) * FAC_N)
+#define D_AT(s, f, k, rr) (((k) <= (s).K - 2) ? (s).nb[(size_t)(k) * NB_N + N_D + (rr)] : 0.0)
+#else
+template <bool PT>
+__device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, SweepPre &pre)
+{
+    const int K = s.K;
+    cwf64 *fac = s.fac + (size_t)k * FAC_N;
 #pragma unroll
     for (int q = 0; q < 2; ++q) pre.v[q] = fac[lane + 64 * q];
     pre.v[2] = fac[(PT || lane + 128 < F_PT) ? lane + 128 : F_PT - 1];
@@ -927,10 +969,15 @@ __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, 
     // A: head of stage record k; Bpm: B_kp of record k-1; D: Newton record k (what a node lacks is zeroed when stashed)
     cgf64 *stk = s.stage + (size_t)(k <= K - 2 ? k : K - 2) * MPCX_STAGE_DOUBLES;
     cgf64 *stm = s.stage + (size_t)(k >= 1 ? k - 1 : 0) * MPCX_STAGE_DOUBLES;
-    cgf64 *nb = s.nb + (size_t)k * NB_N;
+    cwf64 *nb = s.nb + (size_t)k * NB_N;
     pre.v[4] = stk[lane];
+#ifdef MPCX_WS_LDS
+    const double g5 = stm[70 + (lane < 21 ? lane : 0)], l5 = nb[N_D + ((lane >= 21 && lane < 28) ? lane - 21 : 0)];
+    pre.v[5] = (lane < 21) ? g5 : l5;
+#else
     cgf64 *p5 = (lane < 21) ? stm + 70 + lane : nb + N_D + ((lane < 28) ? lane - 21 : 0);
     pre.v[5] = *p5;
+#endif
 }
 
 __device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int lane, const SweepPre &pre)
@@ -940,6 +987,10 @@ __device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int la
     f[F_A + lane] = (k <= K - 2) ? pre.v[4] : 0.0;
     f[F_BPM + lane] = ((lane < 21) ? (k >= 1) : (k <= K - 2)) ? pre.v[5] : 0.0;
 }
+
+#define FAC_AT(s, f, k) (f)
+#define D_AT(s, f, k, rr) ((f)[F_D + (rr)])
+#endif
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
 __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
@@ -957,16 +1008,17 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
     WG_SYNC();
     for (int k = K - 1; k >= 0; --k) {
         const double *f = w.flat[k & 1];
+        const auto fr = FAC_AT(s, f, k);               // the node's factor record (its LDS home, or the staged copy)
         if (k >= 1) { sweep_fetch_mats<true>(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
         const bool dyn = (k <= K - 2);
         double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            Grow[q] = f[F_G + rr * 7 + q]; Ptrow[q] = f[F_PT + rr * 7 + q]; Acol[q] = f[F_A + q * 7 + rr];
-            Bpmcol[q] = f[F_BPM + q * 3 + r3]; Bhcol[q] = f[F_BH + q * 3 + r3];
+            Grow[q] = fr[F_G + rr * 7 + q]; Ptrow[q] = fr[F_PT + rr * 7 + q]; Acol[q] = f[F_A + q * 7 + rr];
+            Bpmcol[q] = f[F_BPM + q * 3 + r3]; Bhcol[q] = fr[F_BH + q * 3 + r3];
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Kgcol[q] = f[F_KG + q * 7 + rr];
+        for (int q = 0; q < 3; ++q) Kgcol[q] = fr[F_KG + q * 7 + rr];
         const double v = cur.rho + pnext;
         double t = pnext;
 #pragma unroll
@@ -982,7 +1034,7 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
 #pragma unroll
         for (int q = 0; q < 3; ++q) p -= Kgcol[q] * gshfl8(qu, q);
         if (act) {
-            gf64 *ch = s.ch + (size_t)k * CH_N;
+            wf64 *ch = s.ch + (size_t)k * CH_N;
             ch[C_P + c * 7 + r] = p;
             if (r < 3) ch[C_QU + c * 3 + r] = qu;
             pnext = p;
@@ -1010,7 +1062,7 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
     // qu_k, p_{k+1} and Sigma_k of the lane's channel / component: branch-free loads, masked after arrival
     auto load_pq = [&](int k, double &qu, double &pn, double &sg) {
-        cgf64 *ch = s.ch + (size_t)k * CH_N;
+        cwf64 *ch = s.ch + (size_t)k * CH_N;
         qu = ch[C_QU + c * 3 + r3];
         pn = (ch + (k <= K - 2 ? CH_N : 0))[C_P + c * 7 + rr];
         sg = s.Sig(k <= K - 2 ? k : K - 2)[rr];
@@ -1023,16 +1075,17 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
     WG_SYNC();
     for (int k = 0; k < K; ++k) {
         const double *f = w.flat[k & 1];
+        const auto fr = FAC_AT(s, f, k);
         FT_DECL
         if (k + 1 < K) { sweep_fetch_mats<false>(s, k + 1, lane, pre); nraw = chan_fetch(s, k + 1, c, rr, r3); load_pq(k + 1, qun, pnn, sgn); }
         const bool dyn = (k <= K - 2);
         FT_MARK(10)
         double Kgrow[7], Arow[7], Gcol[7], Mrow[7], Qirow[3], Bpmrow[3], Bhrow[3];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { Kgrow[q] = f[F_KG + r3 * 7 + q]; Arow[q] = f[F_A + rr * 7 + q]; Gcol[q] = f[F_G + q * 7 + rr]; Mrow[q] = f[F_MINV + rr * 7 + q]; }
+        for (int q = 0; q < 7; ++q) { Kgrow[q] = fr[F_KG + r3 * 7 + q]; Arow[q] = f[F_A + rr * 7 + q]; Gcol[q] = fr[F_G + q * 7 + rr]; Mrow[q] = fr[F_MINV + rr * 7 + q]; }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { Qirow[q] = f[F_QI + r3 * 3 + q]; Bpmrow[q] = f[F_BPM + rr * 3 + q]; Bhrow[q] = f[F_BH + rr * 3 + q]; }
-        const double Dr = f[F_D + rr];
+        for (int q = 0; q < 3; ++q) { Qirow[q] = fr[F_QI + r3 * 3 + q]; Bpmrow[q] = f[F_BPM + rr * 3 + q]; Bhrow[q] = fr[F_BH + rr * 3 + q]; }
+        const double Dr = D_AT(s, f, k, rr);
         double u = 0.0;
 #pragma unroll
         for (int q = 0; q < 7; ++q) u -= Kgrow[q] * gshfl8(y, q);
@@ -1053,12 +1106,14 @@ __device__ __noinline__ void sweep_forward(const Sat &s_in, SatData &sd, Scratch
         FT_MARK(12)
         {
             // the channel's trajectory at this node: branch-free stores (see ustore)
-            const int tb = s.o_traj + (k * NCH + c) * TR_N, sink_t = s.o_sink + lane;
             const double lam = Dr * nu + cur.rho;
             const bool ad = act && dyn;
-            ustore(s.ws, act ? tb + T_X + r : sink_t, x);
-            ustore(s.ws, (act && r < 3) ? tb + T_U + r3 : sink_t, u);
-            ustore(s.ws, ad ? tb + T_NU + r : sink_t, nu);
+            // (the trajectories live in the global workspace in every build: WS_GLOBAL / SINK_GLOBAL are the plain base and sink
+            //  offset except in the LDS-resident build, whose LDS part has a base and a sink of its own)
+            const int tb = s.o_traj + (k * NCH + c) * TR_N, sink_t = SINK_GLOBAL(s) + lane;
+            ustore(WS_GLOBAL(s), act ? tb + T_X + r : sink_t, x);
+            ustore(WS_GLOBAL(s), (act && r < 3) ? tb + T_U + r3 : sink_t, u);
+            ustore(WS_GLOBAL(s), ad ? tb + T_NU + r : sink_t, nu);
             if (act && k == K - 1) sd.xK[c][r] = x;
             siglam += ad ? sgc * lam : 0.0;
             y = ad ? yh + nu : y;

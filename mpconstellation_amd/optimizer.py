@@ -66,7 +66,8 @@ def _result_arrays(S, K, device, pinned):
     """X, U, NU, kkt, status, iters for one call.  pinned: page-locked buffers owned by this module and REUSED by the next
     call of the same shape on the device (results are DMA targets, no staging copy; copy what must outlive the next call)."""
     if not pinned:
-        return (np.empty((S, 7, K)), np.empty((S, 3, K)), np.empty((S, 7, K)), np.empty(S), np.zeros(S, dtype=np.int32),
+        take = _ffi.result_pool.take         # (large arrays are recycled once the caller has dropped the previous results)
+        return (take((S, 7, K)), take((S, 3, K)), take((S, 7, K)), np.empty(S), np.zeros(S, dtype=np.int32),
                 np.zeros(S, dtype=np.int32))
     key = (S, K, device)
     if key not in _pinned_results:
@@ -228,7 +229,7 @@ def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None
         tf_sim, interval, n_eval, drag, j2 = fly[:5]
         sim = (float(tf_sim), float(interval), int(n_eval), (_ffi.FLAG_DRAG if drag else 0) | (_ffi.FLAG_J2 if j2 else 0),
                float(fly[5]) if len(fly) > 5 else 1e-3)
-        y_sim = np.empty((S, 7, sim[2])); sst = np.zeros(S, dtype=np.int32)
+        y_sim = _ffi.result_pool.take((S, 7, sim[2])); sst = np.zeros(S, dtype=np.int32)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
     rc = lib.mpcx_mpc_update_batch(ctx, S, K, int(n_scp), float(base_res), _ffi.dptr(y0), _ffi.dptr(horizon), _ffi.dptr(consts),
