@@ -60,6 +60,10 @@ extern "C" {
  * points per interval of the RK45 dense output instead of the accepted step nodes. */
 #define MPCX_FLAG_UNIFORM_STEPS 4
 #define MPCX_UNIFORM_STEPS(n) ((n) << 8)
+/* discretize entry points only: Discretizer.ivp_solver = 'RK23' (linearize_discretize.py:40,105: the attribute is solve_ivp's
+ * `method`) -- scipy's Bogacki-Shampine 3(2) pair instead of the default 'RK45', same step-size controller, same tolerances.
+ * The implicit methods scipy also offers (Radau, BDF, LSODA) and DOP853 are not implemented. */
+#define MPCX_FLAG_RK23 8
 
 /* normalised constants per satellite: reference constants.py:11-20 field order */
 enum { MPCX_C_MU = 0, MPCX_C_R_E, MPCX_C_J2, MPCX_C_G0, MPCX_C_ISP, MPCX_C_S, MPCX_C_R0,

@@ -16,7 +16,7 @@ STATUS_TEXT = {
     9: "ragged batch: node / table-column / output-point count outside the accepted range",
     8: "constraint set empty (start node outside its radius bounds, terminal window outside r_max, empty window or tf range)",
 }
-FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS = 1, 2, 4
+FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS, FLAG_RK23 = 1, 2, 4, 8
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
 NCONST = 8
 STAGE_DOUBLES = 105

@@ -262,7 +262,9 @@ __device__ __forceinline__ void node_integrand(RhsCtx &p, const double (&y)[7],
 // UNIFORM: Discretizer.use_uniform_steps (linearize_discretize.py:27-30, 50-53): the quadrature nodes are integrator_steps
 // uniform points per interval taken from the RK45 dense-output interpolant (scipy's t_eval branch), A_k the interpolant
 // at the last of them; a separate instantiation, the default path is untouched.
-template <int LAYOUT, bool UNIFORM>
+// METHOD: 45 -- scipy's 'RK45', the reference's default (linearize_discretize.py:105) -- or 23: 'RK23' (ivp_solver goes to
+// solve_ivp's `method`, :40): the same controller around the Bogacki-Shampine tableau, separate instantiations.
+template <int LAYOUT, bool UNIFORM, int METHOD = 45>
 #ifndef MPCX_DISC_WAVES
 #define MPCX_DISC_WAVES 1      // waves per SIMD the register allocation is bounded for (360 registers at 1)
 #endif
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
     const double tau_kp1 = (k + 1 == Km1s) ? 1.0 : (double)(k + 1) * step + 0.0;
     const double t_bound = tau_kp1;
     const double rtol = 1e-3, atol = 1e-6;
+    constexpr double kErrExp = (METHOD == 23) ? -1.0 / 3.0 : -0.2;      // rk.py:93: -1 / (error_estimator_order + 1)
     int err = (badk || badku) ? MPCX_ST_BADK : 0;
 
     double y[7], f[7];
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
         const double d2 = sqrt(group_sum(s2)) * inv_sqrt_n / h0;
         double h1;
         if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-        else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        else h1 = pow(0.01 / fmax(d1, d2), METHOD == 23 ? 1.0 / 3.0 : 1.0 / 5.0);       // 1 / (error_estimator_order + 1)
         h_abs = fmin(fmin(100.0 * h0, h1), fmin(interval, a.max_step));
         if (interval == 0.0) h_abs = 0.0;
     }
@@ -380,6 +383,28 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
         const double h_try = fabs(h);
 
         double K1[7], K2[7], K3[7], K4[7], K5[7], K6[7], yt[7], yn[7];
+        double se = 0.0;
+        if constexpr (METHOD == 23) {
+            // rk_step (rk.py:14-70) with the RK23 tableau: two inner stages, y_new, and f(y_new) -- kept in K6, the slot of the
+            // last stage in both methods (first-same-as-last: it becomes f of the next step)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK23_A10) * h;
+            rhs_eval(p, yt, t + RK23_C[1] * h, K1, err);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * 0.0 + K1[i] * RK23_A21) * h;
+            rhs_eval(p, yt, t + RK23_C[2] * h, K2, err);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) yn[i] = y[i] + h * (f[i] * RK23_B[0] + K1[i] * RK23_B[1] + K2[i] * RK23_B[2]);
+            rhs_eval(p, yn, t + h, K6, err);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                K3[i] = 0.0; K4[i] = 0.0; K5[i] = 0.0;
+                const double e = f[i] * RK23_E[0] + K1[i] * RK23_E[1] + K2[i] * RK23_E[2] + K6[i] * RK23_E[3];
+                const double sc = atol + fmax(fabs(y[i]), fabs(yn[i])) * rtol;
+                const double q = (e * h) * rcp_nr(sc);
+                se += q * q;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 7; ++i) yt[i] = y[i] + (f[i] * RK_A[1][0]) * h;
         rhs_eval(p, yt, t + RK_C[1] * h, K1, err);
@@ -406,7 +431,6 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
                                 K3[i] * RK_B[3] + K4[i] * RK_B[4] + K5[i] * RK_B[5]);
         rhs_eval(p, yn, t + h, K6, err);
 
-        double se = 0.0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const double e = f[i] * RK_E[0] + K1[i] * RK_E[1] + K2[i] * RK_E[2] + K3[i] * RK_E[3] +
@@ -415,16 +439,17 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
             const double q = (e * h) * rcp_nr(sc);
             se += q * q;
         }
+        }
         const double error_norm = sqrt(group_sum(se)) / sqrt(56.0);
         bool accept = false;
         if (error_norm < 1.0) {
             double factor = (error_norm == 0.0) ? RK_MAX_FACTOR
-                                                : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(error_norm, -0.2));
+                                                : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(error_norm, kErrExp));
             if (rejected) factor = fmin(1.0, factor);
             if (active && !fail) { h_abs = h_try * factor; accept = true; }
         } else if (active && !fail) {
             // NaN error norms land here as in scipy (comparison false) and shrink the step
-            h_abs = h_try * fmax(RK_MIN_FACTOR, RK_SAFETY * pow(error_norm, -0.2));
+            h_abs = h_try * fmax(RK_MIN_FACTOR, RK_SAFETY * pow(error_norm, kErrExp));
             rejected = true;
         }
         if (fail) {            // scipy: TOO_SMALL_STEP -> solver fails; freeze this group
@@ -447,6 +472,17 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
                 double Q[7][4];
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
+                    if constexpr (METHOD == 23) {
+                        const double kk[4] = {f[i], K1[i], K2[i], K6[i]};       // (K of rk.py: f, the two inner stages, f(y_new))
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            double q = 0.0;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) q += kk[jj] * RK23_P[jj][cc];
+                            Q[i][cc] = q;
+                        }
+                        Q[i][3] = 0.0;
+                    } else {
                     const double kk[7] = {f[i], K1[i], K2[i], K3[i], K4[i], K5[i], K6[i]};
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
@@ -454,6 +490,7 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
 #pragma unroll
                         for (int jj = 0; jj < 7; ++jj) q += kk[jj] * RK_P[jj][cc];
                         Q[i][cc] = q;
+                    }
                     }
                 }
                 for (;;) {
@@ -465,7 +502,8 @@ __global__ __launch_bounds__(64, MPCX_DISC_WAVES) void discretize_kernel(DiscArg
                     double yd[7], g[7];
 #pragma unroll
                     for (int i = 0; i < 7; ++i) {
-                        const double accq = Q[i][0] * p1 + Q[i][1] * p2 + Q[i][2] * p3 + Q[i][3] * p4;
+                        const double accq = (METHOD == 23) ? Q[i][0] * p1 + Q[i][1] * p2 + Q[i][2] * p3
+                                                            : Q[i][0] * p1 + Q[i][1] * p2 + Q[i][2] * p3 + Q[i][3] * p4;
                         yd[i] = has ? h * accq + yold[i] : y[i];
                     }
                     node_integrand(p, yd, has ? te : t, tau_k, tau_kp1, g, err);
@@ -571,14 +609,19 @@ static int launch_discretize(mpcx_ctx *ctx, int layout, DiscArgs a, hipStream_t 
     const unsigned blocks = (unsigned)((total + 7) / 8);
     const bool uni = (a.flags & MPCX_FLAG_UNIFORM_STEPS) != 0;
     if (uni && (a.flags >> 8) < 2) return ctx_fail(ctx, MPCX_E_BADARG, "discretize: uniform steps need MPCX_UNIFORM_STEPS(n), n >= 2");
+    const bool rk23 = (a.flags & MPCX_FLAG_RK23) != 0;
     if (!uni) a.flags &= (MPCX_FLAG_DRAG | MPCX_FLAG_J2);
+#define MPCX_DISC_LAUNCH(L, U, M) hipLaunchKernelGGL((discretize_kernel<L, U, M>), dim3(blocks), dim3(64), 0, st, a)
     if (layout == LAYOUT_STAGE) {
-        if (uni) hipLaunchKernelGGL((discretize_kernel<LAYOUT_STAGE, true>), dim3(blocks), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((discretize_kernel<LAYOUT_STAGE, false>), dim3(blocks), dim3(64), 0, st, a);
+        if (rk23) { if (uni) MPCX_DISC_LAUNCH(LAYOUT_STAGE, true, 23); else MPCX_DISC_LAUNCH(LAYOUT_STAGE, false, 23); }
+        else if (uni) MPCX_DISC_LAUNCH(LAYOUT_STAGE, true, 45);
+        else MPCX_DISC_LAUNCH(LAYOUT_STAGE, false, 45);
     } else {
-        if (uni) hipLaunchKernelGGL((discretize_kernel<LAYOUT_REF, true>), dim3(blocks), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((discretize_kernel<LAYOUT_REF, false>), dim3(blocks), dim3(64), 0, st, a);
+        if (rk23) { if (uni) MPCX_DISC_LAUNCH(LAYOUT_REF, true, 23); else MPCX_DISC_LAUNCH(LAYOUT_REF, false, 23); }
+        else if (uni) MPCX_DISC_LAUNCH(LAYOUT_REF, true, 45);
+        else MPCX_DISC_LAUNCH(LAYOUT_REF, false, 45);
     }
+#undef MPCX_DISC_LAUNCH
     MPCX_HIP(ctx, hipGetLastError());
     return MPCX_OK;
 }

@@ -34,6 +34,12 @@ __device__ constexpr double RK_P[7][4] = {
     {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
     {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
 constexpr double RK_SAFETY = 0.9, RK_MIN_FACTOR = 0.2, RK_MAX_FACTOR = 10.0;
+// scipy's RK23 (Bogacki-Shampine 3(2), rk.py:183-278; Discretizer.ivp_solver = 'RK23'): C = (0, 1/2, 3/4), A, B, E, P (4 x 3)
+__device__ constexpr double RK23_C[3] = {0.0, 1.0 / 2, 3.0 / 4};
+__device__ constexpr double RK23_A10 = 1.0 / 2, RK23_A21 = 3.0 / 4;      // (A[2][0] = 0)
+__device__ constexpr double RK23_B[3] = {2.0 / 9, 1.0 / 3, 4.0 / 9};
+__device__ constexpr double RK23_E[4] = {5.0 / 72, -1.0 / 12, -1.0 / 9, 1.0 / 8};
+__device__ constexpr double RK23_P[4][3] = {{1, -4.0 / 3, 5.0 / 9}, {0, 1, -2.0 / 3}, {0, 4.0 / 3, -8.0 / 9}, {0, -1, 1}};
 
 // Python / numpy float floor division (the `tau // dtau` of linearize_discretize.py:310)
 __device__ __forceinline__ double py_floordiv(double a, double b)

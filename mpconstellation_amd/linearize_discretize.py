@@ -46,8 +46,7 @@ class Discretizer:
         lib = _ffi.load()
         ctx = _ffi.context(self.device)
         flags = _ffi.FLAG_J2 if self.include_J2 else 0
-        if self.use_uniform_steps:                           # linearize_discretize.py:27-30: t_eval = linspace(.., integrator_steps)
-            flags |= _ffi.FLAG_UNIFORM_STEPS | (int(self.integrator_steps) << 8)
+        flags |= self.device_flags()
         rc = lib.mpcx_discretize_batch(ctx, S, K, Ku, _ffi.dptr(x), _ffi.dptr(u), _ffi.dptr(tf),
                                        _ffi.dptr(consts), flags, float(self.ivp_max_step),
                                        _ffi.dptr(A), _ffi.dptr(Bp), _ffi.dptr(Bn), _ffi.dptr(Sig),
@@ -74,12 +73,23 @@ class Discretizer:
             raise RuntimeError(_ffi.STATUS_TEXT.get(int(status[0]), "discretize failed"))
         return A[0], Bp[0], Bn[0], Sig[0], xi[0]
 
+    def device_flags(self):
+        """the integration settings as flags of the discretize / fused-step entry points (include/mpcx.h): use_uniform_steps
+        with integrator_steps (linearize_discretize.py:27-30: t_eval = linspace(.., integrator_steps)), ivp_solver (:40)"""
+        flags = 0
+        if self.use_uniform_steps:
+            flags |= _ffi.FLAG_UNIFORM_STEPS | (int(self.integrator_steps) << 8)
+        if self.ivp_solver == 'RK23':
+            flags |= _ffi.FLAG_RK23
+        return flags
+
     def _check_modes(self):
         if self.include_drag:
             # the reference's drag branch cannot run either (Constants has no CD, rho_func is None)
             raise NotImplementedError("drag in the linearisation is not supported")
-        if self.ivp_solver != 'RK45':
-            raise NotImplementedError("only ivp_solver='RK45' is implemented on the device")
+        if self.ivp_solver not in ('RK45', 'RK23'):
+            raise NotImplementedError("ivp_solver: 'RK45' (the reference's default) and 'RK23' are implemented on the device; "
+                                      "scipy's DOP853 and its implicit methods (Radau, BDF, LSODA) are not")
         if self.use_uniform_steps and int(self.integrator_steps) < 2:
             raise ValueError("use_uniform_steps needs integrator_steps >= 2")
 

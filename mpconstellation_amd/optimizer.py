@@ -87,7 +87,7 @@ def _tf_io(S, fixed_tf):
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
                    linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, shared_tf=False,
-                   devices=None, **solver):
+                   devices=None, rk23=False, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Ks (S,) int: a ragged batch -- satellite s has Ks[s] <= K nodes in the first columns of its rows (what the reference's
@@ -106,7 +106,7 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
         bc = lambda a: _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)))
         Ksb = None if Ks is None else np.ascontiguousarray(np.broadcast_to(np.asarray(Ks), (S,)), dtype=np.int32)
         fn = lambda x, u, t, c, r, k, device, slot: mpc_step_batch(x, u, t, c, r, options, include_J2, max_step, device, slot, linear_vt,
-                                                                   None, False, uniform_steps, regularised, k, False, None, **solver)
+                                                                   None, False, uniform_steps, regularised, k, False, None, rk23, **solver)
         return join_results(sharded_call(fn, devices, [xbar, _ffi.as_f64(ubar), bc(tf), _ffi.as_f64(consts), bc(r_des), Ksb]))
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
@@ -126,6 +126,8 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     dflags = _ffi.FLAG_J2 if include_J2 else 0
     if uniform_steps:                         # Discretizer.use_uniform_steps with integrator_steps = uniform_steps
         dflags |= _ffi.FLAG_UNIFORM_STEPS | (int(uniform_steps) << 8)
+    if rk23:                                  # Discretizer.ivp_solver = 'RK23'
+        dflags |= _ffi.FLAG_RK23
     if Ks is None:
         rc = lib.mpcx_mpc_step_batch(ctx, S, K, _ffi.dptr(xbar), _ffi.dptr(ubar), _ffi.dptr(tf), _ffi.dptr(consts),
                                      _ffi.dptr(r_des), dflags, float(max_step), C.byref(opts),
@@ -472,7 +474,8 @@ class Optimizer:
             self.result = mpc_step_batch(xbar, ubar, self.tf, consts, options['r_des'], options,
                                          include_J2=self.d.include_J2, max_step=self.d.ivp_max_step,
                                          device=getattr(self.d, "device", 0),
-                                         uniform_steps=int(self.d.integrator_steps) if self.d.use_uniform_steps else 0, **solver)
+                                         uniform_steps=int(self.d.integrator_steps) if self.d.use_uniform_steps else 0,
+                                         rk23=(self.d.ivp_solver == 'RK23'), **solver)
         self.status = self.result.status
         if self.shared_tf and self._N > 1 and not self.tf_search.converged:
             import warnings

@@ -80,7 +80,8 @@ static int get_matrices(int K, int Ku, const double *x, const double *u, double 
     for (int i = 0; i < 7; ++i) { y0[i * 7 + i] = 1.0; y0[49 + i] = x[i * K + k]; }   /* :31-34 */
     dphi_ctx ctx = {u, Ku, tf, cst, flags, 0};
     rk45 s;
-    rk45_init(&s, 56, dphi, &ctx, tau_k, y0, tau_kp1, max_step, 1e-3, 1e-6);          /* :37-41 */
+    /* :37-41; method = options['ivp_solver'] (:40): flag bit 8 = 'RK23', otherwise the default 'RK45' (:105) */
+    rk_init_method(&s, (flags & 8) ? 23 : 45, 56, dphi, &ctx, tau_k, y0, tau_kp1, max_step, 1e-3, 1e-6);
 
     int cap = n_uniform > 64 ? n_uniform + 1 : 64, n = 0;
     double *ts = malloc(cap * sizeof(double)), *ys = malloc(cap * 56 * sizeof(double));

@@ -7,6 +7,8 @@
  *   scipy/integrate/_ivp/rk.py   : SAFETY/MIN_FACTOR/MAX_FACTOR :8-11, rk_step :14-70,
  *                                  RungeKutta._step_impl :110-168, RK45 tableau :377-404
  *   scipy/integrate/_ivp/common.py: norm :63-65, select_initial_step :68-134
+ * and, for Discretizer.ivp_solver = 'RK23', the Bogacki-Shampine 3(2) tableau of the same file (RK23, rk.py:183-278:
+ * C, A, B, E, P, order 3, error_estimator_order 2, n_stages 3) driven by the same stepper.
  */
 #include <math.h>
 #include <float.h>
@@ -34,6 +36,23 @@ const double RK45_P[7][4] = {
     {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
     {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
 
+/* RK23 (rk.py:183-278) in the same array shapes */
+static const double RK23_C[6] = {0.0, 1.0 / 2, 3.0 / 4, 0, 0, 0};
+static const double RK23_A[6][5] = {{0, 0, 0, 0, 0}, {1.0 / 2, 0, 0, 0, 0}, {0, 3.0 / 4, 0, 0, 0}, {0}, {0}, {0}};
+static const double RK23_B[6] = {2.0 / 9, 1.0 / 3, 4.0 / 9, 0, 0, 0};
+static const double RK23_E[7] = {5.0 / 72, -1.0 / 12, -1.0 / 9, 1.0 / 8, 0, 0, 0};
+static const double RK23_P[7][4] = {{1, -4.0 / 3, 5.0 / 9, 0}, {0, 1, -2.0 / 3, 0}, {0, 4.0 / 3, -8.0 / 9, 0}, {0, -1, 1, 0},
+                                    {0}, {0}, {0}};
+
+typedef struct { int n_stages, err_order, n_p; const double *C; const double (*A)[5]; const double *B, *E; const double (*P)[4]; } tableau;
+static tableau tab_of(int method)
+{
+    tableau t;
+    if (method == 23) { t.n_stages = 3; t.err_order = 2; t.n_p = 3; t.C = RK23_C; t.A = RK23_A; t.B = RK23_B; t.E = RK23_E; t.P = RK23_P; }
+    else { t.n_stages = 6; t.err_order = 4; t.n_p = 4; t.C = RK_C; t.A = RK_A; t.B = RK_B; t.E = RK_E; t.P = RK45_P; }
+    return t;
+}
+
 #define SAFETY 0.9
 #define MIN_FACTOR 0.2
 #define MAX_FACTOR 10.0
@@ -45,7 +64,7 @@ static double rms_norm(const double *x, int n) /* common.py:63-65 */
     return sqrt(s) / sqrt((double)n);
 }
 
-/* common.py:68-134 with direction = +1, order = 4 */
+/* common.py:68-134 with direction = +1, order = the method's error_estimator_order (4 / 2) */
 static double select_initial_step(rk45 *s, double t0, const double *y0, double t_bound,
                                   const double *f0)
 {
@@ -69,7 +88,7 @@ static double select_initial_step(rk45 *s, double t0, const double *y0, double t
     if (d1 <= 1e-15 && d2 <= 1e-15)
         h1 = fmax(1e-6, h0 * 1e-3);
     else
-        h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+        h1 = pow(0.01 / fmax(d1, d2), 1.0 / (tab_of(s->method).err_order + 1.0));
     double h = 100.0 * h0;
     if (h1 < h) h = h1;
     if (interval_length < h) h = interval_length;
@@ -80,7 +99,14 @@ static double select_initial_step(rk45 *s, double t0, const double *y0, double t
 void rk45_init(rk45 *s, int n, rk45_fun fun, void *ctx, double t0, const double *y0, double t_bound,
                double max_step, double rtol, double atol)
 {
+    rk_init_method(s, 45, n, fun, ctx, t0, y0, t_bound, max_step, rtol, atol);
+}
+
+void rk_init_method(rk45 *s, int method, int n, rk45_fun fun, void *ctx, double t0, const double *y0, double t_bound,
+                    double max_step, double rtol, double atol)
+{
     memset(s, 0, sizeof *s);
+    s->method = method;
     s->n = n; s->fun = fun; s->ctx = ctx; s->t = t0; s->t_bound = t_bound;
     s->max_step = max_step; s->rtol = rtol; s->atol = atol;
     memcpy(s->y, y0, n * sizeof(double));
@@ -94,6 +120,9 @@ void rk45_init(rk45 *s, int n, rk45_fun fun, void *ctx, double t0, const double 
 int rk45_step(rk45 *s)
 {
     int n = s->n;
+    const tableau tb = tab_of(s->method);
+    const int ns = tb.n_stages;
+    const double expo = -1.0 / (tb.err_order + 1.0);           /* rk.py:93: error_exponent */
     double t = s->t;
     const double *y = s->y;
     double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
@@ -114,25 +143,25 @@ int rk45_step(rk45 *s)
         h_abs = fabs(h);
         /* rk_step */
         memcpy(s->K[0], s->f, n * sizeof(double));
-        for (int st = 1; st < 6; ++st) {
+        for (int st = 1; st < ns; ++st) {
             for (int i = 0; i < n; ++i) {
                 double dy = 0.0;
-                for (int j = 0; j < st; ++j) dy += s->K[j][i] * RK_A[st][j];
+                for (int j = 0; j < st; ++j) dy += s->K[j][i] * tb.A[st][j];
                 ytmp[i] = y[i] + dy * h;
             }
-            if (s->fun(t + RK_C[st] * h, ytmp, s->K[st], s->ctx)) s->fun_err = 1;
+            if (s->fun(t + tb.C[st] * h, ytmp, s->K[st], s->ctx)) s->fun_err = 1;
         }
         for (int i = 0; i < n; ++i) {
             double acc = 0.0;
-            for (int j = 0; j < 6; ++j) acc += s->K[j][i] * RK_B[j];
+            for (int j = 0; j < ns; ++j) acc += s->K[j][i] * tb.B[j];
             y_new[i] = y[i] + h * acc;
         }
-        if (s->fun(t + h, y_new, s->K[6], s->ctx)) s->fun_err = 1;
-        s->nfev += 6;
+        if (s->fun(t + h, y_new, s->K[ns], s->ctx)) s->fun_err = 1;
+        s->nfev += ns;
         /* error estimate rk.py:104-108, :137-138 */
         for (int i = 0; i < n; ++i) {
             double e = 0.0;
-            for (int j = 0; j < 7; ++j) e += s->K[j][i] * RK_E[j];
+            for (int j = 0; j <= ns; ++j) e += s->K[j][i] * tb.E[j];
             double scale = s->atol + fmax(fabs(y[i]), fabs(y_new[i])) * s->rtol;
             err[i] = e * h / scale;
         }
@@ -140,12 +169,12 @@ int rk45_step(rk45 *s)
         if (error_norm < 1.0) {
             double factor;
             if (error_norm == 0.0) factor = MAX_FACTOR;
-            else factor = fmin(MAX_FACTOR, SAFETY * pow(error_norm, -0.2));
+            else factor = fmin(MAX_FACTOR, SAFETY * pow(error_norm, expo));
             if (step_rejected) factor = fmin(1.0, factor);
             h_abs *= factor;
             break;
         }
-        h_abs *= fmax(MIN_FACTOR, SAFETY * pow(error_norm, -0.2));
+        h_abs *= fmax(MIN_FACTOR, SAFETY * pow(error_norm, expo));
         step_rejected = 1;
     }
     s->h_previous = h;
@@ -154,7 +183,7 @@ int rk45_step(rk45 *s)
     s->t = t_new;
     memcpy(s->y, y_new, n * sizeof(double));
     s->h_abs = h_abs;
-    memcpy(s->f, s->K[6], n * sizeof(double));
+    memcpy(s->f, s->K[ns], n * sizeof(double));
     s->nsteps++;
     return 0;
 }
@@ -163,15 +192,16 @@ int rk45_step(rk45 *s)
 void rk45_dense_eval(const rk45 *s, double t, double *y)
 {
     int n = s->n;
+    const tableau tb = tab_of(s->method);
     double h = s->h_previous;
     double x = (t - s->t_old) / h;
     double p[4];
     p[0] = x; p[1] = p[0] * x; p[2] = p[1] * x; p[3] = p[2] * x;
     for (int i = 0; i < n; ++i) {
         double acc = 0.0;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < tb.n_p; ++c) {
             double q = 0.0;
-            for (int j = 0; j < 7; ++j) q += s->K[j][i] * RK45_P[j][c];
+            for (int j = 0; j <= tb.n_stages; ++j) q += s->K[j][i] * tb.P[j][c];
             acc += q * p[c];
         }
         y[i] = h * acc + s->y_old[i];

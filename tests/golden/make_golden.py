@@ -286,6 +286,30 @@ def gen_uniform_steps_cases():
     save("uniform_steps_K12_tf1.npz", const=const_vec(const), x=x, t=t, u=u, tf=np.float64(1), steps=np.array([101, 11]), **out)
 
 
+def gen_rk23_cases():
+    """Discretizer.ivp_solver = 'RK23' (linearize_discretize.py:40,105: the attribute goes to solve_ivp's `method`): the
+    default adaptive quadrature nodes and the uniform-step mode, with the accepted step nodes of the adaptive run."""
+    sat = Satellite(R_HUBBLE, V_HUBBLE, M_HUBBLE)
+    scale = SatelliteScale(sat=sat)
+    const = scale.get_normalized_constants()
+    out = {}
+    for name, ctrl, tf, base_res in (("tan_K30_tf1", ConstantTangentialThrustController([sat], 0.5), 1, 30),
+                                     ("const_K20_tf2", ConstantThrustController([sat], np.array([0.44, 0.7, 1.0])), 2, 10)):
+        x, t, u = reference_case(sat, scale, ctrl, tf, base_res)
+        d = Discretizer(const, include_drag=False, include_J2=False)
+        d.ivp_solver = 'RK23'
+        A, Bp, Bn, Sig, xi = d.discretize(F, x, u, tf)
+        counts, nfev, nt, ny = rk_nodes(d, x, u, tf)
+        out.update({f"x_{name}": x, f"t_{name}": t, f"u_{name}": u, f"tf_{name}": np.float64(tf), f"A_{name}": A, f"Bp_{name}": Bp,
+                    f"Bn_{name}": Bn, f"Sigma_{name}": Sig, f"xi_{name}": xi, f"node_counts_{name}": counts, f"node_nfev_{name}": nfev,
+                    f"node_t_{name}": nt, f"node_y_{name}": ny})
+        if name == "tan_K30_tf1":
+            d.use_uniform_steps = True; d.integrator_steps = 21
+            A, Bp, Bn, Sig, xi = d.discretize(F, x, u, tf)
+            out.update({"uni_steps": np.int64(21), "uni_A": A, "uni_Bp": Bp, "uni_Bn": Bn, "uni_Sigma": Sig, "uni_xi": xi})
+    save("rk23_discretize.npz", const=const_vec(const), cases=np.array(["tan_K30_tf1", "const_K20_tf2"]), **out)
+
+
 def gen_csv_case():
     """The trajectory CSV the reference writes (Simulator.save_to_csv, simulator.py:192-201, read by visualizer.m:23-28):
     file name pattern, the file's text and the run that produced it."""
@@ -318,9 +342,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "uniform":
         gen_uniform_steps_cases()
         raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rk23":
+        gen_rk23_cases()
+        raise SystemExit(0)
     gen_constants_and_pointwise()
     gen_discretize_cases()
     gen_constellation_cases()
     gen_propagation_cases()
     gen_csv_case()
     gen_uniform_steps_cases()
+    gen_rk23_cases()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
-FLAG_DRAG, FLAG_J2 = 1, 2
+FLAG_DRAG, FLAG_J2, FLAG_RK23 = 1, 2, 8      # (FLAG_RK23: Discretizer.ivp_solver = 'RK23' in oracle_discretize*)
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
 CT_NTERMS = 32
 CT_SLICES = {

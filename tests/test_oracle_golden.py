@@ -130,3 +130,26 @@ def test_uniform_steps_mode(golden_dir, steps):
     for k, key in (("A", "A"), ("Bp", "Bp"), ("Bn", "Bn"), ("Sigma", "Sigma"), ("xi", "xi")):
         ref = g[f"{key}_{steps}"]
         assert np.abs(o[k] - ref).max() <= 2e-15 * np.abs(ref).max(), key
+
+
+def test_rk23_mode(golden_dir):
+    """Discretizer.ivp_solver = 'RK23' (linearize_discretize.py:40,105): the oracle's stepper with scipy's Bogacki-Shampine
+    tableau against arrays the reference produced with that setting -- step nodes node for node, the five arrays, and the
+    uniform-step mode on the RK23 dense output."""
+    g = np.load(os.path.join(golden_dir, "rk23_discretize.npz"))
+    for name in g["cases"]:
+        x, u, tf = g[f"x_{name}"], g[f"u_{name}"], float(g[f"tf_{name}"])
+        o = O.discretize(x, u, tf, g["const"], O.FLAG_RK23, dump_nodes=True)
+        assert o["status"] == 0
+        assert np.array_equal(o["node_counts"], g[f"node_counts_{name}"]) and np.array_equal(o["node_nfev"], g[f"node_nfev_{name}"])
+        # (the same steps; their lengths agree to 1e-11 only: RK23's error estimate is a difference of nearly equal stage
+        #  values, so rounding-level differences of the right-hand side reach the step-size factor at 1e-9 relative)
+        assert np.abs(o["node_t"] - g[f"node_t_{name}"]).max() < 1e-11 and np.abs(o["node_y"] - g[f"node_y_{name}"]).max() < 1e-10
+        for k in ("A", "Bp", "Bn", "Sigma", "xi"):
+            assert relerr(o[k], g[f"{k}_{name}"]) < RTOL, (name, k)
+        # (not the RK45 result: the quadrature nodes differ)
+        assert relerr(O.discretize(x, u, tf, g["const"])["Bp"], g[f"Bp_{name}"]) > 1e-6
+    name = "tan_K30_tf1"
+    o = O.discretize(g[f"x_{name}"], g[f"u_{name}"], 1.0, g["const"], O.FLAG_RK23, uniform_steps=int(g["uni_steps"]))
+    for k in ("A", "Bp", "Bn", "Sigma", "xi"):
+        assert relerr(o[k], g["uni_" + k]) < RTOL, k
