@@ -251,3 +251,31 @@ def test_ragged_foh_resampling_matches_the_scalar_reference_formula():
         f = SequenceController(u=u[s][:, :Ku[s]], tf_u=1.3, tf_sim=1.3).get_u_func()
         ref = np.column_stack([f(None, tq) for tq in np.linspace(0, 1, n[s])])
         assert np.array_equal(ref, out[s][:, :n[s]]) and not out[s][:, n[s]:].any()
+
+
+def test_result_arrays_are_recycled_only_when_dropped():
+    """_ffi.result_pool: the wrappers' large result arrays are reused once the caller holds no reference to them any more (a
+    fresh 7 MB numpy array is a fresh mapping whose pages fault on first write: 1.8 ms of a 8.8 ms call), and never while it
+    does -- not the array, not a view of it, not a SolveResult that carries it."""
+    from mpconstellation_amd import _ffi
+    from mpconstellation_amd.optimizer import SolveResult
+    pool = _ffi._ResultPool()
+    shape = (4096, 7, 30)
+    a = pool.take(shape); ida = id(a)
+    b = pool.take(shape)
+    assert b is not a                                    # a is still held
+    res = SolveResult(b, None, None, None, None, None, None)
+    del a, b
+    c = pool.take(shape)
+    assert id(c) == ida                                  # a was dropped: recycled
+    d = pool.take(shape)
+    assert d is not res.X and d is not c                 # b lives on inside the result object
+    view = c[5]
+    del c, d
+    e = pool.take(shape)
+    assert e.base is None and not np.shares_memory(e, view)      # a view keeps its base array out of circulation
+    small = pool.take((64, 7, 30))
+    assert pool.take((64, 7, 30)) is not small           # below 1 MB: plain allocations
+    assert len(pool._pool[(shape, "<f8")]) <= pool.PER_SHAPE
+    for n in range(40): pool.take((4096, 7, 31 + n))     # many shapes: the oldest leave the pool
+    assert len(pool._pool) <= pool.SHAPES
