@@ -278,6 +278,15 @@ def test_update_in_one_call_equals_one_call_per_iteration():
         assert np.array_equal(a.sim_data[sa.id], b.sim_data[sb.id]) and np.array_equal(sa.get_state_vector(), sb.get_state_vector())
     assert a.sim_data[a.sats[0].id].shape == (7, 100) and a.horizon == 1.0
     assert a.sim_time[a.sats[0].id] is not a.sim_time[a.sats[1].id]           # an array per id, as the reference keeps them
+    # three SCP iterations: the third rollout plays a RAGGED table (the second iteration's plan) -- one call against three
+    c = ConstellationMPC(make(), scp_iterations=3, **kw)
+    d = ConstellationMPC(make(), scp_iterations=3, verbose=True, **kw)
+    c.update()
+    with contextlib.redirect_stdout(io.StringIO()):
+        d.update()
+    assert c.last_status.shape == (3, 5) and (c.last_status == 0).all() and np.array_equal(c.last_status, d.last_status)
+    assert np.array_equal(c.plan_K, d.plan_K) and np.array_equal(c.plan_tf, d.plan_tf) and np.array_equal(c.last_iters, d.last_iters)
+    for i in range(5): assert np.array_equal(c.plan_x[i], d.plan_x[i]) and np.array_equal(c.plan_u[i], d.plan_u[i])
 
 
 def test_several_devices_from_the_api():
