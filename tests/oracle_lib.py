@@ -44,8 +44,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(LIB_PATH)
+        # (ORACLE_LIB: another build of the same sources, e.g. the -fsanitize=address,undefined one of `make -C oracle asan`)
+        _lib = C.CDLL(os.environ.get("ORACLE_LIB") or build())
         _lib.oracle_dynamics.restype = C.c_int
         _lib.oracle_u_foh.restype = C.c_int
         _lib.oracle_discretize.restype = C.c_int
