@@ -8,6 +8,7 @@
 #define MPCX_TWO_WAVE 1
 #define MPCX_WS_LDS 1
 #include <cstring>
+#include <mutex>
 #include "solve_common.hpp"
 #include "solve_launch.hpp"
 #define MPCX_KERNEL2W_NAME solve_kernel_lds
@@ -20,16 +21,29 @@ int mpcxl_launch(const void *args, size_t args_bytes, int blocks, hipStream_t st
     MPCX_NS::SolveArgs a;
     if (args_bytes != sizeof a) return -1;
     memcpy(&a, args, sizeof a);
-    static int lds_limit = -1;                // dynamic LDS the kernel may have beside its static part (per device the same)
-    if (lds_limit < 0) {
-        hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, (const void *)MPCX_NS::solve_kernel_lds) != hipSuccess) return -1;
-        int dev = 0, max_lds = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return -1;
-        if (max_lds < 160 * 1024) max_lds = 160 * 1024;                 // (gfx950: 160 KB per workgroup)
-        const int room = max_lds - (int)at.sharedSizeBytes;
-        if (room > 0 && hipFuncSetAttribute((const void *)MPCX_NS::solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) return -1;
-        lds_limit = room > 0 ? room : 0;
+    // dynamic LDS the kernel may have beside its static part: asked for once PER DEVICE (the attribute belongs to the device's
+    // copy of the function; contexts of several devices call from their own threads: sharding.py)
+    constexpr int kMaxDev = 64;
+    static int limits[kMaxDev];
+    static bool asked[kMaxDev];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -1;
+    int lds_limit;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!asked[dev]) {
+            hipFuncAttributes at;
+            if (hipFuncGetAttributes(&at, (const void *)MPCX_NS::solve_kernel_lds) != hipSuccess) return -1;
+            int max_lds = 0;
+            if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return -1;
+            if (max_lds < 160 * 1024) max_lds = 160 * 1024;                 // (gfx950: 160 KB per workgroup)
+            const int room = max_lds - (int)at.sharedSizeBytes;
+            if (room > 0 && hipFuncSetAttribute((const void *)MPCX_NS::solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) return -1;
+            limits[dev] = room > 0 ? room : 0;
+            asked[dev] = true;
+        }
+        lds_limit = limits[dev];
     }
     const size_t need = mpcx::lds_ws_doubles(a.K) * sizeof(double);
     if (need > (size_t)lds_limit) return 1;
