@@ -27,7 +27,7 @@ WORKLOADS = {            # BASELINE.json configs: name -> (satellites per GPU, n
     "S4096_K100_scp2": (4096, 100, 2), # configs[3]: 2 SCP iterations with nonlinear re-rollout (control.py:166,183-227)
     "S8192_K30": (8192, 30, 1),        # configs[4] per GPU (65,536 over 8)
 }
-DEFAULT_SINGLE, DEFAULT_MULTI = "S4096_K30", "S8192_K30"
+DEFAULT_SINGLE = "S4096_K30"      # the same per-GPU work at every N (weak scaling); configs[4]'s 8192 per GPU rides along as `also` when N > 1
 F64_VALU_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak
 FLOP_PER_NODE_ITER = 18e3       # factorisation 8.7k + 8-channel sweeps 7k + node-parallel phases 2.4k
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table
@@ -334,7 +334,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help=f"default: {DEFAULT_SINGLE} on one GPU, {DEFAULT_MULTI} per GPU on several")
+                    help=f"default: {DEFAULT_SINGLE} per GPU at every N (with N > 1 also S8192_K30 per GPU, reported under `also`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra S64_K30 measurement of the default run")
     ap.add_argument("--cpu-sample", type=int, default=256, help="satellites solved by the CPU oracle")
@@ -359,7 +359,7 @@ def main():
         dist.init_process_group("gloo" if (single_dev or not have_gpu) else "nccl")
     if not have_gpu:
         raise SystemExit("bench.py needs an MI355X: libmpcx has no CPU fallback")
-    workload = args.workload or (DEFAULT_SINGLE if world == 1 else DEFAULT_MULTI)
+    workload = args.workload or DEFAULT_SINGLE
 
     run = Runner(workload, rank, world, local_rank)
     S, K, n_scp = run.S, run.K, run.n_scp
@@ -368,6 +368,22 @@ def main():
     stats = torch.tensor([float(((status == 0) | (status == 7)).sum()), float(S)], dtype=torch.float64,
                          device="cpu" if (world > 1 and dist.get_backend() == "gloo") else "cuda")
     if world > 1: dist.all_reduce(stats)
+    also_multi = None
+    if world > 1 and not args.no_also and workload == DEFAULT_SINGLE:
+        # BASELINE configs[4] (65 536 satellites over 8 GPUs = 8192 per GPU) by every rank in the same run, timed the same way
+        # (barriers, slowest rank); the headline keeps the per-GPU work of the N = 1 line so that the N = 1, 2, 4, 8 values are
+        # one weak-scaling curve
+        run4 = Runner("S8192_K30", rank, world, local_rank)
+        e4, sm4 = measure(run4, 5, 1, world)
+        st4, it4, _ = run4.solver_stats()
+        stats4 = torch.tensor([float(((st4 == 0) | (st4 == 7)).sum())], dtype=torch.float64, device=stats.device)
+        dist.all_reduce(stats4)
+        also_multi = {"S8192_K30": {"value": run4.S * world * 5 / e4, "unit": "satellite-MPC-steps/s", "steps": 5, "warmup": 1,
+                                    "ms_per_step": e4 / 5 * 1e3, "satellites_per_gpu": run4.S, "satellites_total": run4.S * world,
+                                    "solve_kernel_ms_rank0": sm4, "converged": int(stats4[0].item()), "of": run4.S * world,
+                                    "note": "BASELINE configs[4]'s share per GPU (65 536 satellites on 8), all ranks, same run"}}
+        del run4
+        torch.cuda.empty_cache()
 
     if rank == 0:
         S_total = S * world
@@ -414,6 +430,7 @@ def main():
                                            "one GPU's share of BASELINE configs[4] (65 536 satellites over 8 GPUs), same run"),
             }
             out["closed_loop"] = {f"S{n}": closed_loop(n, local_rank) for n in (64, 4096)}
+        if also_multi: out["also"] = also_multi
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)
             if err: out["trajectory_error_vs_cpu_oracle"] = err

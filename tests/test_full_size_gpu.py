@@ -287,7 +287,7 @@ def test_bench_two_ranks_launched_as_child_processes():
     """`python bench.py --gpus 2` from a process that is not itself a rank: bench.py starts its two ranks through
     torch.distributed.run from a parent that never touches the GPU (bench.py: spawn_ranks); on this one-GPU box both ranks
     share device 0 (MPCX_BENCH_SINGLE_DEVICE=1, gloo for the timing reduction).  The JSON line must report the whole job:
-    two ranks, 2 x 8192 satellites, every problem converged."""
+    two ranks, 2 x 4096 satellites (the N = 1 line's work per GPU) and, beside it, 2 x 8192 (configs[4]'s), every problem converged."""
     import json
     import subprocess
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -300,9 +300,12 @@ def test_bench_two_ranks_launched_as_child_processes():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["satellites_total"] == 16384 and out["config"]["workload"] == "S8192_K30"
-    assert out["scaling"] == "weak" and out["solver"]["converged"] == out["solver"]["of"] == 16384
-    assert out["value"] > 0 and abs(out["value"] - 16384 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    # the per-GPU work of the N = 1 line at every N (one weak-scaling curve); configs[4]'s 8192 per GPU in the same run beside it
+    assert out["n_gpus"] == 2 and out["config"]["satellites_total"] == 8192 and out["config"]["workload"] == "S4096_K30"
+    a4 = out["also"]["S8192_K30"]
+    assert a4["satellites_total"] == 16384 and a4["converged"] == a4["of"] and a4["value"] > 0
+    assert out["scaling"] == "weak" and out["solver"]["converged"] == out["solver"]["of"] == 8192
+    assert out["value"] > 0 and abs(out["value"] - 8192 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 
 @pytest.mark.parametrize("K,tf,r_des", [(30, 1.0, 1.5), (30, 2.0, 1.2), (60, 2.0, 1.5), (30, 1.0, 1.05)])
