@@ -1,0 +1,164 @@
+"""Feasibility study (CPU oracle, lives under tests/: it uses oracle/): a TIME-PARALLEL form of the reduced solve of one
+interior-point iteration -- the horizon cut at node m = K // 2 into two segments whose recursions do not wait for each other.
+
+Sequential form (oracle/nlp_ipm.py riccati_factor / riccati_channel, csrc/solve_riccati.hpp): one backward recursion over the
+K nodes, one forward sweep: 2 K dependent node steps.  Partitioned form, in the recursion's shifted state y_k:
+
+  segment 2 (nodes m .. K-1): the same backward recursion as now -- its cost-to-go at the cut is V_m(y) = 1/2 y'P_m y + p_m'y;
+  segment 1 (nodes 0 .. m-1): the same recursion started from a ZERO cost-to-go behind node m-1, and, besides each channel's
+      own right-hand side, seven unit channels whose only datum is a linear terminal cost e_i'y_m.  Its forward sweep from
+      y_0 = 0 gives y_m as an affine function of the terminal price l:  y_m(l) = y_m0 - N l,  N >= 0 (7 x 7, one per
+      factorisation, shared by all channels);
+  interface: l must be the gradient of segment 2's cost-to-go at the point segment 1 arrives at, l = P_m z + p_m with
+      z = y_m(l):   (I + N P_m) z = y_m0 - N p_m   -- one 7 x 7 solve per channel;
+  then segment 1's trajectory = its local one + sum_i l_i (unit trajectory i), segment 2's forward sweep starts from y_m = z.
+
+Both backward recursions run side by side (m and K - m nodes), then both forward sweeps: K dependent node steps instead of
+2 K, at the price of 7 more channels in segment 1 and the interface solve.  This script checks, on interior-point iterates
+of the benchmark constellation and of the closed loop's stiff-window problems, (a) that the partitioned solve returns the
+sequential one's direction and to how many digits, (b) that whole solves run with it take the same iterations.
+
+usage: python tests/tools/partitioned_riccati.py [n_satellites] [closed_loop_cache.pkl]
+(the cache is what closed_loop_start_rules.py gen writes; without it only the benchmark set runs)"""
+import os, pickle, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, ROOT)
+import numpy as np
+import oracle_lib as O, nlp_ipm as N
+from mpconstellation_amd.constellation import constellation_states, normalize_batch
+
+SEQ_CHANNEL = N.riccati_channel
+
+
+def factor_segment1(P, nb, m):
+    """riccati_factor's node step for k = m-1 .. 0 with nothing behind node m-1 (P_m := 0)"""
+    K = P.K; Wx, Wu, D = nb["Wx0"], nb["Wu0"], nb["D"]
+    F = dict(P=np.zeros((K + 1, 7, 7)), Minv=np.zeros((K, 7, 7)), G=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
+             Qi=np.zeros((K, 3, 3)), Kg=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)))
+    for k in range(m - 1, -1, -1):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        Pn = F["P"][k + 1]
+        X1, X2, rd = N.ldl_solve7(np.diag(D[:, k]) + Pn, Pn)
+        C1 = rd[:, None] * X1; C2 = rd[:, None] * X2
+        Pt = Pn - X1.T @ C1; Pt = 0.5 * (Pt + Pt.T)
+        F["G"][k] = X1.T @ C2; F["Minv"][k] = X2.T @ C2
+        Ah = P.A[k]; Bh = P.A[k] @ Bpm + P.Bn[k]
+        Quu = Wu[k] + Bpm.T @ Wx[k] @ Bpm + Bh.T @ Pt @ Bh
+        Quy = Bpm.T @ Wx[k] + Bh.T @ Pt @ Ah
+        np.linalg.cholesky(Quu)
+        Qi = np.linalg.inv(Quu); Kg = Qi @ Quy
+        Pk = Wx[k] + Ah.T @ Pt @ Ah - Quy.T @ Kg
+        for (cu, cy, ex) in nb["stiff"][k]:
+            if cu is None: cu = Bpm.T @ cy
+            t = Qi @ cu; om = 1.0 / (1.0 / ex + cu @ t); v = cy - Kg.T @ cu
+            Pk = Pk + om * np.outer(v, v); Kg = Kg + om * np.outer(t, v); Qi = Qi - om * np.outer(t, t)
+        F["P"][k] = 0.5 * (Pk + Pk.T); F["Pt"][k] = Pt; F["Qi"][k] = Qi; F["Kg"][k] = Kg; F["Bh"][k] = Bh
+    return F
+
+
+def sweep_segment(P, nb, F, k_lo, k_hi, p_end, y_start, gx, gu, rho, aff):
+    """backward sweep over nodes k_hi-1 .. k_lo with the linear cost-to-go p_end behind node k_hi-1, then the forward sweep
+    from y_{k_lo} = y_start; the arithmetic of riccati_channel.  Returns the trajectories of the nodes, y behind the last
+    node and the linear term p_{k_lo} of the segment's cost-to-go."""
+    K = P.K; D = nb["D"]
+    p = np.zeros((K + 1, 7)); qu = np.zeros((K, 3)); p[k_hi] = p_end
+    for k in range(k_hi - 1, k_lo - 1, -1):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        if k <= K - 2:
+            t = p[k + 1] - F["G"][k] @ (rho[:, k] + p[k + 1]) + F["Pt"][k] @ aff[:, k]; Ah = P.A[k]
+        else:
+            t = np.zeros(7); Ah = np.zeros((7, 7))
+        qu[k] = gu[:, k] + Bpm.T @ gx[:, k] + F["Bh"][k].T @ t
+        p[k] = gx[:, k] + Ah.T @ t - F["Kg"][k].T @ qu[k]
+    X = np.zeros((7, K)); U = np.zeros((3, K)); NU = np.zeros((7, K - 1)); LAM = np.zeros((7, K - 1))
+    y = y_start.copy()
+    for k in range(k_lo, k_hi):
+        Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
+        u = -(F["Kg"][k] @ y) - F["Qi"][k] @ qu[k]
+        U[:, k] = u; X[:, k] = y + Bpm @ u
+        if k <= K - 2:
+            yh = P.A[k] @ y + F["Bh"][k] @ u + aff[:, k]
+            nu = -(F["G"][k].T @ yh) - F["Minv"][k] @ (rho[:, k] + p[k + 1])
+            NU[:, k] = nu; LAM[:, k] = D[:, k] * nu + rho[:, k]
+            y = yh + nu
+    return (X, U, NU, LAM), y, p[k_lo]
+
+
+_cache = {}
+STATS = {"cond": [], "err": []}
+
+
+def partitioned_channel(P, nb, F, gx, gu, rho, aff):
+    K = P.K; m = K // 2
+    key = id(F)
+    if key not in _cache:
+        _cache.clear()
+        F1 = factor_segment1(P, nb, m)
+        Z7 = np.zeros((7, K)); Z3 = np.zeros((3, K)); Zn = np.zeros((7, K - 1))
+        units = []; Nm = np.zeros((7, 7))
+        for i in range(7):
+            e = np.zeros(7); e[i] = 1.0
+            tr, ym, _ = sweep_segment(P, nb, F1, 0, m, e, np.zeros(7), Z7, Z3, Zn, Zn)
+            units.append(tr); Nm[:, i] = -ym
+        _cache[key] = (F1, units, Nm, F)              # (F kept alive: its id is the key)
+        STATS["cond"].append(np.linalg.cond(np.eye(7) + Nm @ F["P"][m]))
+    F1, units, Nm, _ = _cache[key]
+    # the two segments' own sweeps (independent of each other): segment 2 backward only, segment 1 backward and forward
+    _, _, p_m = sweep_segment(P, nb, F, m, K, np.zeros(7), np.zeros(7), gx, gu, rho, aff)
+    tr1, ym0, _ = sweep_segment(P, nb, F1, 0, m, np.zeros(7), np.zeros(7), gx, gu, rho, aff)
+    # interface
+    Pm = F["P"][m]
+    z = np.linalg.solve(np.eye(7) + Nm @ Pm, ym0 - Nm @ p_m)
+    ell = Pm @ z + p_m
+    # segment 1: local + sum l_i unit_i ; segment 2: forward from z
+    tr2, _, _ = sweep_segment(P, nb, F, m, K, np.zeros(7), z, gx, gu, rho, aff)
+    out = []
+    for j in range(4):
+        a = tr1[j] + sum(ell[i] * units[i][j] for i in range(7))
+        out.append(a + tr2[j])           # (disjoint node ranges: the other segment's part is zero)
+    # how far from the sequential sweeps' result for the same right-hand side (relative to the largest entry of each array)
+    ref = SEQ_CHANNEL(P, nb, F, gx, gu, rho, aff)
+    STATS["err"].append(max(np.abs(out[j] - ref[j]).max() / max(np.abs(ref[j]).max(), 1e-300) for j in range(4)))
+    return tuple(out)
+
+
+def problems_benchmark(n):
+    st = constellation_states(4096, first=0, count=n)
+    y0, cst = normalize_batch(st)
+    probs = []
+    for i in range(n):
+        ctrl = O.make_ctrl(2, thrust=(0.5, 0.0, 0.0))
+        K = 30
+        x = O.propagate(y0[i], 1.0, cst[i], ctrl, K)[0]; t = np.linspace(0, 1, K)
+        u = O.extract_uk(x, t, ctrl)
+        d = O.discretize(x, u, 1.0, cst[i])
+        probs.append(("bench", N.MpcProblem(x, u, 1.0, cst[i][0], d, O.constraint_terms(x, u, cst[i][0]), {"r_des": 1.5})))
+    return probs
+
+
+def problems_closed_loop(path, n):
+    with open(path, "rb") as f: lst = pickle.load(f)
+    out = []
+    for q in lst[:n]:
+        d = dict(q["d"]);
+        out.append((f"loop seg{q['seg']} it{q['it']}", N.MpcProblem(q["x"], q["u"], q["tf"], q["mu"], d, q["terms"], q["opts"])))
+    return out
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    probs = problems_benchmark(n)
+    if len(sys.argv) > 2: probs += problems_closed_loop(sys.argv[2], 4 * n)
+    print("whole solves: sequential | partitioned (iterations, status), distance of the solutions")
+    tot = [0, 0]
+    for label, P in probs:
+        N.riccati_channel = SEQ_CHANNEL; a = N.solve(P)
+        STATS["cond"].clear(); STATS["err"].clear()
+        N.riccati_channel = partitioned_channel
+        try: b = N.solve(P)
+        finally: N.riccati_channel = SEQ_CHANNEL
+        dx = np.abs(a["X"] - b["X"]).max(); du = np.abs(a["U"] - b["U"]).max()
+        tot[0] += a["iters"]; tot[1] += b["iters"]
+        print(f"{label:16s} K {P.K:3d}  seq {a['iters']:3d} st {a['status']}  part {b['iters']:3d} st {b['status']}  |dX| {dx:.2e} |dU| {du:.2e} |dtf| {abs(a['tf'] - b['tf']):.2e}"
+              f"  cond(I + N P_m) max {max(STATS['cond']):.2e}  channel results against the sequential sweeps': median {np.median(STATS['err']):.1e} max {max(STATS['err']):.1e}", flush=True)
+    print(f"iterations in total: sequential {tot[0]}, partitioned {tot[1]}")
