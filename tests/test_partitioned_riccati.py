@@ -13,7 +13,7 @@ def test_partitioned_solve_equals_the_sequential_one():
     N = PR.N
     (_, P), = PR.problems_benchmark(1)
     a = N.solve(P)
-    PR.STATS["cond"].clear(); PR.STATS["err"].clear()
+    PR.STATS["cond"].clear(); PR.STATS["err"].clear(); PR.STATS["spd"].clear()
     N.riccati_channel = PR.partitioned_channel
     try:
         b = N.solve(P)

@@ -85,7 +85,7 @@ def sweep_segment(P, nb, F, k_lo, k_hi, p_end, y_start, gx, gu, rho, aff):
 
 
 _cache = {}
-STATS = {"cond": [], "err": []}
+STATS = {"cond": [], "err": [], "spd": []}
 
 
 def partitioned_channel(P, nb, F, gx, gu, rho, aff):
@@ -108,7 +108,16 @@ def partitioned_channel(P, nb, F, gx, gu, rho, aff):
     tr1, ym0, _ = sweep_segment(P, nb, F1, 0, m, np.zeros(7), np.zeros(7), gx, gu, rho, aff)
     # interface
     Pm = F["P"][m]
-    z = np.linalg.solve(np.eye(7) + Nm @ Pm, ym0 - Nm @ p_m)
+    # (I + N P_m) is not symmetric; with P_m = L L' (positive definite: every stage carries 2 w_tr I) it is similar to the
+    # symmetric positive definite S = I + L'N L >= I:  z = L'^-1 S^-1 L' r -- two Cholesky factorisations and triangular solves,
+    # no pivoting, which is what a kernel can do in registers (the pivoted LAPACK solve beside it: STATS["spd"])
+    r = ym0 - Nm @ p_m
+    L = np.linalg.cholesky(0.5 * (Pm + Pm.T)); Ns = 0.5 * (Nm + Nm.T)
+    Ls = np.linalg.cholesky(np.eye(7) + L.T @ Ns @ L)
+    t = np.linalg.solve(Ls.T, np.linalg.solve(Ls, L.T @ r))
+    z = np.linalg.solve(L.T, t)
+    z_lu = np.linalg.solve(np.eye(7) + Nm @ Pm, r)
+    STATS["spd"].append(np.abs(z - z_lu).max() / max(np.abs(z_lu).max(), 1e-300))
     ell = Pm @ z + p_m
     # segment 1: local + sum l_i unit_i ; segment 2: forward from z
     tr2, _, _ = sweep_segment(P, nb, F, m, K, np.zeros(7), z, gx, gu, rho, aff)
@@ -153,12 +162,12 @@ if __name__ == "__main__":
     tot = [0, 0]
     for label, P in probs:
         N.riccati_channel = SEQ_CHANNEL; a = N.solve(P)
-        STATS["cond"].clear(); STATS["err"].clear()
+        STATS["cond"].clear(); STATS["err"].clear(); STATS["spd"].clear()
         N.riccati_channel = partitioned_channel
         try: b = N.solve(P)
         finally: N.riccati_channel = SEQ_CHANNEL
         dx = np.abs(a["X"] - b["X"]).max(); du = np.abs(a["U"] - b["U"]).max()
         tot[0] += a["iters"]; tot[1] += b["iters"]
         print(f"{label:16s} K {P.K:3d}  seq {a['iters']:3d} st {a['status']}  part {b['iters']:3d} st {b['status']}  |dX| {dx:.2e} |dU| {du:.2e} |dtf| {abs(a['tf'] - b['tf']):.2e}"
-              f"  cond(I + N P_m) max {max(STATS['cond']):.2e}  channel results against the sequential sweeps': median {np.median(STATS['err']):.1e} max {max(STATS['err']):.1e}", flush=True)
+              f"  cond(I + N P_m) max {max(STATS['cond']):.2e}  channel results against the sequential sweeps': median {np.median(STATS['err']):.1e} max {max(STATS['err']):.1e}  interface: symmetric form against LU max {max(STATS['spd']):.1e}", flush=True)
     print(f"iterations in total: sequential {tot[0]}, partitioned {tot[1]}")
