@@ -8,8 +8,13 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 
 
-def test_partitioned_solve_equals_the_sequential_one():
+import pytest
+
+
+@pytest.mark.parametrize("segments", [2, 4])
+def test_partitioned_solve_equals_the_sequential_one(segments):
     import partitioned_riccati as PR
+    PR.SEGMENTS = segments; PR._cache.clear()
     N = PR.N
     (_, P), = PR.problems_benchmark(1)
     a = N.solve(P)

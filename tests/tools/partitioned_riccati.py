@@ -30,12 +30,12 @@ from mpconstellation_amd.constellation import constellation_states, normalize_ba
 SEQ_CHANNEL = N.riccati_channel
 
 
-def factor_segment1(P, nb, m):
-    """riccati_factor's node step for k = m-1 .. 0 with nothing behind node m-1 (P_m := 0)"""
+def factor_range(P, nb, k_lo, k_hi):
+    """riccati_factor's node step for k = k_hi-1 .. k_lo with nothing behind node k_hi-1 (zero cost-to-go there); k_hi < K"""
     K = P.K; Wx, Wu, D = nb["Wx0"], nb["Wu0"], nb["D"]
     F = dict(P=np.zeros((K + 1, 7, 7)), Minv=np.zeros((K, 7, 7)), G=np.zeros((K, 7, 7)), Pt=np.zeros((K, 7, 7)),
              Qi=np.zeros((K, 3, 3)), Kg=np.zeros((K, 3, 7)), Bh=np.zeros((K, 7, 3)))
-    for k in range(m - 1, -1, -1):
+    for k in range(k_hi - 1, k_lo - 1, -1):
         Bpm = P.Bp[k - 1] if k >= 1 else np.zeros((7, 3))
         Pn = F["P"][k + 1]
         X1, X2, rd = N.ldl_solve7(np.diag(D[:, k]) + Pn, Pn)
@@ -86,48 +86,87 @@ def sweep_segment(P, nb, F, k_lo, k_hi, p_end, y_start, gx, gu, rho, aff):
 
 _cache = {}
 STATS = {"cond": [], "err": [], "spd": []}
+SEGMENTS = int(os.environ.get("SEGMENTS", "2"))
+
+
+def spd_solve(Nm, W, r):
+    """(I + N W)^-1 r through the similar symmetric positive definite I + L'N L, W = L L' (no pivoting: what a kernel can do in
+    registers); the pivoted LAPACK solve beside it is recorded in STATS["spd"]"""
+    L = np.linalg.cholesky(0.5 * (W + W.T)); Ns = 0.5 * (Nm + Nm.T)
+    Ls = np.linalg.cholesky(np.eye(7) + L.T @ Ns @ L)
+    z = np.linalg.solve(L.T, np.linalg.solve(Ls.T, np.linalg.solve(Ls, L.T @ r)))
+    if r.ndim == 1:
+        z_lu = np.linalg.solve(np.eye(7) + Nm @ W, r)
+        STATS["spd"].append(np.abs(z - z_lu).max() / max(np.abs(z_lu).max(), 1e-300))
+    return z
 
 
 def partitioned_channel(P, nb, F, gx, gu, rho, aff):
-    K = P.K; m = K // 2
+    """the reduced solve of one channel over SEGMENTS segments (cuts[j-1] .. cuts[j]-1, j = 1 .. S): every segment but the last
+    has its own recursion from a zero cost-to-go (the last one is the tail of the sequential factorisation F), a local
+    trajectory from the start state 0 and price 0, seven responses to a unit start state (segments 2 .. S) and seven to a unit
+    terminal price (segments 1 .. S-1).  With a_j the start state and l_j the terminal price of segment j:
+        a_{j+1} = y0_j + Phi_j a_j - N_j l_j ,     l_j = W_{j+1} a_{j+1} + p0_{j+1} + Psi_{j+1} l_{j+1}      (a_1 = 0, l_S = 0)
+    -- a coarse problem of S - 1 interfaces, solved by its own backward recursion What_j, qhat_j (7 x 7 blocks, S - 2 steps, the
+    matrices once per factorisation) and a forward pass per channel."""
+    K = P.K; S = SEGMENTS
+    cuts = [round(j * K / S) for j in range(S + 1)]
+    Z7 = np.zeros((7, K)); Z3 = np.zeros((3, K)); Zn = np.zeros((7, K - 1)); z7 = np.zeros(7)
     key = id(F)
     if key not in _cache:
         _cache.clear()
-        F1 = factor_segment1(P, nb, m)
-        Z7 = np.zeros((7, K)); Z3 = np.zeros((3, K)); Zn = np.zeros((7, K - 1))
-        units = []; Nm = np.zeros((7, 7))
-        for i in range(7):
-            e = np.zeros(7); e[i] = 1.0
-            tr, ym, _ = sweep_segment(P, nb, F1, 0, m, e, np.zeros(7), Z7, Z3, Zn, Zn)
-            units.append(tr); Nm[:, i] = -ym
-        _cache[key] = (F1, units, Nm, F)              # (F kept alive: its id is the key)
-        STATS["cond"].append(np.linalg.cond(np.eye(7) + Nm @ F["P"][m]))
-    F1, units, Nm, _ = _cache[key]
-    # the two segments' own sweeps (independent of each other): segment 2 backward only, segment 1 backward and forward
-    _, _, p_m = sweep_segment(P, nb, F, m, K, np.zeros(7), np.zeros(7), gx, gu, rho, aff)
-    tr1, ym0, _ = sweep_segment(P, nb, F1, 0, m, np.zeros(7), np.zeros(7), gx, gu, rho, aff)
-    # interface
-    Pm = F["P"][m]
-    # (I + N P_m) is not symmetric; with P_m = L L' (positive definite: every stage carries 2 w_tr I) it is similar to the
-    # symmetric positive definite S = I + L'N L >= I:  z = L'^-1 S^-1 L' r -- two Cholesky factorisations and triangular solves,
-    # no pivoting, which is what a kernel can do in registers (the pivoted LAPACK solve beside it: STATS["spd"])
-    r = ym0 - Nm @ p_m
-    L = np.linalg.cholesky(0.5 * (Pm + Pm.T)); Ns = 0.5 * (Nm + Nm.T)
-    Ls = np.linalg.cholesky(np.eye(7) + L.T @ Ns @ L)
-    t = np.linalg.solve(Ls.T, np.linalg.solve(Ls, L.T @ r))
-    z = np.linalg.solve(L.T, t)
-    z_lu = np.linalg.solve(np.eye(7) + Nm @ Pm, r)
-    STATS["spd"].append(np.abs(z - z_lu).max() / max(np.abs(z_lu).max(), 1e-300))
-    ell = Pm @ z + p_m
-    # segment 1: local + sum l_i unit_i ; segment 2: forward from z
-    tr2, _, _ = sweep_segment(P, nb, F, m, K, np.zeros(7), z, gx, gu, rho, aff)
-    out = []
-    for j in range(4):
-        a = tr1[j] + sum(ell[i] * units[i][j] for i in range(7))
-        out.append(a + tr2[j])           # (disjoint node ranges: the other segment's part is zero)
+        segs = []
+        for j in range(1, S + 1):
+            lo, hi = cuts[j - 1], cuts[j]
+            Fj = F if j == S else factor_range(P, nb, lo, hi)
+            up = []; ua = []; Nm = np.zeros((7, 7)); Psi = np.zeros((7, 7)); Phi = np.zeros((7, 7))
+            for i in range(7):
+                e = np.zeros(7); e[i] = 1.0
+                if j < S:                                  # unit terminal price
+                    tr, ye, ps = sweep_segment(P, nb, Fj, lo, hi, e, z7, Z7, Z3, Zn, Zn)
+                    up.append(tr); Nm[:, i] = -ye; Psi[:, i] = ps
+                if j > 1:                                  # unit start state
+                    tr, ye, _ = sweep_segment(P, nb, Fj, lo, hi, z7, e, Z7, Z3, Zn, Zn)
+                    ua.append(tr); Phi[:, i] = ye
+            segs.append(dict(F=Fj, lo=lo, hi=hi, up=up, ua=ua, N=Nm, Psi=Psi, Phi=Phi, W=Fj["P"][lo]))
+        # coarse backward recursion (channel independent part): What_j for j = S .. 2
+        What = [None] * (S + 2); What[S] = segs[S - 1]["W"]
+        for j in range(S - 1, 1, -1):
+            sj = segs[j - 1]
+            EPhi = spd_solve(sj["N"], What[j + 1], sj["Phi"])
+            What[j] = sj["W"] + sj["Psi"] @ What[j + 1] @ EPhi
+            What[j] = 0.5 * (What[j] + What[j].T)
+        for j in range(1, S): STATS["cond"].append(np.linalg.cond(np.eye(7) + segs[j - 1]["N"] @ What[j + 1]))
+        _cache[key] = (segs, What, F)
+    segs, What, _ = _cache[key]
+    # per channel: the segments' local sweeps (independent of each other) ...
+    loc = []; y0 = []; p0 = []
+    for j in range(1, S + 1):
+        sj = segs[j - 1]
+        tr, ye, ps = sweep_segment(P, nb, sj["F"], sj["lo"], sj["hi"], z7, z7, gx, gu, rho, aff)
+        loc.append(tr); y0.append(ye); p0.append(ps)
+    # ... the coarse backward pass qhat_j, then forward a_j, l_j
+    qhat = [None] * (S + 2); qhat[S] = p0[S - 1]
+    for j in range(S - 1, 1, -1):
+        sj = segs[j - 1]
+        t = spd_solve(sj["N"], What[j + 1], y0[j - 1] - sj["N"] @ qhat[j + 1])
+        qhat[j] = p0[j - 1] + sj["Psi"] @ (What[j + 1] @ t + qhat[j + 1])
+    a = [None] * (S + 2); ell = [None] * (S + 2); a[1] = z7
+    for j in range(1, S):
+        sj = segs[j - 1]
+        a[j + 1] = spd_solve(sj["N"], What[j + 1], y0[j - 1] + sj["Phi"] @ a[j] - sj["N"] @ qhat[j + 1])
+        ell[j] = What[j + 1] @ a[j + 1] + qhat[j + 1]
+    out = [np.zeros_like(loc[0][q]) for q in range(4)]
+    for j in range(1, S + 1):
+        sj = segs[j - 1]
+        for q in range(4):
+            v = loc[j - 1][q].copy()
+            if j > 1: v += sum(a[j][i] * sj["ua"][i][q] for i in range(7))
+            if j < S: v += sum(ell[j][i] * sj["up"][i][q] for i in range(7))
+            out[q] += v                                    # (disjoint node ranges)
     # how far from the sequential sweeps' result for the same right-hand side (relative to the largest entry of each array)
     ref = SEQ_CHANNEL(P, nb, F, gx, gu, rho, aff)
-    STATS["err"].append(max(np.abs(out[j] - ref[j]).max() / max(np.abs(ref[j]).max(), 1e-300) for j in range(4)))
+    STATS["err"].append(max(np.abs(out[q] - ref[q]).max() / max(np.abs(ref[q]).max(), 1e-300) for q in range(4)))
     return tuple(out)
 
 
@@ -158,7 +197,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     probs = problems_benchmark(n)
     if len(sys.argv) > 2: probs += problems_closed_loop(sys.argv[2], 4 * n)
-    print("whole solves: sequential | partitioned (iterations, status), distance of the solutions")
+    print(f"whole solves: sequential | partitioned into {SEGMENTS} segments (iterations, status), distance of the solutions")
     tot = [0, 0]
     for label, P in probs:
         N.riccati_channel = SEQ_CHANNEL; a = N.solve(P)
