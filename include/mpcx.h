@@ -174,6 +174,11 @@ typedef struct {
  * compute unit's LDS instead of the global workspace (same kernel otherwise, same bits).  This flag keeps them on the
  * global-workspace kernel (measurements, tests). */
 #define MPCX_SOLVE_NO_LDS 32
+/* Time-parallel linear solve for small batches (at most one satellite per compute unit at once; larger batches queue): the
+ * horizon is cut into up to four segments whose Riccati recursions and sweeps run side by side on a pair of waves each and
+ * are joined by a coarse 7 x 7 recursion over the cuts.  Same Newton directions to ~1e-12 relative,
+ * same iteration counts, NOT the same bits as the other kernels -- which is why it is a flag and not the default. */
+#define MPCX_SOLVE_TIME_PARALLEL 64
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 /* Workspace of the _dev solves / fused steps.  The plain queries are device-independent upper bounds (one slot per

@@ -244,7 +244,7 @@ def iptr(a):
 
 
 SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
-SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF, SOLVE_ONE_WAVE, SOLVE_NO_LDS = 1, 2, 4, 8, 16, 32      # mpcx_solve_opts.flags (include/mpcx.h)
+SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF, SOLVE_ONE_WAVE, SOLVE_NO_LDS, SOLVE_TIME_PARALLEL = 1, 2, 4, 8, 16, 32, 64      # mpcx_solve_opts.flags (include/mpcx.h)
 
 
 def check_solver_keywords(solver):

@@ -38,7 +38,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
     c->copier = nullptr;
     c->counter = nullptr; c->launch_seq = 0; c->n_slots = prop.multiProcessorCount * 8;
-    c->red = nullptr; c->red_cap = 0; c->coop_max = 0;
+    c->red = nullptr; c->red_cap = 0; c->coop_max = 0; c->tp_max = 0;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;
     c->own_stream = true;

@@ -135,6 +135,7 @@ struct mpcx_ctx {
     int n_slots;              // single-wave workgroups of solve_kernel the device holds at once (compute units x 8)
     double *red;              // shared-tf launches: reduction slots + arrival counter + abort flag
     int red_cap, coop_max;    // coop_max: workgroups of solve_shared_kernel resident at once (0: not asked yet, -1: unsupported)
+    int tp_max;               // satellites the time-parallel kernel holds at once (0: not asked yet, -1: query failed)
     StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
     HostCopier *copier;                // worker threads of the pageable <-> page-locked copies (created on first use)
     std::vector<hipEvent_t> events;    // one per download of a host-pointer call: its copy-out starts when ITS transfer is done

@@ -12,6 +12,9 @@ using namespace mpcx;
 #define MPCX_TWO_WAVE_MAX 1024      // two waves per satellite pay up to one satellite per SIMD (profiles/r03/batch_size_sweep.txt)
 #endif
 constexpr int kTwoWaveMax = MPCX_TWO_WAVE_MAX;
+// MPCX_SOLVE_TIME_PARALLEL is honoured up to this many satellites (four workgroups each: 512 of them are two per compute unit);
+// larger batches take the kernels they would take without the flag -- the chip is then busy with whole satellites
+constexpr int kTimeParallelMax = 128;
 constexpr int kCounterRing = 64;    // work-queue counters per context: solves in flight at once on different streams
 
 static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
@@ -83,16 +86,20 @@ extern "C" void mpcx_default_solve_opts(mpcx_solve_opts *o)
     o->tol = 1e-8; o->acceptable_tol = 1e-6; o->max_iter = 200; o->acceptable_iter = 15; o->n_refine = 1; o->flags = 0;
 }
 
+// (ws_doubles_tp >= ws_doubles: the slot of the time-parallel kernel, MPCX_SOLVE_TIME_PARALLEL, so that one buffer serves any flags)
 extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
 {
-    return (size_t)S * ws_doubles(K) * sizeof(double);
+    return (size_t)S * ws_doubles_tp(K) * sizeof(double);
 }
 
 // what a solve on THIS context's device touches: one slot per persistent workgroup, min(S, workgroups resident at once)
+// (the time-parallel kernel: larger slots, at most one workgroup per compute unit)
 extern "C" size_t mpcx_solve_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K)
 {
     const int slots = (ctx && S > ctx->n_slots) ? ctx->n_slots : S;
-    return (size_t)slots * ws_doubles(K) * sizeof(double);
+    const int slots_tp = S <= kTimeParallelMax ? S : 0;
+    const size_t a = (size_t)slots * ws_doubles(K), b = (size_t)slots_tp * ws_doubles_tp(K);
+    return (a > b ? a : b) * sizeof(double);
 }
 
 extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const int32_t *Ks, const double *stage, const double *xbar,
@@ -182,6 +189,17 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     // tests/test_full_size_gpu.py::test_two_wave_small_batch_kernel).  MPCX_SOLVE_ONE_WAVE keeps the one-wave kernel.
     // at most one satellite per compute unit: the LDS-resident build (solve_lds.hip), if the horizon's working set fits
     int lds = 1;
+    if ((opts->flags & MPCX_SOLVE_TIME_PARALLEL) && S <= kTimeParallelMax) {
+        // the time-parallel kernel: four workgroups per satellite, each on its own compute unit while the batch is that small,
+        // all resident (they wait for each other); its own slot size, one slot per satellite; the satellites' mailboxes zeroed
+        if (ctx->tp_max == 0) { const int per_cu = mpcxtp_blocks_per_cu(); ctx->tp_max = per_cu > 0 ? per_cu * (ctx->n_slots / 8) / TP_MAXSEG : -1; }
+        if (ctx->tp_max < 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: occupancy query of the time-parallel kernel failed");
+        if (((S + 7) / 8) * 8 > ctx->tp_max) return ctx_fail(ctx, MPCX_E_BADARG, "solve: MPCX_SOLVE_TIME_PARALLEL takes at most as many satellites as the device holds their workgroups at once");
+        a.ws_stride = ws_doubles_tp(K);
+        MPCX_HIP(ctx, hipMemset2DAsync((double *)workspace + tp_mail_offset(K), a.ws_stride * sizeof(double), 0, TP_MAIL_N * sizeof(double), (size_t)S, (hipStream_t)stream));
+        if (mpcxtp_launch(&a, sizeof a, S, (hipStream_t)stream) != 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: time-parallel launch failed");
+        lds = 0;
+    } else
     if (S <= ctx->n_slots / 8 && !(opts->flags & (MPCX_SOLVE_ONE_WAVE | MPCX_SOLVE_NO_LDS))) {
         lds = mpcxl_launch(&a, sizeof a, slots, (hipStream_t)stream);
         if (lds < 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: LDS-resident launch failed");

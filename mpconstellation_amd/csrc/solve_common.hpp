@@ -13,6 +13,8 @@
 #ifdef MPCX_TWO_WAVE
 #ifdef MPCX_WS_LDS
 #define MPCX_NS mpcxl          // (solve_lds.hip: the two-wave kernel with its working set in LDS)
+#elif defined(MPCX_TP)
+#define MPCX_NS mpcxtp         // (solve_tp.hip: the time-parallel kernel, a pair of waves per segment of the horizon)
 #else
 #define MPCX_NS mpcx2w
 #endif
@@ -25,4 +27,7 @@
 
 #include "solve_phases.hpp"
 #include "solve_riccati.hpp"
+#ifdef MPCX_TP
+#include "solve_tp.hpp"
+#endif
 #include "solve_driver.hpp"

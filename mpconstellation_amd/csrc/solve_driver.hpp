@@ -79,6 +79,13 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     //  base) back into a second pointer and emit a branch with one store per path)
     s.o_fac = (int)(KP * (3 * IT_N + NS_N + MPCX_STAGE_DOUBLES + 3) + K * NB_N);
     s.o_ch = s.o_fac + K * FAC_N; s.o_traj = s.o_ch + K * CH_N; s.o_sink = s.o_traj + K * NCH * TR_N + 3 * GL_N;
+#ifdef MPCX_TP
+    // behind the other kernels' layout for the call's row length (ws_doubles_tp): the extra backward record, the second
+    // trajectory bank, the mailbox of the satellite's workgroups and their exchange records
+    s.chx = s.ws + tp_extras_offset(Kmax); s.trajx = s.chx + (size_t)Kmax * CHX_N;
+    s.o_trajx = (int)(tp_extras_offset(Kmax) + (size_t)Kmax * CHX_N);
+    s.mail = (int *)(s.ws + tp_mail_offset(Kmax)); s.xch = s.ws + tp_mail_offset(Kmax) + TP_MAIL_N;
+#endif
 #endif
     return s;
 }
@@ -315,6 +322,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
             first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
+#ifndef MPCX_TP                 // (the shared-tf launch has its own kernel, solve.hip)
             if (SHARED) {
                 // ---- the same direction computation in lock step with the other satellites of the launch ----
                 GridSync &g = *gsync;
@@ -370,6 +378,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
                 continue;
             }
+#endif
             // iterative refinement only once a barrier weight (terminal rank-1 terms, stage balls and planes, the tf
             // bounds) is stiff enough to cost digits
             double twmax = sd.sigmax;
@@ -377,7 +386,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
             if (passes > 1) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);      // (the scalars reduced_residual reads)
             PT_BEGIN
+#ifdef MPCX_TP
+            bool ok = tp_cmd_factor(s, sd, g_tp, lane, passes > 1);       // every segment's factorisation + fused backward sweeps, side by side
+            if (g_tp.dead) break;                                         // (a workgroup of the satellite did not answer: MPCX_ST_NUMERIC)
+#else
             bool ok = riccati_factor(s, sd, w, lane, true, passes > 1);   // factorisation + backward sweep of all 8 channels
+#endif
             PT_END(2)
 #ifdef MPCX_ITER_LOG
             if (!ok) fail_mask += 1;
@@ -393,6 +407,19 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                     }
                     // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only
                     const int c1 = (pass == 0) ? NCH : 1;
+#ifdef MPCX_TP
+                    // the segments' sweeps side by side (all waves), then the coarse problem over the cuts: x_K and Sigma . lam of
+                    // every channel for the border
+                    PT_BEGIN
+                    (void)c1;
+                    if (pass > 0) tp_cmd_sweeps(s, sd, g_tp, lane, false);      // (the first pass's sweeps ran behind the factorisation)
+                    PT_END(3)
+                    if (g_tp.dead) { ok = false; break; }
+                    PT_BEGIN
+                    ok = tp_coarse(s, sd, g_tp, lane, pass == 0);
+                    if (ok && pass == 0) ok = border_factor(sd, lane);
+                    PT_END(4)
+#else
                     if (pass > 0) {
                         PT_BEGIN
                         sweep_backward(s, sd, w, 0, c1, lane);
@@ -402,6 +429,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                     sweep_forward(s, sd, w, 0, c1, lane);
                     if (pass == 0) ok = border_factor(sd, lane);
                     PT_END(4)
+#endif
 #ifdef MPCX_ITER_LOG
                     if (!ok) fail_mask += 100;
 #endif
@@ -422,7 +450,11 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                         lg[n++] = sd.Wtf; lg[n++] = sd.gam; lg[n++] = delta_w;
                     }
 #endif
+#ifdef MPCX_TP
+                    tp_combine(s, sd, g_tp, (double *)&w, lane, pass == 0);
+#else
                     combine_channels(s, sd, (double *)&w, lane, pass == 0);
+#endif
                     PT_END(7)
                 }
             }
@@ -538,7 +570,9 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 // The two kernels' LDS working set: ONE pair of module-scope objects, so that it sits at the same LDS address in both and
 // the out-of-line phase functions (which take it by reference) keep addressing it with compile-time offsets -- with a
 // pair per kernel the addresses reach them as run-time pointers (measured: solve_kernel 6.85 -> 8.4 ms at S4096).
+#ifndef MPCX_TP          // (the time-parallel build defines them ahead of its own functions: solve_tp.hpp)
 __shared__ SatData g_sd;
 __shared__ Scratch g_w;
+#endif
 
 }  // namespace MPCX_NS

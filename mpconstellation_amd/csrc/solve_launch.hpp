@@ -24,3 +24,7 @@ int mpcx2w_launch(const void *args, size_t args_bytes, int blocks, hipStream_t s
 // solve_lds.hip: the same kernel with the satellite's working set in LDS (at most one satellite per compute unit at a time);
 // returns 1 without launching when the working set of the call's node count does not fit
 int mpcxl_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);
+// solve_tp.hip: the time-parallel kernel (a workgroup of two waves per segment of the horizon, four per satellite, cooperative
+// launch; MPCX_SOLVE_TIME_PARALLEL); blocks = satellites
+int mpcxtp_launch(const void *args, size_t args_bytes, int blocks, hipStream_t stream);
+int mpcxtp_blocks_per_cu();

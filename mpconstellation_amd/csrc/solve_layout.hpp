@@ -93,6 +93,27 @@ __host__ __device__ inline size_t lds_ws_doubles(int K)
     return KP * (3 * IT_N + 3) + (size_t)K * (NB_N + FAC_N + CH_N) + 3 * GL_N + 64;
 }
 
+// ---- time-parallel build (solve_tp.hip, MPCX_SOLVE_TIME_PARALLEL): the horizon cut into segments, a pair of waves each ----
+// DESIGN.md section 8 / tests/tools/partitioned_riccati.py: every segment but the last runs the recursion from a zero
+// cost-to-go and carries, beside the right-hand side and the dtf channel, seven unit-price channels (terminal price e_i on the
+// state behind its last node) and seven unit-state channels (start state e_i); a coarse 7 x 7 recursion over the cuts joins them.
+constexpr int TP_MAXSEG = 4;
+constexpr int CHX_N = 10;             // per node: backward vectors (p 7, qu 3) of the right-hand-side channel of a segment whose lane groups carry the price channels
+__host__ __device__ inline int tp_segments(int K) { return K >= 24 ? 4 : (K >= 8 ? 2 : 1); }
+__host__ __device__ inline int tp_cut(int K, int nseg, int j) { return (j * K) / nseg; }      // segment j = nodes tp_cut(j) .. tp_cut(j+1)-1
+// what a segment's workgroup hands to the one that runs the coarse problem (global memory): W, N, Phi, the ends of its local
+// trajectories and the Sigma . lam sums of its trajectories
+constexpr int TP_XCH_N = 256, TP_MAIL_N = 16;
+// slot workspace of the time-parallel kernel: the other kernels' slot for the call's row length K, then the extra backward
+// record, a second bank of 8 trajectories per node, the mailbox of the satellite's workgroups and their exchange records
+__host__ __device__ inline size_t tp_extras_offset(int K) { return ws_doubles(K); }
+__host__ __device__ inline size_t tp_mail_offset(int K) { return ws_doubles(K) + (size_t)K * (CHX_N + NCH * TR_N); }
+__host__ __device__ inline size_t ws_doubles_tp(int K)
+{
+    const size_t n = tp_mail_offset(K) + TP_MAIL_N + (size_t)TP_MAXSEG * TP_XCH_N;
+    return (n + 15) & ~(size_t)15;
+}
+
 constexpr int GR_SUM = 6, GR_MAX = 3, GR_MIN = 3, GR_N = GR_SUM + GR_MAX + GR_MIN;      // launch-wide reductions of the shared-tf mode (solve_riccati.hpp: grid_reduce)
 constexpr int kPredHist = 8;      // solves whose iteration counts the launch-order predictor remembers (solve.hip: update_prediction_kernel)
 }  // namespace mpcx

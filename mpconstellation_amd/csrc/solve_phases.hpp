@@ -321,6 +321,11 @@ struct Sat {
     gf64 *wsg;                                  // base of the global part (o_traj, o_sinkg count from here; o_fac, o_ch, o_sink from ws in LDS)
     int o_sinkg;
 #endif
+#ifdef MPCX_TP
+    gf64 *chx, *trajx;                          // time-parallel build: the extra backward record (K x CHX_N), the second bank of
+    int o_trajx;                                // eight trajectory slots per node, the satellite's mailbox and exchange records
+    int *mail; gf64 *xch;                       // (solve_tp.hpp)
+#endif
     __device__ Col<wf64> itn(int k) const { return Col<wf64>{wave_uniform(it), k, KP}; }
     __device__ Col<wf64> itBn(int k) const { return Col<wf64>{wave_uniform(itB), k, KP}; }
     __device__ Col<wf64> drn(int k) const { return Col<wf64>{wave_uniform(dr), k, KP}; }
@@ -353,6 +358,10 @@ __device__ __forceinline__ Sat uniform_view(const Sat &v)
     s.sink = wave_uniform(v.sink); s.ws = wave_uniform(v.ws);
 #ifdef MPCX_WS_LDS
     s.wsg = wave_uniform(v.wsg); s.o_sinkg = __builtin_amdgcn_readfirstlane(v.o_sinkg);
+#endif
+#ifdef MPCX_TP
+    s.chx = wave_uniform(v.chx); s.trajx = wave_uniform(v.trajx); s.o_trajx = __builtin_amdgcn_readfirstlane(v.o_trajx);
+    s.mail = wave_uniform(v.mail); s.xch = wave_uniform(v.xch);
 #endif
     s.o_fac = __builtin_amdgcn_readfirstlane(v.o_fac); s.o_ch = __builtin_amdgcn_readfirstlane(v.o_ch);
     s.o_traj = __builtin_amdgcn_readfirstlane(v.o_traj); s.o_sink = __builtin_amdgcn_readfirstlane(v.o_sink);

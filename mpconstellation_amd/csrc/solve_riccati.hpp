@@ -61,6 +61,9 @@ struct Scratch {   // LDS working set of the recursion (and, between recursions,
     double WlLi1[98];              // the second wave's own L^-1 [Pn | I]
     int cmd, cmd_arg, good_flag;   // command of the first wave to the second (solve2w.hip), breakdown flag of a node
 #endif
+#ifdef MPCX_TP
+    double flatB[2][FLAT_N];       // the pair's second wave sweeps its own channels at the same time: its own staging buffers
+#endif
     double Pn[49], WlLi[98], Qyy[49];
     double T[7 * FS];              // Pt F = [Pt A | Pt Bh]
     double sink[64];               // target of the lanes that have nothing to write in a branch-free phase
@@ -269,6 +272,24 @@ __device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double
 
 
 #ifdef MPCX_TWO_WAVE
+#ifdef MPCX_TP
+// Time-parallel build: the workgroup (a pair of waves) factorises the nodes lo .. hi-1 of its segment from a zero cost-to-go
+// behind node hi-1 (the last segment, hi = K, has the terminal node as before).  Lane groups of the fused backward sweep of a
+// segment that is not the last: group 0 the dtf channel, groups 1..7 the unit prices e_0..e_6 on the state behind node hi-1
+// (the right-hand-side channel of such a segment is swept on its own afterwards: nine channels, eight groups).
+struct TpRange { int lo, hi; bool last; double *Wout; };
+#define RF_ARGS , const TpRange &rg
+#define RF_HI rg.hi
+#define RF_LO rg.lo
+#define RF_LAST rg.last
+#define RF_GOOD w.good_flag
+#else
+#define RF_ARGS
+#define RF_HI K
+#define RF_LO 0
+#define RF_LAST true
+#define RF_GOOD w.good_flag
+#endif
 // The same factorisation shared by the two waves of a small-batch workgroup (role 0 / role 1), one hardware barrier per node.
 // Role 0 keeps what the next node waits for -- the critical chain P_{k+1} -> LDL^T -> X1 -> Pt -> T = Pt F -> S = F^T T ->
 // Q_uu^-1 -> P_k -- and the operand prefetch; role 1 takes everything else off that chain: its own (redundant) LDL^T for
@@ -276,7 +297,7 @@ __device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double
 // in another operand buffer) and all stores to the factor record.  Every element is computed by the same expressions as in
 // the one-wave form (bit-identical results: the library is built with -ffp-contract=on).  ~7 750 -> ~4 800 cycles per node for a wave that is alone on its
 // SIMD (64 satellites on a 1024-SIMD chip: the small-batch regime of BASELINE configs[1]).
-__device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scratch &w, int lane, int role, bool keep_pt)
+__device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scratch &w, int lane, int role, bool keep_pt RF_ARGS)
 {
     const Sat s = uniform_view(s_in);
     const int K = s.K;
@@ -329,11 +350,11 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
         if (e2 < OPS_IN) *(double *)(base + slot2) = (e2 < 149 || e2 >= 156 || dynk) ? pre[2] : 0.0;
     };
     if (role == 1) {                     // (the operand prefetch is the second wave's: it has the slack)
-        fetch(K - 1);
-        stash(w.ops[(K - 1) % 3], K - 1);
-        if (lane < 49) w.ops[(K - 1) % 3].G2[(lane / 7) * FS + lane % 7] = sd.WxK[lane];
+        fetch(RF_HI - 1);
+        stash(w.ops[(RF_HI - 1) % 3], RF_HI - 1);
+        if (RF_LAST && lane < 49) w.ops[(RF_HI - 1) % 3].G2[(lane / 7) * FS + lane % 7] = sd.WxK[lane];
     } else {
-        for (int e = lane; e < 49; e += 64) w.Pn2[K & 1][e] = 0.0;       // P_K = 0 (read as "P of node k+1" by node K-1)
+        for (int e = lane; e < 49; e += 64) w.Pn2[RF_HI & 1][e] = 0.0;       // P_K = 0 (read as "P of node k+1" by node K-1)
         if (lane == 0) { w.zero = 0.0; w.good_flag = 1; }
     }
     WG_BARRIER();
@@ -354,7 +375,8 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
     // ---- role 1: the fused backward sweep, one node behind (same arithmetic as sweep_backward) ----
     ChanIn cur{0.0, 0.0, 0.0, 0.0};
     ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
-    double pnext = 0.0;
+    const int scl = RF_LAST ? sc : (sc == 0 ? 1 : 2);        // the group's channel as chan_fetch / chan_mask know it (2: no stage data)
+    double pnext = RF_LAST ? 0.0 : ((sc >= 1 && sr == sc - 1) ? 1.0 : 0.0);
     auto sweep_node = [&](const StageOps &o, int j) {        // node j's p, qu from its complete operand buffer
         const bool dynj = (j <= K - 2);
         double sw_G[7], sw_Pt[7];
@@ -390,7 +412,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
         ustore(s.ws, on21 ? fb + F_BH + lane : sink_e, o.F[(l21 / 3) * FS + 7 + l21 % 3]);
         ustore(s.ws, lane < 9 ? fb + F_QI + lane : sink_e, o.Qi[lane < 9 ? lane : 0]);
     };
-    for (int k = K - 1; k >= 0; --k) {
+    for (int k = RF_HI - 1; k >= RF_LO; --k) {
         StageOps &o = w.ops[k % 3];
         const double *Pn = w.Pn2[(k + 1) & 1];
         const bool dyn = (k <= K - 2);
@@ -451,7 +473,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
                 for (int l = 0; l < 7; ++l) a1 += w.WlLi[l * 14 + lo] * (rd[l] * w.WlLi[l * 14 + hi]);
                 const double pt = dyn ? Pn[lo * 7 + hi] - a1 : 0.0;
                 *(on ? &o.Pt[lane] : &w.sink[lane]) = pt;
-                if (keep_pt) ustore(s.ws, on ? s.o_fac + k * FAC_N + F_PT + lane : sink_e, pt);
+                if (keep_pt || !RF_LAST) ustore(s.ws, on ? s.o_fac + k * FAC_N + F_PT + lane : sink_e, pt);    // (a segment that is not the last sweeps its right-hand-side channel on its own: that sweep reads Pt)
                 wsync();
             }
             // P5
@@ -511,11 +533,11 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
                 wsync();
                 stiff_stage_update2(o, w, w.Pn2[k & 1], lane);
             }
-            if (!__all(good) && lane == 0) w.good_flag = 0;
+            if (!__all(good) && lane == 0) RF_GOOD = 0;
         } else {
             // ---- role 1 ----
-            if (k >= 1) fetch(k - 1);
-            nraw = chan_fetch(s, k, sc, srr, sr3);
+            if (k > RF_LO) fetch(k - 1);
+            nraw = chan_fetch(s, k, scl, srr, sr3);
             if (dyn) {
                 double m[28], rd[7];
 #pragma unroll
@@ -577,26 +599,30 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
                 ustore(s.ws, on ? fb + F_G + lane : sink_e, 0.0);
                 ustore(s.ws, on ? fb + F_MINV + lane : sink_e, 0.0);
             }
-            if (dyn) sweep_node(w.ops[(k + 1) % 3], k + 1);          // node k+1: complete since the last barrier
+            if (k + 1 < RF_HI) sweep_node(w.ops[(k + 1) % 3], k + 1);          // node k+1: complete since the last barrier
             // inputs of node k for its sweep in the next slot
-            cur = chan_mask(nraw, sc, sr, sact);
+            cur = chan_mask(nraw, scl, sr, sact);
             if (!dyn) {
                 const double tg = (sc == 2) ? sd.avt[srr] : sd.ta[sc >= 3 ? sc - 3 : 0][srr];
                 cur.gx = (sact && sc >= 2) ? tg : cur.gx;
                 cur.rho = 0.0; cur.aff = 0.0;
             }
-            if (k >= 1) stash(w.ops[(k - 1) % 3], k - 1);
+            if (k > RF_LO) stash(w.ops[(k - 1) % 3], k - 1);
         }
         WG_BARRIER();
-        if (w.good_flag == 0) { good = false; break; }
+        if (RF_GOOD == 0) { good = false; break; }
     }
-    if (role == 1 && good) sweep_node(w.ops[0], 0);
+#ifdef MPCX_TP
+    if (role == 0 && good && lane < 49) rg.Wout[lane] = w.Pn2[RF_LO & 1][lane];      // the segment's cost-to-go Hessian at its first node
+#endif
+    if (role == 1 && good) sweep_node(w.ops[RF_LO % 3], RF_LO);
     WG_BARRIER();
     return good;
 }
 
 // What the first wave's driver calls: tell the second wave (parked in solve_kernel2w's command loop) to join, take role 0.
-enum { CMD_FACTOR = 1, CMD_EXIT = 2 };
+enum { CMD_FACTOR = 1, CMD_EXIT = 2, CMD_SWEEP = 3 };
+#ifndef MPCX_TP
 __device__ __forceinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
 {
     (void)fuse_sweep;                              // (the backward sweep always rides along: it is the second wave's)
@@ -604,6 +630,7 @@ __device__ __forceinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratc
     WG_BARRIER();
     return riccati_factor2(s, sd, w, lane, 0, keep_pt);
 }
+#endif
 #else
 // Backward Riccati sweep: factorisation (DESIGN.md "Solver algorithm").  Returns false on breakdown.
 // With fuse_sweep the backward linear-term sweep of all 8 channels rides along: node k's p_k, qu_k are formed
@@ -993,7 +1020,18 @@ __device__ __forceinline__ void sweep_stash_mats(double *f, int K, int k, int la
 #endif
 
 // Backward sweep for channels [c0, c1): p_k and qu_k stored per channel.
-__device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane)
+// (time-parallel build: over the nodes lo .. hi-1 of a segment from p = 0 behind node hi-1; chx: the right-hand-side channel
+//  of a segment that is not the last -- its vectors go to the extra record, the channel slots there hold dtf and the prices)
+#ifdef MPCX_TP
+#define SB_ARGS , int sb_lo, int sb_hi, gf64 *chx
+#define SB_LO sb_lo
+#define SB_HI sb_hi
+#else
+#define SB_ARGS
+#define SB_LO 0
+#define SB_HI K
+#endif
+__device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratch &w, int c0, int c1, int lane SB_ARGS)
 {
     const Sat s = uniform_view(s_in);
     const int K = s.K;
@@ -1001,15 +1039,15 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
     const bool act = (c >= c0 && c < c1) && r < 7;
     const int rr = (r < 7) ? r : 6, r3 = (r < 3) ? r : 2;
     SweepPre pre;
-    sweep_fetch_mats<true>(s, K - 1, lane, pre);
-    sweep_stash_mats(w.flat[(K - 1) & 1], K, K - 1, lane, pre);
-    ChanIn cur = chan_inputs(s, sd, K - 1, c, r, act), nxt = cur;
+    sweep_fetch_mats<true>(s, SB_HI - 1, lane, pre);
+    sweep_stash_mats(w.flat[(SB_HI - 1) & 1], K, SB_HI - 1, lane, pre);
+    ChanIn cur = chan_inputs(s, sd, SB_HI - 1, c, r, act), nxt = cur;
     double pnext = 0.0;
     WG_SYNC();
-    for (int k = K - 1; k >= 0; --k) {
+    for (int k = SB_HI - 1; k >= SB_LO; --k) {
         const double *f = w.flat[k & 1];
         const auto fr = FAC_AT(s, f, k);               // the node's factor record (its LDS home, or the staged copy)
-        if (k >= 1) { sweep_fetch_mats<true>(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
+        if (k > SB_LO) { sweep_fetch_mats<true>(s, k - 1, lane, pre); nxt = chan_inputs(s, sd, k - 1, c, r, act); }
         const bool dyn = (k <= K - 2);
         double Grow[7], Ptrow[7], Acol[7], Bpmcol[7], Bhcol[7], Kgcol[3];
 #pragma unroll
@@ -1034,12 +1072,21 @@ __device__ __noinline__ void sweep_backward(const Sat &s_in, SatData &sd, Scratc
 #pragma unroll
         for (int q = 0; q < 3; ++q) p -= Kgcol[q] * gshfl8(qu, q);
         if (act) {
+#ifdef MPCX_TP
+            if (chx) {
+                gf64 *cx = chx + (size_t)k * CHX_N;
+                cx[r] = p;
+                if (r < 3) cx[7 + r] = qu;
+            } else
+#endif
+            {
             wf64 *ch = s.ch + (size_t)k * CH_N;
             ch[C_P + c * 7 + r] = p;
             if (r < 3) ch[C_QU + c * 3 + r] = qu;
+            }
             pnext = p;
         }
-        if (k >= 1) sweep_stash_mats(w.flat[(k - 1) & 1], K, k - 1, lane, pre);
+        if (k > SB_LO) sweep_stash_mats(w.flat[(k - 1) & 1], K, k - 1, lane, pre);
         cur = nxt;
         wsync();
     }
