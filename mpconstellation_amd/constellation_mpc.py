@@ -24,7 +24,8 @@ from .simulator import propagate_batch
 
 class ConstellationMPC:
     def __init__(self, sats, base_res=100, tf_horizon=1, tf_interval=1, r_des=1.5, scp_iterations=2, sim_base_res=100,
-                 include_drag=True, include_J2=True, device=0, strict=False, scales=None, verbose=False, devices=None):
+                 include_drag=True, include_J2=True, device=0, strict=False, scales=None, verbose=False, devices=None,
+                 time_parallel=False):
         self.sats = list(sats)
         # every satellite in its own "designer units" (so that each sees MU = 4 pi^2) unless the caller brings the scales
         self.scales = list(scales) if scales is not None else [SatelliteScale(sat=s) for s in self.sats]
@@ -40,6 +41,9 @@ class ConstellationMPC:
         # context per device, no exchange between them (sharding.sharded_call) -- the reference loops over
         # its satellites serially (simulator.py:41,58)
         self.devices = list(devices) if devices is not None else None
+        # time_parallel: the solves of small constellations (up to 128 satellites) on the time-parallel kernel (include/mpcx.h,
+        # MPCX_SOLVE_TIME_PARALLEL: the horizon in four segments side by side; same iterations, not the other kernels' bits)
+        self.solver_flags = _ffi.SOLVE_TIME_PARALLEL if time_parallel else 0
         self.strict = strict                  # raise instead of warning when a solve does not converge (control.py mirror)
         # per-satellite unit factors as vectors: the whole constellation is (re)dimensionalised in one array expression
         # (satellite_scale.py:46-100: r / r0, v / v0, m / m0 and back)
@@ -124,7 +128,8 @@ class ConstellationMPC:
             flown = None
         else:
             res = self._timed("update", mpc_update_batch, y0, float(self.horizon), self.consts, self.r_des, self.base_res,
-                              n_scp=self.scp_iterations, options=opts, device=self.device, fly=fly, devices=self.devices)
+                              n_scp=self.scp_iterations, options=opts, device=self.device, fly=fly, devices=self.devices,
+                              flags=self.solver_flags)
             self._check(res.prop_status)
             self.last_status = res.status; self.last_iters = res.iters
             for it in range(self.scp_iterations):
@@ -148,7 +153,7 @@ class ConstellationMPC:
         res = None
         for it in range(self.scp_iterations):
             res = self._timed("update", scp_iteration_batch, y0, tf_u, self.consts, self.r_des, law, K, options=opts,
-                              Ks=Ks, Kus=Kus, device=self.device)
+                              Ks=Ks, Kus=Kus, device=self.device, flags=self.solver_flags)
             self._check(res.prop_status)
             self.last_status[it] = res.status; self.last_iters[it] = res.iters
             _check_solver_status(res.status, self.strict)
