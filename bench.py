@@ -275,11 +275,12 @@ def host_pointer_rate(h, S, local_rank, reps=20):
                     "(mpcx_host_alloc); `pageable`: ordinary numpy arrays, staged through the context's pinned pool"}
 
 
-def also_workload(name, steps, warmup, local_rank, note, with_host=False):
+def also_workload(name, steps, warmup, local_rank, note, with_host=False, flags=0):
     """one more BASELINE config measured in the same run under the driver's clock (its own Runner, steps, warmup)"""
     import torch
     S, K, n_scp = WORKLOADS[name]
     r = Runner(name, 0, 1, local_rank)
+    r.opts.flags = flags
     e, sm = measure(r, steps, warmup, 1)
     st, it, kk = r.solver_stats()
     out = {"value": S * steps / e, "unit": "satellite-MPC-steps/s", "steps": steps, "warmup": warmup,
@@ -295,7 +296,7 @@ def also_workload(name, steps, warmup, local_rank, note, with_host=False):
     return out
 
 
-def closed_loop(S, local_rank, segments=2):
+def closed_loop(S, local_rank, segments=2, time_parallel=False):
     """The metric's "MPC steps/sec (whole constellation)" for the loop the hot path sits in: ConstellationMPC.run_segments
     in the reference's test_mpc configuration (test_simulator.py:79-98: base_res 30, tf_horizon 2, two segments, r_des 1.5,
     truth model with drag + J2 at base_res 100).  One constellation-MPC-step = controller.update() for every satellite
@@ -305,8 +306,8 @@ def closed_loop(S, local_rank, segments=2):
     from mpconstellation_amd.constellation import constellation_states
     st = constellation_states(S)
     make = lambda: [Satellite(s[:3].copy(), s[3:6].copy(), float(s[6])) for s in st]
-    ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank).run_segments(tf=2, num_segments=1)   # warm-up: workspaces, staging pools
-    mpc = ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank)
+    ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank, time_parallel=time_parallel).run_segments(tf=2, num_segments=1)   # warm-up: workspaces, staging pools
+    mpc = ConstellationMPC(make(), base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, sim_base_res=100, device=local_rank, time_parallel=time_parallel)
     t0 = time.perf_counter()
     mpc.run_segments(tf=2, num_segments=segments)
     dt = time.perf_counter() - t0
@@ -424,12 +425,16 @@ def main():
             out["also"] = {
                 "S64_K30": also_workload("S64_K30", args.steps, args.warmup, local_rank,
                                          "BASELINE configs[1] (64 satellites: 64 of the chip's 1024 SIMDs busy), same run", with_host=True),
+                "S64_K30_time_parallel": also_workload("S64_K30", args.steps, args.warmup, local_rank,
+                                                       "the same 64 satellites on the time-parallel kernel (MPCX_SOLVE_TIME_PARALLEL: four segments of the horizon side by "
+                                                       "side, a workgroup each; same iterations, not the default kernels' bits), same run", flags=64),
                 "S4096_K100_scp2": also_workload("S4096_K100_scp2", 3, 1, local_rank,
                                                  "BASELINE configs[3]: K = 100, 2 SCP iterations with device re-rollout per step, same run"),
                 "S8192_K30": also_workload("S8192_K30", 5, 1, local_rank,
                                            "one GPU's share of BASELINE configs[4] (65 536 satellites over 8 GPUs), same run"),
             }
             out["closed_loop"] = {f"S{n}": closed_loop(n, local_rank) for n in (64, 4096)}
+            out["closed_loop"]["S64_time_parallel"] = closed_loop(64, local_rank, time_parallel=True)
         if also_multi: out["also"] = also_multi
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], err = cpu_baseline(h["xbar"], h["ubar"], h["tfbar"], h["consts"], h["r_des"], args.cpu_sample, dev_res)

@@ -100,7 +100,13 @@ __host__ __device__ inline size_t lds_ws_doubles(int K)
 constexpr int TP_MAXSEG = 4;
 constexpr int CHX_N = 10;             // per node: backward vectors (p 7, qu 3) of the right-hand-side channel of a segment whose lane groups carry the price channels
 __host__ __device__ inline int tp_segments(int K) { return K >= 24 ? 4 : (K >= 8 ? 2 : 1); }
-__host__ __device__ inline int tp_cut(int K, int nseg, int j) { return (j * K) / nseg; }      // segment j = nodes tp_cut(j) .. tp_cut(j+1)-1
+// segment j = nodes tp_cut(j) .. tp_cut(j+1)-1.  The last segment is longer: its workgroup has no right-hand-side sweep of its own
+// to run behind the factorisation (it is fused there) and starts before the others have seen the command -- 7 / 7 / 7 / 9 of 30.
+__host__ __device__ inline int tp_cut(int K, int nseg, int j)
+{
+    if (j >= nseg) return K;
+    return nseg == 4 ? (j * 7 * K) / 30 : (j * K) / nseg;
+}
 // what a segment's workgroup hands to the one that runs the coarse problem (global memory): W, N, Phi, the ends of its local
 // trajectories and the Sigma . lam sums of its trajectories
 constexpr int TP_XCH_N = 256, TP_MAIL_N = 16;

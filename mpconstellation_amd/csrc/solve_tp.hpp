@@ -90,8 +90,8 @@ __device__ __forceinline__ void tp_acquire(bool light)
 __device__ __forceinline__ void tp_pause(int spins)
 {
     if (spins < 8) __builtin_amdgcn_s_sleep(2);
-    else if (spins < 64) __builtin_amdgcn_s_sleep(16);
-    else __builtin_amdgcn_s_sleep(64);
+    else if (spins < 64) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(24);
 }
 __device__ __forceinline__ int tp_xcc_id() { return (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15; }      // HW_REG_XCC_ID[3:0]
 
