@@ -15,6 +15,9 @@ constexpr int kTwoWaveMax = MPCX_TWO_WAVE_MAX;
 // MPCX_SOLVE_TIME_PARALLEL is honoured up to this many satellites (four workgroups each: 512 of them are two per compute unit);
 // larger batches take the kernels they would take without the flag -- the chip is then busy with whole satellites
 constexpr int kTimeParallelMax = 128;
+// ... and from this row length on: four segments (below, two segments or one do not pay for the exchange between the workgroups:
+// 1.53 against 1.38 ms at 16 nodes; satellites of a ragged batch with fewer nodes than that are still solved, in two segments or one)
+constexpr int kTimeParallelMinK = 24;
 constexpr int kCounterRing = 64;    // work-queue counters per context: solves in flight at once on different streams
 
 static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
@@ -97,7 +100,7 @@ extern "C" size_t mpcx_solve_workspace_bytes(int S, int K)
 extern "C" size_t mpcx_solve_workspace_bytes_ctx(const mpcx_ctx *ctx, int S, int K)
 {
     const int slots = (ctx && S > ctx->n_slots) ? ctx->n_slots : S;
-    const int slots_tp = S <= kTimeParallelMax ? S : 0;
+    const int slots_tp = (S <= kTimeParallelMax && K >= kTimeParallelMinK) ? S : 0;
     const size_t a = (size_t)slots * ws_doubles(K), b = (size_t)slots_tp * ws_doubles_tp(K);
     return (a > b ? a : b) * sizeof(double);
 }
@@ -189,7 +192,7 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     // tests/test_full_size_gpu.py::test_two_wave_small_batch_kernel).  MPCX_SOLVE_ONE_WAVE keeps the one-wave kernel.
     // at most one satellite per compute unit: the LDS-resident build (solve_lds.hip), if the horizon's working set fits
     int lds = 1;
-    if ((opts->flags & MPCX_SOLVE_TIME_PARALLEL) && S <= kTimeParallelMax) {
+    if ((opts->flags & MPCX_SOLVE_TIME_PARALLEL) && S <= kTimeParallelMax && K >= kTimeParallelMinK) {
         // the time-parallel kernel: four workgroups per satellite, each on its own compute unit while the batch is that small,
         // all resident (they wait for each other); its own slot size, one slot per satellite; the satellites' mailboxes zeroed
         if (ctx->tp_max == 0) { const int per_cu = mpcxtp_blocks_per_cu(); ctx->tp_max = per_cu > 0 ? per_cu * (ctx->n_slots / 8) / TP_MAXSEG : -1; }

@@ -50,8 +50,8 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*", ""))):
 import hashlib
 # the kernel sources these counters belong to: bench.py reports them only for exactly this code (the C entry points --
 # solve_api.hip, api.hip, mpcx_host.hpp -- are not kernel sources: editing them leaves the profiles valid)
-KERNEL_SOURCES = ("solve.hip", "solve2w.hip", "solve_lds.hip", "solve_kernel2w.hpp", "solve_common.hpp", "solve_layout.hpp", "solve_phases.hpp", "solve_riccati.hpp",
-                  "solve_driver.hpp", "discretize.hip", "mpcx_device.hpp")
+KERNEL_SOURCES = ("solve.hip", "solve2w.hip", "solve_lds.hip", "solve_tp.hip", "solve_tp.hpp", "solve_kernel2w.hpp", "solve_common.hpp", "solve_layout.hpp", "solve_phases.hpp",
+                  "solve_riccati.hpp", "solve_driver.hpp", "discretize.hip", "mpcx_device.hpp")
 source_hashes = {f: hashlib.sha256(open(os.path.join(root, "..", "mpconstellation_amd", "csrc", f), "rb").read()).hexdigest()
                  for f in KERNEL_SOURCES}
 build_flags = None
