@@ -105,7 +105,10 @@ __host__ __device__ inline int tp_segments(int K) { return K >= 24 ? 4 : (K >= 8
 __host__ __device__ inline int tp_cut(int K, int nseg, int j)
 {
     if (j >= nseg) return K;
-    return nseg == 4 ? (j * 7 * K) / 30 : (j * K) / nseg;
+#ifndef MPCX_TP_LASTFRAC
+#define MPCX_TP_LASTFRAC 9           // the last segment's share of the horizon in thirtieths (the others share the rest evenly)
+#endif
+    return nseg == 4 ? (j * (30 - MPCX_TP_LASTFRAC) * K) / 90 : (j * K) / nseg;
 }
 // what a segment's workgroup hands to the one that runs the coarse problem (global memory): W, N, Phi, the ends of its local
 // trajectories and the Sigma . lam sums of its trajectories

@@ -18,7 +18,8 @@ Both backward recursions run side by side (m and K - m nodes), then both forward
 of the benchmark constellation and of the closed loop's stiff-window problems, (a) that the partitioned solve returns the
 sequential one's direction and to how many digits, (b) that whole solves run with it take the same iterations.
 
-usage: python tests/tools/partitioned_riccati.py [n_satellites] [closed_loop_cache.pkl]
+(csrc/solve_tp.hip / solve_tp.hpp are this algebra on the device, four segments of 7 / 7 / 7 / 9 thirtieths of the horizon.)
+usage: [SEGMENTS=2|3|4] python tests/tools/partitioned_riccati.py [n_satellites] [closed_loop_cache.pkl]
 (the cache is what closed_loop_start_rules.py gen writes; without it only the benchmark set runs)"""
 import os, pickle, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
@@ -92,9 +93,19 @@ SEGMENTS = int(os.environ.get("SEGMENTS", "2"))
 def spd_solve(Nm, W, r):
     """(I + N W)^-1 r through the similar symmetric positive definite I + L'N L, W = L L' (no pivoting: what a kernel can do in
     registers); the pivoted LAPACK solve beside it is recorded in STATS["spd"]"""
-    L = np.linalg.cholesky(0.5 * (W + W.T)); Ns = 0.5 * (Nm + Nm.T)
-    Ls = np.linalg.cholesky(np.eye(7) + L.T @ Ns @ L)
-    z = np.linalg.solve(L.T, np.linalg.solve(Ls.T, np.linalg.solve(Ls, L.T @ r)))
+    Ns = 0.5 * (Nm + Nm.T); Ws = 0.5 * (W + W.T)
+    try:
+        L = np.linalg.cholesky(Ws)
+        Ls = np.linalg.cholesky(np.eye(7) + L.T @ Ns @ L)
+        z = np.linalg.solve(L.T, np.linalg.solve(Ls.T, np.linalg.solve(Ls, L.T @ r)))
+    except np.linalg.LinAlgError:
+        # the cost-to-go behind the cut is not positive definite (the tangential equality's curvature lam_vt H_v in the early
+        # iterations; the sequential recursion asks for D + P > 0, not for P > 0): the other similar symmetric matrix, with
+        # N = C C' -- N contains D^-1 of the segment's last node -- I + C'W C, whose Cholesky factorisation is the cut's share of
+        # the recursion's pivot test.  (csrc/solve_tp.hpp: tp_iface_factor, mode 1)
+        C = np.linalg.cholesky(Ns)
+        Ls = np.linalg.cholesky(np.eye(7) + C.T @ Ws @ C)
+        z = C @ np.linalg.solve(Ls.T, np.linalg.solve(Ls, np.linalg.solve(C, r)))
     if r.ndim == 1:
         z_lu = np.linalg.solve(np.eye(7) + Nm @ W, r)
         STATS["spd"].append(np.abs(z - z_lu).max() / max(np.abs(z_lu).max(), 1e-300))
