@@ -83,7 +83,7 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     // behind the other kernels' layout for the call's row length (ws_doubles_tp): the extra backward record, the second
     // trajectory bank, the mailbox of the satellite's workgroups and their exchange records
     s.chx = s.ws + tp_extras_offset(Kmax); s.trajx = s.chx + (size_t)Kmax * CHX_N;
-    s.o_trajx = (int)(tp_extras_offset(Kmax) + (size_t)Kmax * CHX_N);
+    s.o_trajx = (int)(tp_extras_offset(Kmax) + (size_t)Kmax * CHX_N); s.o_chx = (int)tp_extras_offset(Kmax);
     s.mail = (int *)(s.ws + tp_mail_offset(Kmax)); s.xch = s.ws + tp_mail_offset(Kmax) + TP_MAIL_N;
 #endif
 #endif
@@ -451,7 +451,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                     }
 #endif
 #ifdef MPCX_TP
-                    tp_combine(s, sd, g_tp, (double *)&w, lane, pass == 0);
+                    tp_cmd_combine(s, sd, g_tp, (double *)&w, lane, pass == 0);
 #else
                     combine_channels(s, sd, (double *)&w, lane, pass == 0);
 #endif

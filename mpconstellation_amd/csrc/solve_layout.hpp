@@ -106,9 +106,9 @@ __host__ __device__ inline int tp_cut(int K, int nseg, int j)
 {
     if (j >= nseg) return K;
 #ifndef MPCX_TP_LASTFRAC
-#define MPCX_TP_LASTFRAC 9           // the last segment's share of the horizon in thirtieths (the others share the rest evenly)
+#define MPCX_TP_LASTFRAC 18          // the last segment's share of the horizon in sixtieths (the others share the rest evenly)
 #endif
-    return nseg == 4 ? (j * (30 - MPCX_TP_LASTFRAC) * K) / 90 : (j * K) / nseg;
+    return nseg == 4 ? (j * (60 - MPCX_TP_LASTFRAC) * K) / 180 : (j * K) / nseg;
 }
 // what a segment's workgroup hands to the one that runs the coarse problem (global memory): W, N, Phi, the ends of its local
 // trajectories and the Sigma . lam sums of its trajectories

@@ -323,7 +323,7 @@ struct Sat {
 #endif
 #ifdef MPCX_TP
     gf64 *chx, *trajx;                          // time-parallel build: the extra backward record (K x CHX_N), the second bank of
-    int o_trajx;                                // eight trajectory slots per node, the satellite's mailbox and exchange records
+    int o_trajx, o_chx;                         // eight trajectory slots per node, the satellite's mailbox and exchange records
     int *mail; gf64 *xch;                       // (solve_tp.hpp)
 #endif
     __device__ Col<wf64> itn(int k) const { return Col<wf64>{wave_uniform(it), k, KP}; }
@@ -360,7 +360,7 @@ __device__ __forceinline__ Sat uniform_view(const Sat &v)
     s.wsg = wave_uniform(v.wsg); s.o_sinkg = __builtin_amdgcn_readfirstlane(v.o_sinkg);
 #endif
 #ifdef MPCX_TP
-    s.chx = wave_uniform(v.chx); s.trajx = wave_uniform(v.trajx); s.o_trajx = __builtin_amdgcn_readfirstlane(v.o_trajx);
+    s.chx = wave_uniform(v.chx); s.trajx = wave_uniform(v.trajx); s.o_trajx = __builtin_amdgcn_readfirstlane(v.o_trajx); s.o_chx = __builtin_amdgcn_readfirstlane(v.o_chx);
     s.mail = wave_uniform(v.mail); s.xch = wave_uniform(v.xch);
 #endif
     s.o_fac = __builtin_amdgcn_readfirstlane(v.o_fac); s.o_ch = __builtin_amdgcn_readfirstlane(v.o_ch);

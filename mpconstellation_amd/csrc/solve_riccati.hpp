@@ -275,8 +275,8 @@ __device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double
 #ifdef MPCX_TP
 // Time-parallel build: the workgroup (a pair of waves) factorises the nodes lo .. hi-1 of its segment from a zero cost-to-go
 // behind node hi-1 (the last segment, hi = K, has the terminal node as before).  Lane groups of the fused backward sweep of a
-// segment that is not the last: group 0 the dtf channel, groups 1..7 the unit prices e_0..e_6 on the state behind node hi-1
-// (the right-hand-side channel of such a segment is swept on its own afterwards: nine channels, eight groups).
+// segment that is not the last: group 0 the dtf channel, groups 1..7 the unit prices e_0..e_6 on the state behind node hi-1; its
+// ninth channel, the right-hand side, rides in the lanes of group 0 a second time (results in the extra record chx).
 struct TpRange { int lo, hi; bool last; double *Wout; };
 #define RF_ARGS , const TpRange &rg
 #define RF_HI rg.hi
@@ -377,6 +377,14 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
     ChanRaw nraw{0.0, 0.0, 0.0, 0.0};
     const int scl = RF_LAST ? sc : (sc == 0 ? 1 : 2);        // the group's channel as chan_fetch / chan_mask know it (2: no stage data)
     double pnext = RF_LAST ? 0.0 : ((sc >= 1 && sr == sc - 1) ? 1.0 : 0.0);
+#ifdef MPCX_TP
+    // the ninth channel of a segment that is not the last -- its right-hand side -- rides in the lanes of group 0 a second
+    // time: the same matrix rows in registers, its own vectors; results into the extra record
+    ChanIn cur0{0.0, 0.0, 0.0, 0.0};
+    ChanRaw nraw0{0.0, 0.0, 0.0, 0.0};
+    double pnext0 = 0.0;
+    const bool act0 = sact && sc == 0 && !RF_LAST;
+#endif
     auto sweep_node = [&](const StageOps &o, int j) {        // node j's p, qu from its complete operand buffer
         const bool dynj = (j <= K - 2);
         double sw_G[7], sw_Pt[7];
@@ -404,6 +412,27 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
         ustore(s.ws, sact ? s.o_ch + j * CH_N + C_P + sc * 7 + sr : sink_e, pp);
         ustore(s.ws, (sact && sr < 3) ? s.o_ch + j * CH_N + C_QU + sc * 3 + sr3 : sink_e, qu);
         pnext = sact ? pp : pnext;
+#ifdef MPCX_TP
+        if (!RF_LAST) {
+            const double v0 = cur0.rho + pnext0;
+            double t0 = pnext0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) t0 += -sw_G[q] * gshfl8(v0, q) + sw_Pt[q] * gshfl8(cur0.aff, q);
+            if (!dynj || !act0) t0 = 0.0;
+            double qu0 = cur0.gu;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) qu0 += Bpmcol[q] * gshfl8(cur0.gx, q) + Bhcol[q] * gshfl8(t0, q);
+            if (sr >= 3 || !act0) qu0 = 0.0;
+            double pp0 = cur0.gx;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pp0 += Acol[q] * gshfl8(t0, q);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pp0 -= Kgcol[q] * gshfl8(qu0, q);
+            ustore(s.ws, act0 ? s.o_chx + j * CHX_N + sr : sink_e, pp0);
+            ustore(s.ws, (act0 && sr < 3) ? s.o_chx + j * CHX_N + 7 + sr3 : sink_e, qu0);
+            pnext0 = act0 ? pp0 : pnext0;
+        }
+#endif
         // ... and the part of node j's factor record that the first wave left in LDS: gain, Bh, Q_uu^-1
         const bool on21 = lane < 21;
         const int l21 = on21 ? lane : 0;
@@ -473,7 +502,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
                 for (int l = 0; l < 7; ++l) a1 += w.WlLi[l * 14 + lo] * (rd[l] * w.WlLi[l * 14 + hi]);
                 const double pt = dyn ? Pn[lo * 7 + hi] - a1 : 0.0;
                 *(on ? &o.Pt[lane] : &w.sink[lane]) = pt;
-                if (keep_pt || !RF_LAST) ustore(s.ws, on ? s.o_fac + k * FAC_N + F_PT + lane : sink_e, pt);    // (a segment that is not the last sweeps its right-hand-side channel on its own: that sweep reads Pt)
+                if (keep_pt) ustore(s.ws, on ? s.o_fac + k * FAC_N + F_PT + lane : sink_e, pt);
                 wsync();
             }
             // P5
@@ -538,6 +567,9 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
             // ---- role 1 ----
             if (k > RF_LO) fetch(k - 1);
             nraw = chan_fetch(s, k, scl, srr, sr3);
+#ifdef MPCX_TP
+            if (!RF_LAST) nraw0 = chan_fetch(s, k, 0, srr, sr3);
+#endif
             if (dyn) {
                 double m[28], rd[7];
 #pragma unroll
@@ -602,6 +634,9 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
             if (k + 1 < RF_HI) sweep_node(w.ops[(k + 1) % 3], k + 1);          // node k+1: complete since the last barrier
             // inputs of node k for its sweep in the next slot
             cur = chan_mask(nraw, scl, sr, sact);
+#ifdef MPCX_TP
+            if (!RF_LAST) cur0 = chan_mask(nraw0, 0, sr, act0);
+#endif
             if (!dyn) {
                 const double tg = (sc == 2) ? sd.avt[srr] : sd.ta[sc >= 3 ? sc - 3 : 0][srr];
                 cur.gx = (sact && sc >= 2) ? tg : cur.gx;
@@ -621,7 +656,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
 }
 
 // What the first wave's driver calls: tell the second wave (parked in solve_kernel2w's command loop) to join, take role 0.
-enum { CMD_FACTOR = 1, CMD_EXIT = 2, CMD_SWEEP = 3 };
+enum { CMD_FACTOR = 1, CMD_EXIT = 2, CMD_SWEEP = 3, CMD_COMBINE = 4 };
 #ifndef MPCX_TP
 __device__ __forceinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
 {

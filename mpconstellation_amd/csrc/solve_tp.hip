@@ -56,6 +56,7 @@ __global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel_tp(SolveAr
                 const int cmd = __builtin_amdgcn_readfirstlane(w.cmd), arg = __builtin_amdgcn_readfirstlane(w.cmd_arg);
                 TP_DBG("[drv b%d wave 1] command %d arg %d\n", (int)blockIdx.x, cmd, arg);
                 if (cmd == CMD_EXIT) break;
+                if (cmd == CMD_COMBINE) { tp_combine(s, sd, tp, (double *)&w, lane, arg != 0, 1); continue; }
                 bool ok = true;
                 if (cmd == CMD_FACTOR) ok = riccati_factor2(s, sd, w, lane, 1, arg != 0, tp_range(tp, j));
                 if (ok) { tp_sweeps_pair(s, sd, w, tp, j, 1, lane, cmd == CMD_FACTOR); WG_BARRIER(); }

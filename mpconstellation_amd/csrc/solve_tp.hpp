@@ -39,6 +39,7 @@ struct TpData {
     int seq;                             // commands posted so far (first workgroup) / seen so far (the others)
     int dead;                            // a wait ran out: the satellite's solve ends with MPCX_ST_NUMERIC
     int light;                           // the satellite's workgroups share an XCD: light fences (tp_release / tp_acquire)
+    wf64 *it_cur;                        // the iterate as the first wave sees it now (tp_combine on the second wave)
     double xK_loc[NCH][7], xK_ua[7][7];
     double T1[49], T2[49];
     TpSeg seg[TP_MAXSEG];
@@ -492,10 +493,10 @@ __device__ __noinline__ bool tp_coarse(const Sat &s, SatData &sd, TpData &tp, in
 
 // combine_channels of the time-parallel build: the direction is, per segment, a combination of its 16 trajectory slots with
 // the coefficients 1 / border solution for the local ones, sum_c sol_c a_j[c] for the states and sum_c sol_c l_j[c] for the prices.
-__device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp, double *stg, int lane, bool first)
+// (both waves of the first workgroup: the second takes every other round of each half; wave 0 computes the coefficients first --
+//  tp_cmd_combine -- and tells the second where the iterate is: accepting a trial swaps two pointers of the FIRST wave's view)
+__device__ __forceinline__ void tp_combine_coefs(SatData &sd, TpData &tp, int lane)
 {
-    const Sat s = uniform_view(s_in);
-    const int K = s.K, KP = s.KP;
     const int nseg = tp.nseg, last = nseg - 1;
     if (lane < 16 * nseg) {
         const int j = lane >> 4, slot = lane & 15;
@@ -512,13 +513,19 @@ __device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp
         tp.seg[j].coef[slot] = v;
     }
     wsync();
+}
+__device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp, double *stg, int lane, bool first, int wave)
+{
+    const Sat s = uniform_view(s_in);
+    const int K = s.K, KP = s.KP;
+    const int nseg = tp.nseg;
     wf64 *dr = wave_uniform(s.dr);
-    cwf64 *it = wave_uniform((cwf64 *)s.it);
+    cwf64 *it = wave_uniform((cwf64 *)tp.it_cur);
     cgf64 *traj = wave_uniform((cgf64 *)s.traj), *trajx = wave_uniform((cgf64 *)s.trajx);
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int nk = (K - k0 < 32) ? K - k0 : 32;
         const int n = nk * TR_N;
-        for (int e0 = 0; e0 < n; e0 += 256) {
+        for (int e0 = 256 * wave; e0 < n; e0 += 512) {
             double v[4];
             int slot[4];
 #pragma unroll
@@ -538,8 +545,8 @@ __device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
-        WG_SYNC();
-        for (int e = lane; e < DIR_N * 32; e += 64) {
+        WG_BARRIER();
+        for (int e = lane + 64 * wave; e < DIR_N * 32; e += 128) {
             const int i = e >> 5, kl = e & 31, k = k0 + kl;
             const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
             const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
@@ -551,9 +558,9 @@ __device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp
             const double val = (i >= T_LAM) ? fma(Dj, stg[(T_NU + jj) * CMB_LD + kl], rj) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
             if (act) dr[dst] = base + val;
         }
-        WG_SYNC();
+        WG_BARRIER();
     }
-    if (lane == 0) {
+    if (wave == 0 && lane == 0) {
         if (first) { s.drg[G_TF] = sd.sol[0]; s.drg[G_LVT] = sd.linvt ? 0.0 : -s.itg[G_LVT] + sd.sol[1]; }
         else { s.drg[G_TF] += sd.sol[0]; if (!sd.linvt) s.drg[G_LVT] += sd.sol[1]; }
         if (sd.linvt) sd.zeta_vt = (first ? 0.0 : sd.zeta_vt) + sd.sol[1];
@@ -576,13 +583,13 @@ __device__ __forceinline__ TpRange tp_range(TpData &tp, int j)
     return TpRange{__builtin_amdgcn_readfirstlane(tp.cut[j]), __builtin_amdgcn_readfirstlane(tp.cut[j + 1]), j == nseg - 1, tp.seg[j].W};
 }
 
-// the sweeps of one pass on the segment's two waves: role 0 -- the right-hand-side channel's own backward sweep (it is fused
-// into the factorisation only in the last segment's first pass), then the first eight trajectory slots; role 1 -- the others
+// the sweeps of one pass on the segment's two waves: role 0 -- in a refinement pass the right-hand-side channel's backward sweep
+// (in the first pass all backward sweeps are fused into the factorisation), then the first eight trajectory slots; role 1 -- the others
 __device__ __forceinline__ void tp_sweeps_pair(const Sat &s, SatData &sd, Scratch &w, TpData &tp, int j, int role, int lane, bool pass0)
 {
     const bool last = (j == tp.nseg - 1);
     if (role == 0) {
-        if (!last || !pass0) sweep_backward(s, sd, w, 0, 1, lane, tp.cut[j], tp.cut[j + 1], last ? (gf64 *)nullptr : s.chx);
+        if (!pass0) sweep_backward(s, sd, w, 0, 1, lane, tp.cut[j], tp.cut[j + 1], last ? (gf64 *)nullptr : s.chx);
         tp_sweep_forward(s, sd, w.flat, tp, j, 0, pass0 ? NCH : 1, lane);
     } else if (pass0)
         tp_sweep_forward(s, sd, w.flatB, tp, j, 1, NCH, lane);      // (one segment only: zeros, so that every slot the combination reads is defined)
@@ -658,6 +665,14 @@ __device__ __forceinline__ void tp_cmd_sweeps(const Sat &s, SatData &sd, TpData 
     TP_DBG("[drv b%d] own sweeps done\n", (int)blockIdx.x);
     (void)tp_wait(s, tp, lane);
     TP_DBG("[drv b%d] workers' sweeps done dead %d\n", (int)blockIdx.x, tp.dead);
+}
+
+__device__ __forceinline__ void tp_cmd_combine(const Sat &s, SatData &sd, TpData &tp, double *stg, int lane, bool first)
+{
+    tp_combine_coefs(sd, tp, lane);
+    if (lane == 0) { tp.it_cur = s.it; g_w.cmd = CMD_COMBINE; g_w.cmd_arg = first ? 1 : 0; }
+    WG_BARRIER();
+    tp_combine(s, sd, tp, stg, lane, first, 0);
 }
 
 // a workgroup that owns another segment: wait for the first workgroup's commands (its first wave polls the mailbox, the second
