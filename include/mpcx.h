@@ -179,8 +179,8 @@ typedef struct {
  * (csrc/solve_tp.hip).  Honoured for batches of at most 128 satellites and row lengths K >= 24 (four
  * workgroups per satellite, all resident); other calls take the kernels they would take without the flag.  Same Newton
  * directions to ~1e-10 relative, the same iteration counts on 98-100 % of the problems, NOT the same bits as the other
- * kernels -- which is why it is a flag and not the default.  64 satellites: 1.17 against 1.33 ms at 30 nodes, 1.83 against
- * 2.35 ms at 60. */
+ * kernels -- which is why it is a flag and not the default.  64 satellites: solve kernel 1.11 against 1.32 ms at 30 nodes, call 1.76
+ * against 2.36 ms at 60. */
 #define MPCX_SOLVE_TIME_PARALLEL 64
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
