@@ -6,7 +6,6 @@
 #define MPCX_TWO_WAVE 1
 #define MPCX_TP 1
 #include <cstring>
-#include <cstdlib>
 #include "solve_common.hpp"
 #include "solve_launch.hpp"
 
@@ -84,9 +83,5 @@ int mpcxtp_launch(const void *args, size_t args_bytes, int blocks, hipStream_t s
     // (cooperative: the workgroups of a satellite wait for each other, all of them must be resident)
     void *kargs[] = {(void *)&a};
     const int grid = ((blocks + 7) / 8) * 8 * mpcx::TP_MAXSEG;
-    // (while the workgroups are no more than the compute units, a pad of dynamic LDS keeps the dispatcher from putting two on one:
-    //  they would share its LDS pipe and, wave by wave, its SIMDs -- and a satellite is as slow as its slowest segment)
-    static const int pad_env = getenv("MPCX_TP_LDS_PAD") ? atoi(getenv("MPCX_TP_LDS_PAD")) : -1;
-    const size_t pad = pad_env >= 0 ? (size_t)pad_env : (grid <= 256 ? 36 * 1024 : 0);
-    return hipLaunchCooperativeKernel((const void *)MPCX_NS::solve_kernel_tp, dim3(grid), dim3(128), kargs, pad, stream) == hipSuccess ? 0 : -1;
+    return hipLaunchCooperativeKernel((const void *)MPCX_NS::solve_kernel_tp, dim3(grid), dim3(128), kargs, 0, stream) == hipSuccess ? 0 : -1;
 }
