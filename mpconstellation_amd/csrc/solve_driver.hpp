@@ -563,6 +563,9 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         for (int i = 0; i < 16; ++i) dbg[24 + i] = (double)sd.fpt[i];
         // calibration: the satellite's life in s_memrealtime ticks (constant 100 MHz) and in s_memtime ticks
         dbg[40] = (double)(__builtin_amdgcn_s_memrealtime() - rt0_); dbg[41] = (double)(__builtin_amdgcn_s_memtime() - mt0_);
+#ifdef MPCX_TP
+        for (int i = 0; i < 16; ++i) dbg[48 + i] = (double)s.mail[16 + i];       // the segments' cycles of the last factorisation command (solve_tp.hpp)
+#endif
 #endif
     }
 }

@@ -40,6 +40,9 @@ struct TpData {
     int dead;                            // a wait ran out: the satellite's solve ends with MPCX_ST_NUMERIC
     int light;                           // the satellite's workgroups share an XCD: light fences (tp_release / tp_acquire)
     wf64 *it_cur;                        // the iterate as the first wave sees it now (tp_combine on the second wave)
+#ifdef MPCX_PHASE_TIMING
+    unsigned long long t_wait0;
+#endif
     double xK_loc[NCH][7], xK_ua[7][7];
     double T1[49], T2[49];
     TpSeg seg[TP_MAXSEG];
@@ -646,11 +649,23 @@ __device__ __forceinline__ bool tp_cmd_factor(const Sat &s, SatData &sd, TpData 
     TP_DBG("[drv b%d] posted FACTOR seq %d\n", (int)blockIdx.x, tp.seq);
     if (lane == 0) { g_w.cmd = CMD_FACTOR; g_w.cmd_arg = keep_pt ? 1 : 0; }
     WG_BARRIER();
+#ifdef MPCX_PHASE_TIMING
+    const unsigned long long dt0 = __builtin_amdgcn_s_memtime();
+#endif
     const bool mine = riccati_factor2(s, sd, g_w, lane, 0, keep_pt, tp_range(tp, tp.nseg - 1));
+#ifdef MPCX_PHASE_TIMING
+    const unsigned long long dt1 = __builtin_amdgcn_s_memtime();
+#endif
     if (mine) { tp_sweeps_pair(s, sd, g_w, tp, tp.nseg - 1, 0, lane, true); WG_BARRIER(); }
+#ifdef MPCX_PHASE_TIMING
+    if (lane == 0) { int *m = s.mail; const unsigned long long dt2 = __builtin_amdgcn_s_memtime(); m[28] = (int)(dt1 - dt0); m[29] = (int)(dt2 - dt1); tp.t_wait0 = dt2; }
+#endif
     TP_DBG("[drv b%d] own factor done ok %d\n", (int)blockIdx.x, (int)mine);
     const bool theirs = tp_wait(s, tp, lane);
     TP_DBG("[drv b%d] workers done ok %d dead %d\n", (int)blockIdx.x, (int)theirs, tp.dead);
+#ifdef MPCX_PHASE_TIMING
+    if (lane == 0) s.mail[30] = (int)(__builtin_amdgcn_s_memtime() - tp.t_wait0);
+#endif
     return mine && theirs;
 }
 __device__ __forceinline__ void tp_cmd_sweeps(const Sat &s, SatData &sd, TpData &tp, int lane, bool pass0)
@@ -706,10 +721,20 @@ __device__ __forceinline__ void tp_worker(const Sat &s, SatData &sd, TpData &tp,
         if (cmd == CMD_EXIT) break;
         bool ok = true;
         const bool pass0 = (cmd == CMD_FACTOR);
+#ifdef MPCX_PHASE_TIMING
+        const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
+        unsigned long long wt1 = wt0, wt2 = wt0;
+#endif
         if (pass0) ok = riccati_factor2(s, sd, g_w, lane, wave, arg != 0, tp_range(tp, j));
+#ifdef MPCX_PHASE_TIMING
+        wt1 = __builtin_amdgcn_s_memtime();
+#endif
         if (ok) {              // (the same in both waves: the breakdown flag is the workgroup's)
             tp_sweeps_pair(s, sd, g_w, tp, j, wave, lane, pass0);
             WG_BARRIER();
+#ifdef MPCX_PHASE_TIMING
+            wt2 = __builtin_amdgcn_s_memtime();
+#endif
             // the exchange record of the segment: what the sweeps left in LDS and the start co-states -- the backward vectors p at
             // the segment's first node (dtf in channel slot 0, price i in slot 1 + i, the right-hand side in the extra record)
             if (wave == 0) {
@@ -738,6 +763,11 @@ __device__ __forceinline__ void tp_worker(const Sat &s, SatData &sd, TpData &tp,
         TP_DBG("[wrk b%d seg %d wave %d] command %d finished ok %d\n", (int)blockIdx.x, j, wave, cmd, (int)ok);
         if (wave == 0) {
             const int okw = __builtin_amdgcn_readfirstlane((int)ok);
+#ifdef MPCX_PHASE_TIMING
+            if (lane == 0 && pass0) {      // diagnostic build only: this command's cycles -- factorisation, sweeps, exchange record + release
+                m[16 + 4 * j] = (int)(wt1 - wt0); m[17 + 4 * j] = (int)(wt2 - wt1); m[18 + 4 * j] = (int)(__builtin_amdgcn_s_memtime() - wt2);
+            }
+#endif
             if (lane == 0) {
                 if (!okw) __hip_atomic_store(m + TPM_OK, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(m + TPM_PROG + j, 10 * tp.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -41,3 +41,8 @@ nn = max(1, int(t[2, 1])) * x.shape[1]
 print("-- inside the recursions (cycles per node per call) --")
 for n, c in zip(fn, f):
     if c: print(f"   {n:24s} {c/nn:8.0f}")
+if flags & 64:
+    w = r.NU[0].ravel()[48:64]
+    print("-- time-parallel: cycles of the last factorisation command per workgroup (segment: factorisation, sweeps, exchange record + release) --")
+    for j in range(3): print(f"   segment {j}: {w[4*j]:8.0f} {w[4*j+1]:8.0f} {w[4*j+2]:8.0f}")
+    print(f"   last segment (first workgroup): factorisation {w[12]:8.0f}  sweeps {w[13]:8.0f}  then waited {w[14]:8.0f} for the others")
