@@ -282,6 +282,23 @@ struct Col {
     __device__ __forceinline__ Col node(int dk) const { return Col{base, k + dk, ld}; }   // same fields, node k + dk
 };
 
+// xld: a load of data that ANOTHER workgroup of the satellite has written (time-parallel build only: the Newton and
+// right-hand-side records the first workgroup writes every iteration, the other segments' trajectories and exchange records).
+// It goes past the compute unit's L1 to the L2 the satellite's workgroups share (a relaxed agent-scope atomic load:
+// global_load ... sc1), so that no acquire has to invalidate caches -- the agent-scope invalidate (buffer_inv sc1) drops the
+// XCD's whole L2, the read-only stage records of every satellite on it included.  Everywhere else it is a plain load.
+// Measured (-DMPCX_TP_ACQ_MODE=4): correct, and NOT faster than the invalidate (88.4 against 88.4 k cycles for the
+// factorisation command at 64 satellites, profiles/r04/time_parallel.txt) -- the default stays the invalidate, mode 2, which
+// does not depend on every such load having been found.
+#ifndef MPCX_TP_ACQ_MODE
+#define MPCX_TP_ACQ_MODE 2
+#endif
+#if defined(MPCX_TP) && MPCX_TP_ACQ_MODE == 4
+template <typename P> __device__ __forceinline__ double xld(P *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+template <typename P> __device__ __forceinline__ double xld(P *p) { return *p; }
+#endif
+
 // Store to element `e` of the satellite's workspace (wave-uniform base): scalar base + 32-bit vector offset.  The recursions issue
 // their factor-record / trajectory stores for every lane (lanes with nothing to store aim at the satellite's sink): code
 // without divergent store blocks is straight-line, so the compiler can count the stores issued after the node-ahead

@@ -106,9 +106,9 @@ __device__ __forceinline__ ChanIn chan_inputs(const Sat &s, const SatData &sd, i
     const bool dyn = (k <= K - 2);
     if (c == 0) {
         cwf64 *ch = s.ch + (size_t)k * CH_N + C_RHS;
-        ci.gx = ch[R_GX + r];
-        if (r < 3) ci.gu = ch[R_GU + r];
-        if (dyn) { ci.rho = ch[R_RHO + r]; ci.aff = ch[R_AFF + r]; }
+        ci.gx = xld(ch + R_GX + r);
+        if (r < 3) ci.gu = xld(ch + R_GU + r);
+        if (dyn) { ci.rho = xld(ch + R_RHO + r); ci.aff = xld(ch + R_AFF + r); }
     } else if (c == 1) { if (dyn) ci.aff = s.Sig(k)[r]; }
     else if (k == K - 1) ci.gx = (c == 2) ? sd.avt[r] : sd.ta[c - 3][r];
     return ci;
@@ -130,7 +130,7 @@ __device__ __forceinline__ ChanRaw chan_fetch(const Sat &s, int k, int c, int rr
     cr.gx = ch[R_GX + rr]; cr.gu = ch[R_GU + r3]; cr.rho = ch[R_RHO + rr]; cr.aff = (c == 1) ? sg : af;
 #else
     cgf64 *pa = (c == 1) ? s.Sig(k < K - 2 ? k : K - 2) + rr : ch + R_AFF + rr;
-    cr.gx = ch[R_GX + rr]; cr.gu = ch[R_GU + r3]; cr.rho = ch[R_RHO + rr]; cr.aff = *pa;
+    cr.gx = xld(ch + R_GX + rr); cr.gu = xld(ch + R_GU + r3); cr.rho = xld(ch + R_RHO + rr); cr.aff = xld(pa);
 #endif
     return cr;
 }
@@ -329,7 +329,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
 #else
         cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
         cgf64 *p2 = nb + src2;
-        pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
+        pre[0] = stk[lane]; pre[1] = xld(p1); pre[2] = xld(p2);
 #endif
     };
     auto ops_slot = [](int e) -> int {
@@ -743,7 +743,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
 #else
         cgf64 *p1 = (e1 < 70) ? stk + e1 : (e1 < 91) ? stm + e1 : nb + wx1;
         cgf64 *p2 = nb + src2;
-        pre[0] = stk[lane]; pre[1] = *p1; pre[2] = *p2;
+        pre[0] = stk[lane]; pre[1] = xld(p1); pre[2] = xld(p2);
 #endif
     };
     // LDS slot (byte offset inside StageOps) of element e of the fetch order [A 49 | Bn 21 | Bpm 21 | Wx 49 | Wu 9 | D 7 | SX 8]
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void sweep_fetch_mats(const Sat &s, int k, int lane, 
     pre.v[5] = (lane < 21) ? g5 : l5;
 #else
     cgf64 *p5 = (lane < 21) ? stm + 70 + lane : nb + N_D + ((lane < 28) ? lane - 21 : 0);
-    pre.v[5] = *p5;
+    pre.v[5] = xld(p5);
 #endif
 }
 

@@ -71,9 +71,9 @@ constexpr int kTpSpinMax = 1 << 17;
 // workgroups of a satellite sit on ONE XCD (solve_tp.hip gives them block indices of one residue mod 8; each checks the XCC
 // it really runs on and the first workgroup compares them before anything is exchanged): their common L2 is coherent for
 // them, a writer only has to wait until its stores have reached it, a reader to drop its compute unit's L1 -- `light`.
-#ifndef MPCX_TP_ACQ_MODE
-#define MPCX_TP_ACQ_MODE 2        // (1, buffer_inv sc0, leaves stale lines in the reader's L1: measured wrong; 2, sc1, is what the agent fence issues)
-#endif
+// MPCX_TP_ACQ_MODE (solve_phases.hpp, xld): 4 -- no cache maintenance at all, every load of another workgroup's data goes past
+// the L1 (xld); 2 -- buffer_inv sc1, what the agent fence issues (drops the XCD's L2); 1 -- buffer_inv sc0: leaves stale lines
+// in the reader's L1, measured wrong
 #ifndef MPCX_TP_REL_MODE
 #define MPCX_TP_REL_MODE 1
 #endif
@@ -87,6 +87,7 @@ __device__ __forceinline__ void tp_acquire(bool light)
     if (light && MPCX_TP_ACQ_MODE == 1) { asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
     else if (light && MPCX_TP_ACQ_MODE == 2) { asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
     else if (light && MPCX_TP_ACQ_MODE == 3) { asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    else if (light && MPCX_TP_ACQ_MODE == 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // pause between two polls of a mailbox word: short at first, then longer -- a hundred and ninety waves polling every hundred
@@ -377,7 +378,7 @@ __device__ __noinline__ bool tp_coarse(const Sat &s, SatData &sd, TpData &tp, in
         TpSeg &sj = tp.seg[j];
         cgf64 *x = (cgf64 *)s.xch + (size_t)j * TP_XCH_N;
         for (int e = lane; e < XO_END; e += 64) {
-            const double v = x[e];
+            const double v = xld(x + e);
             if (e < XO_N) { if (pass0) sj.W[e] = v; }
             else if (e < XO_PHI) { if (pass0) sj.N[e - XO_N] = v; }
             else if (e < XO_Y0) { if (pass0) sj.Phi[e - XO_PHI] = v; }
@@ -542,7 +543,7 @@ __device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp
                 cgf64 *tr = traj + (size_t)k * NCH * TR_N + i, *tx = trajx + (size_t)k * NCH * TR_N + i;
                 double acc = 0.0;
 #pragma unroll
-                for (int t = 0; t < NCH; ++t) acc += cf[t] * tr[t * TR_N] + cf[8 + t] * tx[t * TR_N];
+                for (int t = 0; t < NCH; ++t) acc += cf[t] * xld(tr + t * TR_N) + cf[8 + t] * xld(tx + t * TR_N);
                 v[q] = acc; slot[q] = (e < n) ? i * CMB_LD + kl : -1;
             }
 #pragma unroll

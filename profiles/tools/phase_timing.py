@@ -22,6 +22,15 @@ import ast
 opts = ast.literal_eval(os.environ.get("OPTS", "{}"))          # e.g. OptimalController's set: OPTS='{"eps_r": 1e-6, "eps_vr": 1e-16, "tf_max": 1.0}'
 if "r_des" in opts: args = args[:-1] + ([opts.pop("r_des")] * S,)
 flags = int(os.environ.get("FLAGS", "0"))        # 16: the one-wave kernel for small batches too
+if os.environ.get("K"):          # another horizon: the benchmark constellation's first S satellites through the fused step
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_full_size_gpu import workload
+    from mpconstellation_amd import mpc_step_batch
+    Kk = int(os.environ["K"])
+    xb, ub, cs, rd = workload(4096, Kk, first=0, count=S)
+    x = xb[0]
+    solve_batch = lambda *a, **kw: mpc_step_batch(xb, ub, np.ones(S), cs, rd, **kw)
+    args = ()
 r = solve_batch(*args, options=opts, flags=flags)
 t0 = time.perf_counter(); r = solve_batch(*args, options=opts, flags=flags); wall = time.perf_counter() - t0
 print(f"S {S}: host-pointer solve_batch wall {wall*1e3:.3f} ms (copies of {S*30*17*8/1e6:.1f} MB results included)")
