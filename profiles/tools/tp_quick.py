@@ -1,3 +1,4 @@
+"""profiling helper: three quick cases of the time-parallel kernel against the default ones (correctness counters + call time); MPCX_LIB selects another build"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
