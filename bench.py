@@ -343,6 +343,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra S64_K30 measurement of the default run")
     ap.add_argument("--cpu-sample", type=int, default=256, help="satellites solved by the CPU oracle")
+    ap.add_argument("--solve-flags", type=int, default=0, help="mpcx_solve_opts.flags of the measured solves (64: the time-parallel kernel; profiling runs)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -367,6 +368,7 @@ def main():
     workload = args.workload or DEFAULT_SINGLE
 
     run = Runner(workload, rank, world, local_rank)
+    run.opts.flags = args.solve_flags
     S, K, n_scp = run.S, run.K, run.n_scp
     elapsed, solve_ms = measure(run, args.steps, args.warmup, world)
     status, iters, kkt = run.solver_stats()
@@ -399,7 +401,7 @@ def main():
             "value": value, "unit": "satellite-MPC-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "satellites_per_gpu": S, "satellites_total": S_total, "nodes_K": K,
+            "config": {"workload": workload + (f" (solve flags {args.solve_flags})" if args.solve_flags else ""), "satellites_per_gpu": S, "satellites_total": S_total, "nodes_K": K,
                        "scp_iterations_per_step": n_scp, "parallelism": f"satellite-sharded x{world}, no collective"},
             "roofline": roofline(workload, S, K, solve_ms, iters),
             "solver": {"converged": int(stats[0].item()), "of": int(stats[1].item()),

@@ -15,6 +15,11 @@ for W in S4096_K30 S64_K30 S4096_K100_scp2 S8192_K30; do
     python3 "$REPO/bench.py" --workload $W --steps 8 --warmup 2 --no-also --no-cpu-baseline > "$OUT/$W.bench.log" 2>&1
   echo "stats $W done"
 done
+# the time-parallel kernel (MPCX_SOLVE_TIME_PARALLEL) on configs[1]: kernel durations only
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/S64_K30_tp/stats" -o stats -- \
+  python3 "$REPO/bench.py" --workload S64_K30 --solve-flags 64 --steps 8 --warmup 2 --no-also --no-cpu-baseline > "$OUT/S64_K30_tp.bench.log" 2>&1 \
+  || echo "(the profiled process of the cooperative launch ends with a fault in its exit handlers, after the bench line and the profiler's files are written: seen under rocprofv3 only)"
+echo "stats S64_K30_tp done"
 SQ_A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"
 SQ_B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F64"
 # (K = 100: the configuration BASELINE.json calls the HBM-bound regime)
