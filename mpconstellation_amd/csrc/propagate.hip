@@ -110,7 +110,7 @@ __device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double in
                                          double r, double v, double m, double &dr, double &dv, double &dm, int &err)
 {
     constexpr int flags = FLAGS;
-    const double r2 = quad_sum(on ? r * r : 0.0);
+    const double r2 = quad_sum(r * r);            // (lane 3 of the quad carries r = v = 0: nothing to mask in the sums)
     const double irn = rsq_fast(r2), irn2 = irn * irn;
     if (m <= 0.0) err = MPCX_ST_MASS;
     const double im = rcp_fast(m > 0.0 ? m : 1.0);
@@ -121,9 +121,9 @@ __device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double in
         // control.py:66-84: u = mag * t_hat, t_hat = h_hat x r_hat with h = r x v.  (r x v) x r = v |r|^2 - r (r.v) is that
         // direction without a cross product (h is normal to r, so |h x r| = |h| |r|): one quad sum for r.v, one for the
         // norm, no rotations of the triple
-        const double rv = quad_sum(on ? r * v : 0.0);
+        const double rv = quad_sum(r * v);
         const double w = v * r2 - r * rv;
-        const double iwn = rsq_fast(quad_sum(on ? w * w : 0.0));
+        const double iwn = rsq_fast(quad_sum(w * w));
         u = c.vc * (w * iwn);
         un = fabs(c.vc);
     } else if (KIND == MPCX_CTRL_SEQUENCE) {                  // control.py:132-142
@@ -137,13 +137,13 @@ __device__ __forceinline__ void prop_rhs(Ctrl &c, const SatConst &cst, double in
         const double uf = foh_cached(tn, c, err);
         const double uu = quad_sum(on ? uf * uf : 0.0);
         un = live ? uu * rsq_fast(fmax(uu, 1e-300)) : 0.0;    // |u| (0 for u = 0)
-        u = live ? uf : 0.0;
+        u = (live && on) ? uf : 0.0;
     } else { u = 0.0; un = 0.0; }
     const double kg = -cst.mu * (irn2 * irn);
     dr = v;
     dv = kg * r + u * im;
     if (flags & MPCX_FLAG_DRAG) {                            // simulator.py:150-153
-        const double vn = sqrt(quad_sum(on ? v * v : 0.0));
+        const double vn = sqrt(quad_sum(v * v));
         const double coef = -0.5 * kCd * cst.s * im * (kRho500 / cst.rho) * vn;
         dv += coef * v;
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     c.kc = -1; c.tau_k = 2.0; c.tau_kp1 = -1.0; c.uk = c.uk1 = 0.0; c.id = 0.0;
     if (a.ctrl_kind == MPCX_CTRL_CONSTANT) {
         const double *v3 = a.ctrl_vec + (size_t)sat * 3;
-        c.vc = v3[comp]; c.vn = sqrt(v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2]);
+        c.vc = on ? v3[comp] : 0.0; c.vn = sqrt(v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2]);
     } else if (a.ctrl_kind == MPCX_CTRL_TANGENTIAL) c.vc = a.ctrl_vec[sat];
     else if (a.ctrl_kind == MPCX_CTRL_SEQUENCE) { c.useq = a.ctrl_vec + (size_t)sat * 3 * a.Ku + (size_t)comp * a.Ku; c.end_tau = a.end_tau[sat]; }
     c.inv_end_tau = 1.0 / c.end_tau;
@@ -188,9 +188,10 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
     int err = 0;
     // rms over the 7 components of the system from this lane's three (the mass is counted by lane 0)
     auto rms7 = [&](double pr, double pv, double pm) {
-        return sqrt(quad_sum((on ? pr * pr + pv * pv : 0.0) + (lane4 == 0 ? pm * pm : 0.0))) / sqrt(7.0);
+        return sqrt(quad_sum(pr * pr + pv * pv + (lane4 == 0 ? pm * pm : 0.0))) / sqrt(7.0);
     };
-    double yr = a.y0[(size_t)sat * 7 + comp], yv = a.y0[(size_t)sat * 7 + 3 + comp], ym = a.y0[(size_t)sat * 7 + 6];
+    // (the quad's fourth lane carries a zero position / velocity component: its products vanish from every quad sum)
+    double yr = on ? a.y0[(size_t)sat * 7 + comp] : 0.0, yv = on ? a.y0[(size_t)sat * 7 + 3 + comp] : 0.0, ym = a.y0[(size_t)sat * 7 + 6];
     double fr, fv, fm;
     double t = 0.0;
     prop_rhs<KIND, FLAGS>(c, cst, inv_gi, tf, t, comp, on, yr, yv, ym, fr, fv, fm, err);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64) void propagate_kernel(PropArgs a)
         const double ehr = (fr * RK_E[0] + Kr[0] * RK_E[1] + Kr[1] * RK_E[2] + Kr[2] * RK_E[3] + Kr[3] * RK_E[4] + Kr[4] * RK_E[5] + Kr[5] * RK_E[6]) * h;
         const double ehv = (fv * RK_E[0] + Kv[0] * RK_E[1] + Kv[1] * RK_E[2] + Kv[2] * RK_E[3] + Kv[3] * RK_E[4] + Kv[4] * RK_E[5] + Kv[5] * RK_E[6]) * h;
         const double ehm = (fm * RK_E[0] + Km[0] * RK_E[1] + Km[1] * RK_E[2] + Km[2] * RK_E[3] + Km[3] * RK_E[4] + Km[4] * RK_E[5] + Km[5] * RK_E[6]) * h;
-        const double ssq = quad_sum((on ? ehr * ehr + ehv * ehv : 0.0) + (lane4 == 0 ? ehm * ehm : 0.0));
+        const double ssq = quad_sum(ehr * ehr + ehv * ehv + (lane4 == 0 ? ehm * ehm : 0.0));
         // scipy's error norm divides each component by atol + max(|y|, |y_new|) rtol >= atol.  If even the bound
         // rms(e h) / atol is below 0.4 the exact norm is below 0.5 (and below 1) whatever it is, which is all the
         // controller asks of it when the step was max_step long (see below): no divisions, no square roots then.
