@@ -50,6 +50,17 @@ def test_stiff_option_set_with_refinement_passes():
     assert np.abs(a.X - b.X).max() < 1e-5 and np.abs(a.tf - b.tf).max() < 1e-6
 
 
+@pytest.mark.parametrize("kw", [dict(linear_vt=True), dict(fixed_tf=1.05), dict(linear_vt=True, fixed_tf=0.97), dict(options={"w_tr": 0.02})])
+def test_solver_variants(kw):
+    """the convex tangential pair (another border), a fixed final time (dtf out of the border), another trust-region weight"""
+    kw = dict(kw)
+    if "fixed_tf" in kw: kw["fixed_tf"] = np.full(32, kw["fixed_tf"])
+    a, b = _pair(32, 30, **kw)
+    assert (a.status == 0).all() and (b.status == 0).all()
+    assert np.abs(a.iters - b.iters).max() <= 1 and (a.iters == b.iters).mean() >= 0.9
+    assert np.abs(a.X - b.X).max() < 1e-6 and np.abs(a.tf - b.tf).max() < 1e-7
+
+
 def test_ragged_batch_and_refused_node_counts():
     from mpconstellation_amd import mpc_step_batch
     S, K = 12, 40
