@@ -15,8 +15,9 @@
 // With a_j the start state and l_j the terminal price of segment j for one of the eight channels of the reduced solve:
 //       a_{j+1} = y0_j + Phi_j a_j - N_j l_j ,      l_j = W_{j+1} a_{j+1} + p0_{j+1} + Psi_{j+1} l_{j+1}       (a_0 = 0, no price on the last)
 // -- a coarse problem over the cuts with 7 x 7 blocks: backward  What_j = W_j + Psi_j What_{j+1} (I + N_j What_{j+1})^-1 Phi_j  (once
-// per factorisation) and qhat_j (per channel), forward a_j, l_j.  (I + N W)^-1 r goes through the similar symmetric positive
-// definite I + C'N C, W = C C': two LDL^T without pivoting, in registers.  The segment's trajectory is then
+// per factorisation) and qhat_j (per channel), forward a_j, l_j.  (I + N W)^-1 r goes through a similar symmetric positive
+// definite matrix -- I + C'N C with W = C C', or I + C'W C with N = C C' where W is not positive definite (tp_iface_factor) --:
+// two LDL^T without pivoting, in registers.  The segment's trajectory is then
 // local + sum_i a_i (state i) + sum_i l_i (price i): the combination that forms the direction takes these coefficients.
 #pragma once
 
@@ -24,6 +25,7 @@ namespace MPCX_NS {
 
 struct TpSeg {
     double W[49], N[49], Psi[49], Phi[49], What[49];
+    double rcd[7];                       // 1 / diag(Cw)
     double Cw[49], Ls[49], rds[7];       // interface behind this segment: What_{j+1} = Cw Cw' (Cw lower), I + Cw'N Cw = Ls diag(1/rds) Ls' (Ls unit lower)
     double E[49], EPhi[49], EN[49];      // E = (I + N What_{j+1})^-1 explicitly, E Phi, E N: the per-channel passes are matrix-vector products
     double M1[49], M2[49];               // qhat_j = p0_j + M1 y0_j + M2 qhat_{j+1}:  M1 = Psi What_{j+1} E,  M2 = Psi (I - What_{j+1} E N)
@@ -238,7 +240,7 @@ __device__ __forceinline__ bool tp_ldl7(const double *M, double (&m)[28])
     for (int pp = 0; pp < 7; ++pp) {
         const double d = m[pp * (pp + 1) / 2 + pp];
         if (!(d > 0.0)) ok = false;
-        const double rd = 1.0 / (d > 0.0 ? d : 1.0);
+        const double rd = rcp_pos(d > 0.0 ? d : 1.0);
         double col[7];
 #pragma unroll
         for (int i = pp + 1; i < 7; ++i) col[i] = m[i * (i + 1) / 2 + pp];
@@ -271,7 +273,13 @@ __device__ __noinline__ bool tp_iface_factor(TpSeg &sj, const double *Wn, TpData
     if (lane == 0) {
         double sq[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { const double d = m[i * (i + 1) / 2 + i]; sq[i] = sqrt(d > 0.0 ? d : 1.0); }
+        for (int i = 0; i < 7; ++i) {      // sqrt(d) = d / sqrt(d): reciprocal square root seed + two Newton steps
+            const double d = (m[i * (i + 1) / 2 + i] > 0.0) ? m[i * (i + 1) / 2 + i] : 1.0;
+            double rs = __builtin_amdgcn_rsq(d);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { const double e = fma(-d * rs, rs, 1.0); rs = fma(0.5 * rs, e, rs); }
+            sq[i] = d * rs; sj.rcd[i] = rs;
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -304,7 +312,7 @@ __device__ __noinline__ bool tp_iface_factor(TpSeg &sj, const double *Wn, TpData
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            sj.rds[i] = 1.0 / m[i * (i + 1) / 2 + i];
+            sj.rds[i] = rcp_pos(m[i * (i + 1) / 2 + i] > 0.0 ? m[i * (i + 1) / 2 + i] : 1.0);
 #pragma unroll
             for (int jj = 0; jj < 7; ++jj) sj.Ls[i * 7 + jj] = (jj > i) ? 0.0 : (jj == i ? 1.0 : m[i * (i + 1) / 2 + jj]);
         }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void tp_iface_solve(const TpSeg &sj, double (&r)[7])
             double acc = r[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) acc -= sj.Cw[i * 7 + k] * t[k];
-            t[i] = acc / sj.Cw[i * 7 + i];
+            t[i] = acc * sj.rcd[i];
         }
     }
 #pragma unroll
@@ -351,7 +359,7 @@ __device__ __forceinline__ void tp_iface_solve(const TpSeg &sj, double (&r)[7])
             double acc = t[i];
 #pragma unroll
             for (int k = i + 1; k < 7; ++k) acc -= sj.Cw[k * 7 + i] * r[k];
-            r[i] = acc / sj.Cw[i * 7 + i];
+            r[i] = acc * sj.rcd[i];
         }
     } else {                  // z = C t
 #pragma unroll
