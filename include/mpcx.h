@@ -179,7 +179,7 @@ typedef struct {
  * (csrc/solve_tp.hip).  Honoured for batches of at most 128 satellites and row lengths K >= 24 (four
  * workgroups per satellite, all resident); other calls take the kernels they would take without the flag.  Same Newton
  * directions to ~1e-10 relative, the same iteration counts on 98-100 % of the problems, NOT the same bits as the other
- * kernels -- which is why it is a flag and not the default.  64 satellites: solve kernel 1.11 against 1.32 ms at 30 nodes, call 1.76
+ * kernels -- which is why it is a flag and not the default.  64 satellites: solve kernel 1.09 against 1.33 ms at 30 nodes, call 1.76
  * against 2.36 ms at 60.  The satellite's workgroups wait for each other (a cooperative launch, every wait with a
  * time limit that ends the solve with MPCX_ST_NUMERIC): one time-parallel solve per device at a time. */
 #define MPCX_SOLVE_TIME_PARALLEL 64
