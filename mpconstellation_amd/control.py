@@ -113,7 +113,7 @@ class OptimalController(Controller):
     opt_trajectory, sequence_controller."""
 
     def __init__(self, sats=[], objective=None, base_res=100, tf_horizon=1, tf_interval=1, plot_inter=True,
-                 opt_verbose=True, r_des=1.5, strict=False, device=0):
+                 opt_verbose=True, r_des=1.5, strict=False, device=0, time_parallel=False):
         super().__init__(sats)
         from .satellite_scale import SatelliteScale
         self.u = np.zeros((3, 1))
@@ -132,12 +132,16 @@ class OptimalController(Controller):
         # instead of flying an unconverged plan.
         self.strict = strict
         self.device = device
+        # the plan's solves on the time-parallel kernel (include/mpcx.h, MPCX_SOLVE_TIME_PARALLEL: the horizon in four segments
+        # side by side -- this controller plans for ONE satellite, the case that kernel is for; same iterations, not the bits
+        # the satellite gets as part of a large batch, hence not the default)
+        self.time_parallel = time_parallel
 
     def update(self):
         from .constellation_mpc import ConstellationMPC
         mpc = ConstellationMPC([self.sat], base_res=self.base_res, tf_horizon=self.horizon, tf_interval=self.interval,
                                r_des=self.r_des, scp_iterations=self.SCPn_iterations, device=self.device, strict=self.strict,
-                               scales=[self.scale], verbose=self.opt_verbose)
+                               scales=[self.scale], verbose=self.opt_verbose, time_parallel=self.time_parallel)
         mpc.update()
         self.last_status = [int(c) for c in mpc.last_status[:, 0]]
         self.opt_trajectory = mpc.plan_x[0]

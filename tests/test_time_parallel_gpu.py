@@ -94,3 +94,19 @@ def test_closed_loop_with_the_time_parallel_kernel():
     assert np.abs(a.last_iters - b.last_iters).max() <= 2
     for sa, sb in zip(a.sats, b.sats):
         assert np.allclose(sa.position, sb.position, rtol=1e-6) and np.allclose(sa.velocity, sb.velocity, rtol=1e-6)
+
+
+def test_optimal_controller_on_the_time_parallel_kernel():
+    """the reference's controller plans for one satellite (control.py:162): its two SCP iterations both ways"""
+    from mpconstellation_amd import Satellite
+    from mpconstellation_amd.control import OptimalController
+    from mpconstellation_amd.constellation import constellation_states
+    st = constellation_states(1)[0]
+    plans = []
+    for tpar in (False, True):
+        sat = Satellite(st[:3].copy(), st[3:6].copy(), float(st[6]))
+        c = OptimalController([sat], base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, opt_verbose=False, plot_inter=False, time_parallel=tpar)
+        c.update()
+        assert all(code in (0, 7) for code in c.last_status)
+        plans.append((c.opt_trajectory.copy(), c.sequence_controller.u.copy(), c.sequence_controller.end_tau))
+    assert np.abs(plans[0][0] - plans[1][0]).max() < 1e-6 and np.abs(plans[0][1] - plans[1][1]).max() < 1e-6 and abs(plans[0][2] - plans[1][2]) < 1e-8
