@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 400
+#define MPCX_VERSION 500
 
 /* return codes */
 #define MPCX_OK 0
@@ -51,6 +51,10 @@ extern "C" {
                                * bounds, terminal window outside r_max, r_min > r_max, empty window or tf range); seen before
                                * the first iteration: x_bar, u_bar, tf_bar come back, kkt = the violation (ipopt: restoration
                                * failure / "converged to a point of local infeasibility", ignored by optimizer.py:603) */
+#define MPCX_ST_TIMEOUT 10    /* time-parallel solve only (MPCX_SOLVE_TIME_PARALLEL): one of the satellite's workgroups did not answer
+                               * within the wait limit (~0.1 s of polling) -- e.g. another long kernel kept it from becoming
+                               * resident; not a numerical failure: X, U, NU hold the last iterate, kkt = -1; solve again
+                               * without the flag or with the device to itself */
 
 /* dynamics flags (reference include_drag / include_J2 keyword arguments) */
 #define MPCX_FLAG_DRAG 1
@@ -88,6 +92,24 @@ int mpcx_synchronize(mpcx_ctx *ctx, void *stream);
  * for the device's default stream, MPCX_STREAM_PRIVATE for a new private stream.  The old stream is drained first. */
 #define MPCX_STREAM_PRIVATE ((void *)(intptr_t)-1)
 int mpcx_set_stream(mpcx_ctx *ctx, void *stream);
+/* Where a host-pointer call's time went, as data (the reference has no counterpart: its solve is a subprocess whose time
+ * optimizer.py:603 does not look at).  mpcx_trace_enable(ctx, 1): every following host-pointer call on the context records, at
+ * the price of four events and one polled marker per call,
+ *   MPCX_TR_WALL          entry to return on the host, ms
+ *   MPCX_TR_FIRST_MARKER  from entry until the stream has executed the call's FIRST packet (a bare marker, polled): time the
+ *                         queue took to pick the call up -- before any work of this library ran
+ *   MPCX_TR_HOST_STAGE    host copies into the staging pool + enqueueing of transfers and kernels
+ *   MPCX_TR_HOST_WAIT     host blocked on the stream (events of the downloads, final synchronisation)
+ *   MPCX_TR_HOST_COPYOUT  staging -> the caller's result arrays
+ *   MPCX_TR_DEV_SPAN      the device's own time stamps: first marker -> last download done
+ *   MPCX_TR_DEV_KERNELS   ... first marker -> first download queued (uploads + kernels)
+ *   MPCX_TR_VALID         1 when the record belongs to a traced call
+ * mpcx_last_call_trace copies the record of the context's last traced call (n <= MPCX_TRACE_N doubles).  The same marks are
+ * printed to stderr for calls slower than MPCX_HOST_TRACE=<ms> (environment), with or without mpcx_trace_enable. */
+enum { MPCX_TR_WALL = 0, MPCX_TR_FIRST_MARKER = 1, MPCX_TR_HOST_STAGE = 2, MPCX_TR_HOST_WAIT = 3, MPCX_TR_HOST_COPYOUT = 4,
+       MPCX_TR_DEV_SPAN = 5, MPCX_TR_DEV_KERNELS = 6, MPCX_TR_VALID = 7, MPCX_TRACE_N = 8 };
+int mpcx_trace_enable(mpcx_ctx *ctx, int on);
+int mpcx_last_call_trace(const mpcx_ctx *ctx, double *out, int n);
 /* Page-locked host memory for the arrays a caller hands to the host-pointer entry points again and again (the reference
  * keeps x_bar / u_bar / results in numpy arrays, optimizer.py:13-39, 192-217; a numpy array can live in such a buffer).
  * Arrays in page-locked memory are transferred by DMA straight from / to the caller's buffer; pageable ones go through the
@@ -181,8 +203,15 @@ typedef struct {
  * directions to ~1e-10 relative, the same iteration counts on 98-100 % of the problems, NOT the same bits as the other
  * kernels -- which is why it is a flag and not the default.  64 satellites: solve kernel 1.09 against 1.33 ms at 30 nodes, call 1.76
  * against 2.36 ms at 60.  The satellite's workgroups wait for each other (a cooperative launch, every wait with a
- * time limit that ends the solve with MPCX_ST_NUMERIC): one time-parallel solve per device at a time. */
+ * time limit that ends that satellite's solve with MPCX_ST_TIMEOUT): one time-parallel solve per device at a time -- a long
+ * kernel of another stream or context that keeps some of a satellite's workgroups from becoming resident runs the limit out.
+ * A batch the device cannot hold at once (more satellites than a quarter of its resident workgroups) takes the default kernels,
+ * like a batch above 128. */
 #define MPCX_SOLVE_TIME_PARALLEL 64
+/* Test hook of the time-parallel kernel (tests/test_time_parallel_oracle_gpu.py): the workgroup of every satellite's first
+ * segment leaves before its first command, so that the wait limit runs out -- every satellite must come back MPCX_ST_TIMEOUT with
+ * defined results and the launch must end.  No effect without MPCX_SOLVE_TIME_PARALLEL. */
+#define MPCX_SOLVE_TP_SELFTEST_DEAD (1 << 30)
 
 void mpcx_default_solve_opts(mpcx_solve_opts *o);
 /* Workspace of the _dev solves / fused steps.  The plain queries are device-independent upper bounds (one slot per

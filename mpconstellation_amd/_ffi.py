@@ -15,6 +15,7 @@ STATUS_TEXT = {
     5: "solver hit max_iter", 6: "solver numeric breakdown", 7: "solver stopped at acceptable level",
     9: "ragged batch: node / table-column / output-point count outside the accepted range",
     8: "constraint set empty (start node outside its radius bounds, terminal window outside r_max, empty window or tf range)",
+    10: "time-parallel solve: a workgroup of the satellite did not answer within the wait limit (device shared with another long kernel?)",
 }
 FLAG_DRAG, FLAG_J2, FLAG_UNIFORM_STEPS, FLAG_RK23 = 1, 2, 4, 8
 CTRL_ZERO, CTRL_CONSTANT, CTRL_TANGENTIAL, CTRL_SEQUENCE = 0, 1, 2, 3
@@ -51,6 +52,8 @@ _SIGS = {
     "mpcx_last_error": (C.c_char_p, [_vp]),
     "mpcx_synchronize": (C.c_int, [_vp, _vp]),
     "mpcx_set_stream": (C.c_int, [_vp, _vp]),
+    "mpcx_trace_enable": (C.c_int, [_vp, C.c_int]),
+    "mpcx_last_call_trace": (C.c_int, [_vp, _dp, C.c_int]),
     "mpcx_host_alloc": (_vp, [_vp, C.c_size_t]),
     "mpcx_host_free": (None, [_vp, _vp]),
     "mpcx_discretize_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
@@ -151,6 +154,23 @@ def set_stream(stream, device=0, slot=0):
     check(lib.mpcx_set_stream(ctx, stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream or 0)), ctx, "mpcx_set_stream")
 
 
+TRACE_FIELDS = ("wall_ms", "first_marker_ms", "host_stage_ms", "host_wait_ms", "host_copyout_ms", "dev_span_ms", "dev_kernels_ms", "valid")
+
+
+def trace_enable(on=True, device=0, slot=0):
+    """every following host-pointer call of this context records where its time went (include/mpcx.h, mpcx_trace_enable)"""
+    lib = load(); ctx = context(device, slot)
+    check(lib.mpcx_trace_enable(ctx, 1 if on else 0), ctx, "mpcx_trace_enable")
+
+
+def last_call_trace(device=0, slot=0):
+    """the record of the context's last traced host-pointer call as a dict (TRACE_FIELDS), or None if there is none"""
+    lib = load(); ctx = context(device, slot)
+    out = np.zeros(len(TRACE_FIELDS))
+    check(lib.mpcx_last_call_trace(ctx, dptr(out), len(out)), ctx, "mpcx_last_call_trace")
+    return dict(zip(TRACE_FIELDS, out.tolist())) if out[-1] else None
+
+
 class _PinnedOwner:
     """keeps a page-locked allocation alive as long as a numpy array views it"""
 
@@ -245,6 +265,7 @@ def iptr(a):
 
 SOLVER_KEYWORDS = ("tol", "acceptable_tol", "max_iter", "acceptable_iter", "n_refine", "flags")
 SOLVE_INDEX_ORDER, SOLVE_LINEAR_VT, SOLVE_FIXED_TF, SOLVE_SHARED_TF, SOLVE_ONE_WAVE, SOLVE_NO_LDS, SOLVE_TIME_PARALLEL = 1, 2, 4, 8, 16, 32, 64      # mpcx_solve_opts.flags (include/mpcx.h)
+SOLVE_TP_SELFTEST_DEAD = 1 << 30
 
 
 def check_solver_keywords(solver):

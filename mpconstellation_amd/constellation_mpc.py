@@ -41,6 +41,11 @@ class ConstellationMPC:
         # context per device, no exchange between them (sharding.sharded_call) -- the reference loops over
         # its satellites serially (simulator.py:41,58)
         self.devices = list(devices) if devices is not None else None
+        if verbose and self.devices is not None and len(self.devices) > 1:
+            # (verbose prints control.py:208-209's lines between the SCP iterations: one library call per iteration on ONE
+            #  context; silently solving on self.device while the flight is sharded would be neither of the two things asked for)
+            raise ValueError("ConstellationMPC: verbose=True runs the SCP iterations as separate calls on one device; "
+                             "use devices=[...] without verbose, or verbose with a single device")
         # time_parallel: the solves of small constellations (up to 128 satellites) on the time-parallel kernel (include/mpcx.h,
         # MPCX_SOLVE_TIME_PARALLEL: the horizon in four segments side by side; same iterations, not the other kernels' bits)
         self.solver_flags = _ffi.SOLVE_TIME_PARALLEL if time_parallel else 0

@@ -39,6 +39,7 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     c->copier = nullptr;
     c->counter = nullptr; c->launch_seq = 0; c->n_slots = prop.multiProcessorCount * 8;
     c->red = nullptr; c->red_cap = 0; c->coop_max = 0; c->tp_max = 0;
+    c->trace_on = 0; for (double &v : c->last_trace) v = 0.0;
     c->pool_dev.cur = c->pool_dev.off = 0; c->pool_dev.pinned = false;
     c->pool_host.cur = c->pool_host.off = 0; c->pool_host.pinned = true;
     c->own_stream = true;
@@ -75,11 +76,27 @@ extern "C" int mpcx_set_stream(mpcx_ctx *ctx, void *stream)
     if (!ctx) return MPCX_E_BADARG;
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
     MPCX_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // nothing of this context is left on the old stream
-    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
-    if (stream == MPCX_STREAM_PRIVATE) {
-        MPCX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    } else ctx->stream = (hipStream_t)stream;                          // (NULL: the device's default stream)
+    // (the new stream exists before the old one goes: a failed creation leaves the context on its old, valid stream)
+    hipStream_t fresh = (hipStream_t)stream;                           // (NULL: the device's default stream)
+    if (stream == MPCX_STREAM_PRIVATE) MPCX_HIP(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = fresh;
+    ctx->own_stream = (stream == MPCX_STREAM_PRIVATE);
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_trace_enable(mpcx_ctx *ctx, int on)
+{
+    if (!ctx) return MPCX_E_BADARG;
+    ctx->trace_on = on ? 1 : 0;
+    ctx->last_trace[MPCX_TR_VALID] = 0.0;
+    return MPCX_OK;
+}
+
+extern "C" int mpcx_last_call_trace(const mpcx_ctx *ctx, double *out, int n)
+{
+    if (!ctx || !out || n < 1) return MPCX_E_BADARG;
+    for (int i = 0; i < n; ++i) out[i] = i < MPCX_TRACE_N ? ctx->last_trace[i] : 0.0;
     return MPCX_OK;
 }
 
@@ -98,7 +115,7 @@ extern "C" void *mpcx_host_alloc(mpcx_ctx *ctx, size_t bytes)
     if (!ctx || !bytes) return nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { ctx_fail(ctx, MPCX_E_NOMEM, "page-locked allocation failed"); return nullptr; }
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess)        // (portable: a multi-device call's result set is the DMA target of every device) { ctx_fail(ctx, MPCX_E_NOMEM, "page-locked allocation failed"); return nullptr; }
     return p;
 }
 

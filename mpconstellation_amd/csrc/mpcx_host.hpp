@@ -136,6 +136,8 @@ struct mpcx_ctx {
     double *red;              // shared-tf launches: reduction slots + arrival counter + abort flag
     int red_cap, coop_max;    // coop_max: workgroups of solve_shared_kernel resident at once (0: not asked yet, -1: unsupported)
     int tp_max;               // satellites the time-parallel kernel holds at once (0: not asked yet, -1: query failed)
+    int trace_on;             // mpcx_trace_enable: every host-pointer call records where its time went (last_trace), without the env switch
+    double last_trace[MPCX_TRACE_N];   // the last traced call's record (include/mpcx.h: MPCX_TR_*)
     StagePool pool_dev, pool_host;     // staging of the host-pointer entry points
     HostCopier *copier;                // worker threads of the pageable <-> page-locked copies (created on first use)
     std::vector<hipEvent_t> events;    // one per download of a host-pointer call: its copy-out starts when ITS transfer is done
@@ -192,12 +194,20 @@ struct HostTrace {
     double t[CAP];
     int n;
     bool on;
-    HostTrace() : n(0), on(host_trace_threshold_ms() >= 0.0) { mark("enter"); }
+    explicit HostTrace(bool force = false) : n(0), on(force || host_trace_threshold_ms() >= 0.0) { mark("enter"); }
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void mark(const char *what) { if (on && n < CAP) { name[n] = what; t[n] = now(); ++n; } }
+    // sum of the segments whose name starts with `prefix` (a segment is named by the mark that ENDS it)
+    double sum(const char *prefix) const
+    {
+        double acc = 0.0;
+        const size_t len = strlen(prefix);
+        for (int i = 1; i < n; ++i) if (strncmp(name[i], prefix, len) == 0) acc += t[i] - t[i - 1];
+        return acc;
+    }
     void report(const char *call)
     {
-        if (!on || n < 2 || t[n - 1] - t[0] < host_trace_threshold_ms()) return;
+        if (!on || n < 2 || host_trace_threshold_ms() < 0.0 || t[n - 1] - t[0] < host_trace_threshold_ms()) return;
         fprintf(stderr, "[mpcx host trace] %s: %.3f ms:", call, t[n - 1] - t[0]);
         for (int i = 1; i < n; ++i) fprintf(stderr, " %s %.3f", name[i], t[i] - t[i - 1]);
         fprintf(stderr, "\n");
@@ -207,7 +217,7 @@ struct HostTrace {
 // Bump allocator over the two pools for the duration of one host-pointer call.
 class DeviceArena {
   public:
-    explicit DeviceArena(mpcx_ctx *c) : ctx_(c), code_(0), dirty_(false)
+    explicit DeviceArena(mpcx_ctx *c) : trace(c->trace_on != 0), ctx_(c), code_(0), dirty_(false)
     {
         pool_reset(c->pool_dev); pool_reset(c->pool_host);
         for (auto &e : dev_ev_) e = nullptr;
@@ -325,10 +335,21 @@ class DeviceArena {
         dirty_ = false;
         for (const auto &o : out_) if (!o.ev) memcpy(o.dst, o.src, o.bytes);
         trace.mark("fin:small");
-        if (trace.on && trace.t[trace.n - 1] - trace.t[0] >= host_trace_threshold_ms() && dev_ev_[0] && dev_ev_[2] && dev_ev_[3]) {
+        if (trace.on && dev_ev_[0] && dev_ev_[2] && dev_ev_[3]) {
             float a = 0.f, b = 0.f;
             (void)hipEventElapsedTime(&a, dev_ev_[0], dev_ev_[2]); (void)hipEventElapsedTime(&b, dev_ev_[2], dev_ev_[3]);
-            fprintf(stderr, "[mpcx host trace] device view: uploads + kernels %.3f ms, downloads %.3f ms\n", a, b);
+            if (host_trace_threshold_ms() >= 0.0 && trace.t[trace.n - 1] - trace.t[0] >= host_trace_threshold_ms())
+                fprintf(stderr, "[mpcx host trace] device view: uploads + kernels %.3f ms, downloads %.3f ms\n", a, b);
+            // the call's record for mpcx_last_call_trace: the host's segments by kind, the device's own time stamps
+            double *r = ctx_->last_trace;
+            r[MPCX_TR_WALL] = trace.t[trace.n - 1] - trace.t[0];
+            r[MPCX_TR_FIRST_MARKER] = trace.sum("q:");
+            r[MPCX_TR_HOST_STAGE] = trace.sum("up:") + trace.sum("kernels") + trace.sum("down:");
+            r[MPCX_TR_HOST_WAIT] = trace.sum("fin:event") + trace.sum("fin:sync");
+            r[MPCX_TR_HOST_COPYOUT] = trace.sum("fin:copy") + trace.sum("fin:small");
+            r[MPCX_TR_DEV_SPAN] = (double)a + (double)b;
+            r[MPCX_TR_DEV_KERNELS] = (double)a;
+            r[MPCX_TR_VALID] = 1.0;
         }
         trace.report("host-pointer call");
         return MPCX_OK;

@@ -28,6 +28,7 @@ static SolveOpts to_dev_opts(const mpcx_solve_opts *o)
     d.tol = o->tol; d.acc_tol = o->acceptable_tol; d.max_iter = o->max_iter; d.acc_iter = o->acceptable_iter;
     d.n_refine = o->n_refine; d.linvt = (o->flags & MPCX_SOLVE_LINEAR_VT) ? 1 : 0;
     d.fixed_tf = (o->flags & MPCX_SOLVE_FIXED_TF) ? 1 : 0; d.shared_tf = (o->flags & MPCX_SOLVE_SHARED_TF) ? 1 : 0;
+    d.tp_selftest = (o->flags & MPCX_SOLVE_TP_SELFTEST_DEAD) ? 1 : 0;
     return d;
 }
 
@@ -192,12 +193,17 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     // tests/test_full_size_gpu.py::test_two_wave_small_batch_kernel).  MPCX_SOLVE_ONE_WAVE keeps the one-wave kernel.
     // at most one satellite per compute unit: the LDS-resident build (solve_lds.hip), if the horizon's working set fits
     int lds = 1;
-    if ((opts->flags & MPCX_SOLVE_TIME_PARALLEL) && S <= kTimeParallelMax && K >= kTimeParallelMinK) {
-        // the time-parallel kernel: four workgroups per satellite, each on its own compute unit while the batch is that small,
-        // all resident (they wait for each other); its own slot size, one slot per satellite; the satellites' mailboxes zeroed
+    bool tp = (opts->flags & MPCX_SOLVE_TIME_PARALLEL) && S <= kTimeParallelMax && K >= kTimeParallelMinK;
+    if (tp) {
         if (ctx->tp_max == 0) { const int per_cu = mpcxtp_blocks_per_cu(); ctx->tp_max = per_cu > 0 ? per_cu * (ctx->n_slots / 8) / TP_MAXSEG : -1; }
         if (ctx->tp_max < 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: occupancy query of the time-parallel kernel failed");
-        if (((S + 7) / 8) * 8 > ctx->tp_max) return ctx_fail(ctx, MPCX_E_BADARG, "solve: MPCX_SOLVE_TIME_PARALLEL takes at most as many satellites as the device holds their workgroups at once");
+        // (a device that cannot hold the batch's workgroups at once -- fewer compute units, another partition mode -- solves it with
+        //  the default kernels, as it does a batch above kTimeParallelMax: the flag asks for speed, never for an error)
+        if (((S + 7) / 8) * 8 > ctx->tp_max) tp = false;
+    }
+    if (tp) {
+        // the time-parallel kernel: four workgroups per satellite, each on its own compute unit while the batch is that small,
+        // all resident (they wait for each other); its own slot size, one slot per satellite; the satellites' mailboxes zeroed
         a.ws_stride = ws_doubles_tp(K);
         MPCX_HIP(ctx, hipMemset2DAsync((double *)workspace + tp_mail_offset(K), a.ws_stride * sizeof(double), 0, TP_MAIL_N * sizeof(double), (size_t)S, (hipStream_t)stream));
         if (mpcxtp_launch(&a, sizeof a, S, (hipStream_t)stream) != 0) return ctx_fail(ctx, MPCX_E_HIP, "solve: time-parallel launch failed");

@@ -55,6 +55,7 @@ struct SolveOpts {
     int max_iter, acc_iter, n_refine, linvt;    // linvt: the linearised tangential pair (optimizer.py:471-489) instead of the quartic
     int fixed_tf, shared_tf;                    // fixed_tf: tf is held at the value passed in tf_out (MPCX_SOLVE_FIXED_TF);
                                                 // shared_tf: ONE tf for all satellites of the launch (MPCX_SOLVE_SHARED_TF)
+    int tp_selftest;                            // MPCX_SOLVE_TP_SELFTEST_DEAD: the first segment's workgroup leaves unasked (test hook)
 };
 
 struct SolveArgs {

@@ -28,19 +28,29 @@ int mpcxl_launch(const void *args, size_t args_bytes, int blocks, hipStream_t st
     static bool asked[kMaxDev];
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
+    if (dev >= kMaxDev) return 1;                          // (beyond the table: the global-workspace kernel, not an error)
     int lds_limit;
     {
         std::lock_guard<std::mutex> g(mu);
         if (!asked[dev]) {
+            // Any failure here means "this device does not give the kernel its LDS": remembered as a limit of 0, the caller takes
+            // the global-workspace kernel (return 1) -- never a failed solve.  The runtime reports 64 KB per block for gfx950 where
+            // the hardware and the compiler allow 160 KB (SURVEY: 160 KB compiles, 161 KB does not), so 160 KB is TRIED first and
+            // the reported value second; what hipFuncSetAttribute accepts is the limit.
+            int room = 0;
             hipFuncAttributes at;
-            if (hipFuncGetAttributes(&at, (const void *)MPCX_NS::solve_kernel_lds) != hipSuccess) return -1;
             int max_lds = 0;
-            if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return -1;
-            if (max_lds < 160 * 1024) max_lds = 160 * 1024;                 // (gfx950: 160 KB per workgroup)
-            const int room = max_lds - (int)at.sharedSizeBytes;
-            if (room > 0 && hipFuncSetAttribute((const void *)MPCX_NS::solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) return -1;
-            limits[dev] = room > 0 ? room : 0;
+            if (hipFuncGetAttributes(&at, (const void *)MPCX_NS::solve_kernel_lds) == hipSuccess &&
+                hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) {
+                const int tries[2] = {160 * 1024 - (int)at.sharedSizeBytes, max_lds - (int)at.sharedSizeBytes};
+                for (int t = 0; t < 2 && room == 0; ++t)
+                    if (tries[t] > 0 && (t == 0 || tries[t] < tries[0]) &&
+                        hipFuncSetAttribute((const void *)MPCX_NS::solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, tries[t]) == hipSuccess)
+                        room = tries[t];
+            }
+            (void)hipGetLastError();                       // (a refused attribute must not surface as the next launch's error)
+            limits[dev] = room;
             asked[dev] = true;
         }
         lds_limit = limits[dev];

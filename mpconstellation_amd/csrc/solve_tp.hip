@@ -42,9 +42,11 @@ __global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel_tp(SolveAr
         if (wave == 0) {
             solve_satellite<false>(a, sat, sat, sd, w, lane);
             TP_DBG("[drv b%d] solve_satellite returned, dead %d\n", (int)blockIdx.x, tp.dead);
-            if (tp.dead) {            // a wait ran out: say so, with the mailbox as it stands in the first entries of the NU block
-                if (lane == 0) { a.status[sat] = MPCX_ST_NUMERIC; a.kkt[sat] = -1.0; }
+            if (tp.dead) {            // a wait ran out: not a numerical failure -- its own status; X, U, NU are the last iterate
+                if (lane == 0) { a.status[sat] = MPCX_ST_TIMEOUT; a.kkt[sat] = -1.0; }
+#ifdef MPCX_TP_DEBUG                 // (diagnostic build only: the mailbox as it stands in the first entries of the NU block)
                 if (lane < TP_MAIL_N * 2) a.NU[(size_t)sat * 7 * Kmax + lane] = (double)s.mail[lane];
+#endif
             }
             tp_post(s, tp, CMD_EXIT, 0, lane);
             if (lane == 0) w.cmd = CMD_EXIT;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel_tp(SolveAr
             }
         }
     } else
-        tp_worker(s, sd, tp, j, wave, lane);
+        tp_worker(s, sd, tp, j, wave, lane, a.o.tp_selftest != 0);
 }
 
 }  // namespace MPCX_NS

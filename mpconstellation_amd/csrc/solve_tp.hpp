@@ -81,7 +81,12 @@ constexpr int kTpSpinMax = 1 << 17;
 #endif
 __device__ __forceinline__ void tp_release(bool light)
 {
-    if (light && MPCX_TP_REL_MODE == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // s_waitcnt: the stores are in L2 (L1 is write-through)
+    // light: the wave's stores must have reached the common L2 (the L1 is write-through) before the mailbox word that announces them
+    // is written.  Outside tgsplit mode a workgroup-scope release fence waits for lgkmcnt only (LDS is what a workgroup shares), so
+    // the wait for the global stores is spelled out: without it the mailbox update, which travels to another L2 channel than the
+    // data, could become visible first (round-4 advice; the ISA of the round-4 build had no vmcnt wait between the last
+    // exchange-record store and the DONE atomic).  s_waitcnt counts per wave: issued under any exec mask it covers all lanes' stores.
+    if (light && MPCX_TP_REL_MODE == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 __device__ __forceinline__ void tp_acquire(bool light)
@@ -701,13 +706,14 @@ __device__ __forceinline__ void tp_cmd_combine(const Sat &s, SatData &sd, TpData
 
 // a workgroup that owns another segment: wait for the first workgroup's commands (its first wave polls the mailbox, the second
 // follows through LDS), run them on the segment, leave the exchange record, report
-__device__ __forceinline__ void tp_worker(const Sat &s, SatData &sd, TpData &tp, int j, int wave_in, int lane)
+__device__ __forceinline__ void tp_worker(const Sat &s, SatData &sd, TpData &tp, int j, int wave_in, int lane, bool selftest_dead)
 {
     int *m = s.mail;
     // (every branch on the wave index or on the command is made scalar: with the loop's exit depending on values the compiler
     //  takes for per-lane ones, the structurised loop dropped all lanes but one of the polling wave after its first pass)
     const int wave = __builtin_amdgcn_readfirstlane(wave_in);
     if (wave == 0 && lane == 0) __hip_atomic_store(m + TPM_XCC + j, 1 + tp_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (selftest_dead && j == 0) return;           // MPCX_SOLVE_TP_SELFTEST_DEAD: this workgroup never answers (the first one's wait must run out)
     for (;;) {
         if (wave == 0) {
             TP_DBG("[wrk b%d seg %d] polling for seq > %d\n", (int)blockIdx.x, j, tp.seq);

@@ -18,7 +18,11 @@ class Discretizer:
         self.const = const
         self.include_drag = include_drag
         self.include_J2 = include_J2
-        self.use_scipy_ZOH = use_scipy_ZOH   # same piecewise-linear hold; evaluated by the FOH formula
+        # use_scipy_ZOH (linearize_discretize.py:327-329): the reference then evaluates the hold with scipy's interp1d(kind='linear')
+        # -- the same piecewise-linear function as u_FOH, its own two evaluations <= 1e-16 relative apart on the goldens.  The device
+        # evaluates the FOH formula in both modes and is pinned against arrays the reference produced WITH the flag
+        # (tests/golden/scipy_zoh_discretize.npz, tests/test_discretize_gpu.py::test_scipy_zoh_mode_vs_reference: 1e-10 relative)
+        self.use_scipy_ZOH = use_scipy_ZOH
         self.rho_func = rho_func
         self.drho_func = drho_func
         # ODE / quadrature settings, same names and defaults as the reference (:104-109)

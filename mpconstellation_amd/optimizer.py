@@ -20,9 +20,9 @@ class SolveResult:
         self.first_regularised = None if regularised is None else regularised[:, 1]
 
 
-def _regularised(lib, ctx, S):
+def _regularised(lib, ctx, S, out=None):
     """mpcx_solve_regularised of the solve that just returned on this context"""
-    out = np.zeros((S, 2), dtype=np.int32)
+    out = np.zeros((S, 2), dtype=np.int32) if out is None else out
     _ffi.check(lib.mpcx_solve_regularised(ctx, S, _ffi.iptr(out)), ctx, "mpcx_solve_regularised")
     return out
 
@@ -69,7 +69,8 @@ def _result_arrays(S, K, device, pinned):
         take = _ffi.result_pool.take         # (large arrays are recycled once the caller has dropped the previous results)
         return (take((S, 7, K)), take((S, 3, K)), take((S, 7, K)), np.empty(S), np.zeros(S, dtype=np.int32),
                 np.zeros(S, dtype=np.int32))
-    key = (S, K, device)
+    key = (S, K, device)          # (device: an index, or the tuple of a multi-device call -- one page-locked set for the constellation)
+    device = device[0] if isinstance(device, tuple) else device
     if key not in _pinned_results:
         _pinned_results[key] = (_ffi.pinned_empty((S, 7, K), device=device), _ffi.pinned_empty((S, 3, K), device=device),
                                 _ffi.pinned_empty((S, 7, K), device=device), _ffi.pinned_empty((S,), device=device),
@@ -87,7 +88,7 @@ def _tf_io(S, fixed_tf):
 
 def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False, max_step=1e-2, device=0, slot=0,
                    linear_vt=False, fixed_tf=None, pinned_results=False, uniform_steps=0, regularised=False, Ks=None, shared_tf=False,
-                   devices=None, rk23=False, **solver):
+                   devices=None, rk23=False, out=None, **solver):
     """S independent satellite-MPC-steps (discretize + solve) on the device.
     xbar (S,7,K), ubar (S,3,K), tf (S,), consts (S,8), r_des (S,) -> SolveResult with batched arrays.
     Ks (S,) int: a ragged batch -- satellite s has Ks[s] <= K nodes in the first columns of its rows (what the reference's
@@ -96,18 +97,24 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     Inputs that live in page-locked memory (_ffi.pinned_copy) are transferred without a staging copy; pinned_results=True
     returns the results in page-locked buffers that the next call of the same shape overwrites.
     devices=[d0, d1, ...]: the satellites are dealt out in contiguous blocks to these devices (sharding.sharded_call: one
-    host thread and context per device, no exchange between them) and the blocks' results joined; satellites are
-    independent units, so every satellite gets bit for bit what a single-device call gives it."""
+    host thread and context per device, no exchange between them), every block writing its results in place into its slice of
+    ONE result set for the constellation (page-locked with pinned_results=True: then every device's DMA lands in the caller's
+    arrays directly); satellites are independent units, so every satellite gets bit for bit what a single-device call gives it.
+    out: (internal) views of such a result set for this call's satellites -- X, U, NU, tf, status, iters, kkt[, regularised]."""
     if devices is not None and len(devices) > 1:
-        if shared_tf or fixed_tf is not None or pinned_results:
-            raise ValueError("devices=[...]: independent per-satellite problems only (no shared / fixed tf, no pinned_results)")
-        from .sharding import sharded_call, join_results
-        xbar = _ffi.as_f64(xbar); S = xbar.shape[0]
+        if shared_tf or fixed_tf is not None:
+            raise ValueError("devices=[...]: independent per-satellite problems only (no shared / fixed tf)")
+        from .sharding import sharded_call
+        xbar = _ffi.as_f64(xbar); S, _, K = xbar.shape
         bc = lambda a: _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)))
         Ksb = None if Ks is None else np.ascontiguousarray(np.broadcast_to(np.asarray(Ks), (S,)), dtype=np.int32)
-        fn = lambda x, u, t, c, r, k, device, slot: mpc_step_batch(x, u, t, c, r, options, include_J2, max_step, device, slot, linear_vt,
-                                                                   None, False, uniform_steps, regularised, k, False, None, rk23, **solver)
-        return join_results(sharded_call(fn, devices, [xbar, _ffi.as_f64(ubar), bc(tf), _ffi.as_f64(consts), bc(r_des), Ksb]))
+        X, U, NU, kkt, status, iters = _result_arrays(S, K, tuple(int(d) for d in devices) if pinned_results else int(devices[0]), pinned_results)
+        tfo = np.empty(S); reg = np.zeros((S, 2), dtype=np.int32) if regularised else None
+        fn = lambda x, u, t, c, r, k, device, slot, out: mpc_step_batch(x, u, t, c, r, options, include_J2, max_step, device, slot, linear_vt,
+                                                                        None, False, uniform_steps, regularised, k, False, None, rk23, out, **solver)
+        sharded_call(fn, devices, [xbar, _ffi.as_f64(ubar), bc(tf), _ffi.as_f64(consts), bc(r_des), Ksb],
+                     dict(X=X, U=U, NU=NU, kkt=kkt, status=status, iters=iters, tf=tfo, regularised=reg))
+        return SolveResult(X, U, NU, tfo, status, iters, kkt, regularised=reg)
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
     solver = _solver_flags(solver, linear_vt, fixed_tf, shared_tf)
@@ -119,8 +126,15 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
     r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
     consts = _ffi.as_f64(consts)
     opts = _ffi.make_solve_opts(options, **solver)
-    X, U, NU, kkt, status, iters = _result_arrays(S, K, device, pinned_results and slot == 0)
-    tfo, held = _tf_io(S, fixed_tf)
+    if out is None:
+        X, U, NU, kkt, status, iters = _result_arrays(S, K, device, pinned_results and slot == 0)
+        tfo, held = _tf_io(S, fixed_tf)
+    else:                                                  # (a block of a multi-device call: its slice of the constellation's arrays)
+        from .sharding import OutArrays
+        oa = OutArrays(out)
+        X, U, NU = oa.get("X", (S, 7, K)), oa.get("U", (S, 3, K)), oa.get("NU", (S, 7, K))
+        kkt, status, iters = oa.get("kkt", (S,)), oa.get("status", (S,), np.int32), oa.get("iters", (S,), np.int32)
+        tfo, held = oa.get("tf", (S,)), None
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
     dflags = _ffi.FLAG_J2 if include_J2 else 0
@@ -140,7 +154,9 @@ def mpc_step_batch(xbar, ubar, tf, consts, r_des, options=None, include_J2=False
                                             _ffi.dptr(X), _ffi.dptr(U), _ffi.dptr(NU), _ffi.dptr(tfo), _ffi.iptr(status),
                                             _ffi.iptr(iters), _ffi.dptr(kkt))
     _ffi.check(rc, ctx, "mpcx_mpc_step_batch")
-    reg = _regularised(lib, ctx, S) if regularised else None
+    reg = _regularised(lib, ctx, S, None if out is None else out.get("regularised")) if regularised else None
+    if out is not None:
+        oa.finish()
     return SolveResult(X, U, NU, tfo, status, iters, kkt, regularised=reg) if held is None else \
         SolveResult(X, U, NU, held, status, iters, kkt, tfo, reg)
 
@@ -196,7 +212,7 @@ class UpdateResult(SolveResult):
 
 
 def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None, ref_thrust=0.5, include_J2=False, max_step=1e-2,
-                     prop_max_step=1e-3, device=0, slot=0, linear_vt=False, fly=None, devices=None, **solver):
+                     prop_max_step=1e-3, device=0, slot=0, linear_vt=False, fly=None, devices=None, out=None, **solver):
     """OptimalController.update (control.py:170-235) for S satellites in ONE library call (mpcx_mpc_update_batch): the tangential
     reference rollout over `horizon` sampled at K = int(base_res * horizon) nodes, n_scp x (extract_uk, discretise, solve) with
     the nonlinear re-rollout under the optimised sequence -- sampled at int(base_res * tf_u) nodes per satellite -- between
@@ -206,12 +222,17 @@ def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None
     the result then carries y_sim (S,7,n_eval) and sim_status.
     devices=[d0, d1, ...]: contiguous blocks of satellites on several devices at once (see mpc_step_batch)."""
     if devices is not None and len(devices) > 1:
-        from .sharding import sharded_call, join_results
+        from .sharding import sharded_call
         y0 = _ffi.as_f64(y0); S = y0.shape[0]
         bc = lambda a: _ffi.as_f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)))
-        fn = lambda y, h, c, r, device, slot: mpc_update_batch(y, h, c, r, base_res, n_scp, options, ref_thrust, include_J2, max_step,
-                                                               prop_max_step, device, slot, linear_vt, fly, None, **solver)
-        return join_results(sharded_call(fn, devices, [y0, bc(horizon), _ffi.as_f64(consts), bc(r_des)]))
+        hz = bc(horizon); K = int(base_res * float(hz[0]))
+        res = _update_result(S, K, n_scp, int(devices[0]), fly)          # ONE result set; every block fills its satellites' part
+        fn = lambda y, h, c, r, device, slot, out: mpc_update_batch(y, h, c, r, base_res, n_scp, options, ref_thrust, include_J2, max_step,
+                                                                    prop_max_step, device, slot, linear_vt, fly, None, out, **solver)
+        sharded_call(fn, devices, [y0, hz, _ffi.as_f64(consts), bc(r_des)],
+                     dict(X=res.X, U=res.U, NU=res.NU, kkt=res.kkt, tf=res.tf, Ks=res.Ks, prop_status=res.prop_status,
+                          status=(res.status, 1), iters=(res.iters, 1), y_sim=res.y_sim, sim_status=res.sim_status))
+        return res
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
     solver = _solver_flags(solver, linear_vt, None, False)
@@ -223,15 +244,25 @@ def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None
     r_des = _ffi.as_f64(np.broadcast_to(np.asarray(r_des, dtype=np.float64), (S,)))
     consts = _ffi.as_f64(consts)
     opts = _ffi.make_solve_opts(options, **solver)
-    X, U, NU, kkt, _, _ = _result_arrays(S, K, device, False)
-    status = np.zeros((n_scp, S), dtype=np.int32); iters = np.zeros((n_scp, S), dtype=np.int32)
-    tfo = np.empty(S); Ks = np.zeros(S, dtype=np.int32); pst = np.zeros(S, dtype=np.int32)
-    y_sim = sst = None; sim = (0.0, 0.0, 0, 0, 1e-3)
+    sim = (0.0, 0.0, 0, 0, 1e-3)
     if fly is not None:
         tf_sim, interval, n_eval, drag, j2 = fly[:5]
         sim = (float(tf_sim), float(interval), int(n_eval), (_ffi.FLAG_DRAG if drag else 0) | (_ffi.FLAG_J2 if j2 else 0),
                float(fly[5]) if len(fly) > 5 else 1e-3)
-        y_sim = _ffi.result_pool.take((S, 7, sim[2])); sst = np.zeros(S, dtype=np.int32)
+    if out is None:
+        res = _update_result(S, K, n_scp, device, fly)
+        X, U, NU, kkt, status, iters, tfo, Ks, pst, y_sim, sst = (res.X, res.U, res.NU, res.kkt, res.status, res.iters, res.tf, res.Ks,
+                                                                  res.prop_status, res.y_sim, res.sim_status)
+    else:                                                  # (a block of a multi-device call: its slice of the constellation's arrays)
+        from .sharding import OutArrays
+        oa = OutArrays(out)
+        X, U, NU, kkt = oa.get("X", (S, 7, K)), oa.get("U", (S, 3, K)), oa.get("NU", (S, 7, K)), oa.get("kkt", (S,))
+        status, iters = oa.get("status", (n_scp, S), np.int32), oa.get("iters", (n_scp, S), np.int32)
+        tfo, Ks, pst = oa.get("tf", (S,)), oa.get("Ks", (S,), np.int32), oa.get("prop_status", (S,), np.int32)
+        y_sim = oa.get("y_sim", (S, 7, sim[2])) if fly is not None else None
+        sst = oa.get("sim_status", (S,), np.int32) if fly is not None else None
+        res = UpdateResult(X, U, NU, tfo, status, iters, kkt)
+        res.Ks = Ks; res.prop_status = pst; res.y_sim = y_sim; res.sim_status = sst
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     import ctypes as C
     rc = lib.mpcx_mpc_update_batch(ctx, S, K, int(n_scp), float(base_res), _ffi.dptr(y0), _ffi.dptr(horizon), _ffi.dptr(consts),
@@ -240,8 +271,18 @@ def mpc_update_batch(y0, horizon, consts, r_des, base_res, n_scp=2, options=None
                                    _ffi.iptr(Ks), _ffi.iptr(status), _ffi.iptr(iters), _ffi.dptr(kkt), _ffi.iptr(pst), sim[0], sim[1],
                                    sim[2], sim[3], sim[4], None if y_sim is None else _ffi.dptr(y_sim), None if sst is None else _ffi.iptr(sst))
     _ffi.check(rc, ctx, "mpcx_mpc_update_batch")
-    res = UpdateResult(X, U, NU, tfo, status, iters, kkt)
-    res.Ks = Ks; res.prop_status = pst; res.y_sim = y_sim; res.sim_status = sst
+    if out is not None:
+        oa.finish()
+    return res
+
+
+def _update_result(S, K, n_scp, device, fly):
+    """the result set of an update of S satellites (large arrays from the recycling pool: _ffi.result_pool)"""
+    X, U, NU, kkt, _, _ = _result_arrays(S, K, device, False)
+    res = UpdateResult(X, U, NU, np.empty(S), np.zeros((n_scp, S), dtype=np.int32), np.zeros((n_scp, S), dtype=np.int32), kkt)
+    res.Ks = np.zeros(S, dtype=np.int32); res.prop_status = np.zeros(S, dtype=np.int32)
+    res.y_sim = _ffi.result_pool.take((S, 7, int(fly[2]))) if fly is not None else None
+    res.sim_status = np.zeros(S, dtype=np.int32) if fly is not None else None
     return res
 
 
@@ -400,6 +441,33 @@ class Optimizer:
     @staticmethod
     def skew(x):
         return np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]])
+
+    @staticmethod
+    def thrust_rtn(x, u):
+        """u (3,K) in the radial / tangential / normal frame of the states x (7,K) -- what plot_normalized_thrust draws"""
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        r, v = x[0:3], x[3:6]
+        unit = lambda a: a / np.linalg.norm(a, axis=0)
+        r_hat = unit(r); h_hat = unit(np.cross(r, v, axis=0)); t_hat = np.cross(h_hat, r_hat, axis=0)
+        return np.stack([(b * u).sum(axis=0) for b in (r_hat, t_hat, h_hat)])
+
+    @staticmethod
+    def plot_normalized_thrust(x, u, show=True):
+        """The reference's diagnostic plot (optimizer.py:47-77; its test calls it, test_optimizer.py:70): the thrust history in the
+        RTN frame over normalised time.  matplotlib is imported here, not with the module (plotting is outside the hot path);
+        returns the figure, show=False leaves it unshown."""
+        import matplotlib.pyplot as plt
+        u_rtn = Optimizer.thrust_rtn(x, u)
+        print(f"u shape\n:{np.shape(u)}")
+        fig, ax = plt.subplots()
+        tau = np.linspace(0, 1, u_rtn.shape[1])
+        for row, name in zip(u_rtn, "rtn"):
+            ax.plot(tau, row, label=name)
+        ax.set_title('Normalized Thrust Commands')
+        ax.legend()
+        if show:
+            plt.show()
+        return fig
 
     def init_options(self, options):
         return {**DEFAULT_OPTIONS, **options}

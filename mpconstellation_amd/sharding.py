@@ -4,8 +4,11 @@ data-path collective.  Two ways to use several devices:
    collectives are the timing reduction and the optional final gather_trajectories;
  * one process, several devices (the drop-in API: ConstellationMPC / mpc_step_batch / mpc_update_batch with devices=[...]):
    sharded_call below -- one host thread and one mpcx context (own stream, own staging pools) per device, each solving its
-   contiguous block; the blocks' results are joined on the host.  This replaces the reference's serial loop over the
-   constellation (simulator.py:41,58)."""
+   contiguous block and writing its results IN PLACE into its slice of ONE result set allocated for the whole constellation
+   (the satellite axis is outermost everywhere, so a block's slice of a C-ordered array is itself contiguous: the library's
+   copy-out is the only pass over the results).  This replaces the reference's serial loop over the constellation
+   (simulator.py:41,58).  (Until round 4 every block allocated its own arrays and the blocks were np.concatenate'd afterwards on
+   one host thread: 267 MB at 65 536 x 30, the largest term of an 8-device step.)"""
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -46,11 +49,18 @@ def _pool(n):
         return _pools[n]
 
 
-def sharded_call(fn, devices, batched, *args, **kw):
-    """fn(*block_of_each_batched_array, *args, device=d, slot=s, **kw) for the contiguous block of every device, concurrently
-    (ctypes releases the GIL inside the library call: the devices really run side by side); returns the list of results in
-    device order.  batched: arrays with the satellite axis first (None entries are passed through).  Devices that get no
-    satellite (more devices than satellites) are skipped."""
+last_call = {}      # timing of the last multi-block sharded_call: per block (t_start, t_end) around the library call, and the wall span
+
+
+def sharded_call(fn, devices, batched, outs, *args, **kw):
+    """fn(*block_of_each_batched_array, *args, device=d, slot=s, out=views, **kw) for the contiguous block of every device,
+    concurrently (ctypes releases the GIL inside the library call: the devices really run side by side).
+    batched: input arrays with the satellite axis first (None entries are passed through).
+    outs: the whole constellation's result set, dict name -> array (satellite axis 0) or (array, 1) for the per-iteration
+    records (n_scp, S) of an update; None values are skipped.  Every block gets VIEWS of its satellites' part (`out=`) and
+    writes its results there: nothing is joined afterwards.  Returns the list of fn's return values in device order (whatever
+    the wrappers want to hand back beside the arrays).  Devices that get no satellite (more devices than satellites) are skipped."""
+    import time
     ctxs = device_contexts(devices)
     S = next(a for a in batched if a is not None).shape[0]
     jobs = []
@@ -59,31 +69,60 @@ def sharded_call(fn, devices, batched, *args, **kw):
         if count == 0:
             continue
         blk = [None if a is None else a[first:first + count] for a in batched]
-        jobs.append((blk, dev, slot))
+        jobs.append((blk, dev, slot, block_views(outs, first, count)))
+    spans = [None] * len(jobs)
+
+    def run(i):
+        blk, dev, slot, out = jobs[i]
+        t0 = time.perf_counter()
+        r = fn(*blk, *args, device=dev, slot=slot, out=out, **kw)
+        spans[i] = (t0, time.perf_counter())
+        return r
+    t_in = time.perf_counter()
     if len(jobs) == 1:
-        blk, dev, slot = jobs[0]
-        return [fn(*blk, *args, device=dev, slot=slot, **kw)]
-    futs = [_pool(len(jobs)).submit(fn, *blk, *args, device=dev, slot=slot, **kw) for blk, dev, slot in jobs]
-    return [f.result() for f in futs]
+        res = [run(0)]
+    else:
+        futs = [_pool(len(jobs)).submit(run, i) for i in range(len(jobs))]
+        res = [f.result() for f in futs]
+    last_call.update(blocks=spans, wall=(t_in, time.perf_counter()))
+    return res
 
 
-def join_results(parts, cls=None):
-    """one result object from the blocks' results: every ndarray attribute concatenated along the satellite axis (axis 0, or
-    axis 1 for the per-iteration records (n_scp, S) of an update); attributes that are None everywhere stay None"""
-    first = parts[0]
-    if len(parts) == 1:
-        return first
-    out = first.__class__.__new__(first.__class__)
-    for k, v in first.__dict__.items():
-        vals = [getattr(p, k) for p in parts]
-        if all(x is None for x in vals):
-            setattr(out, k, None)
-        elif isinstance(v, np.ndarray):
-            ax = 1 if (v.ndim == 2 and k in ("status", "iters") and getattr(first, "Ks", None) is not None) else 0
-            setattr(out, k, np.concatenate(vals, axis=ax))
-        else:
-            setattr(out, k, v)
-    return out
+def block_views(outs, first, count):
+    """the part of every whole-constellation result array that belongs to satellites first .. first + count - 1"""
+    views = {}
+    for name, a in (outs or {}).items():
+        if a is None:
+            continue
+        arr, axis = a if isinstance(a, tuple) else (a, 0)
+        views[name] = arr[first:first + count] if axis == 0 else arr[:, first:first + count]
+    return views
+
+
+class OutArrays:
+    """The result arrays of one wrapper call: the caller's (`out`: views of a whole-constellation result set, sharded_call) where
+    given, new ones otherwise.  A view that is not C-contiguous (a block's columns of an (n_scp, S) record) is filled through
+    a small contiguous temporary copied over in finish()."""
+
+    def __init__(self, out=None):
+        self.out = out or {}
+        self.late = []
+
+    def get(self, name, shape, dtype=np.float64, make=None):
+        a = self.out.get(name)
+        if a is None:
+            return make() if make is not None else np.empty(shape, dtype=dtype)
+        if a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
+            raise ValueError(f"out[{name!r}]: expected {tuple(shape)} {np.dtype(dtype)}, got {a.shape} {a.dtype}")
+        if a.flags.c_contiguous:
+            return a
+        tmp = np.empty(shape, dtype=dtype)
+        self.late.append((a, tmp))
+        return tmp
+
+    def finish(self):
+        for a, tmp in self.late:
+            a[...] = tmp
 
 
 def gather_trajectories(local, group=None):

@@ -20,7 +20,7 @@ class OdeResult:
 
 
 def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=False, max_step=1e-3, device=0, slot=0,
-                    Kus=None, thrust=False, devices=None):
+                    Kus=None, thrust=False, devices=None, out=None, row_len=None):
     """y0 (S,7) normalised, tf (S,), consts (S,8); law = (kind, vec, Ku, end_tau) with per-satellite or
     broadcastable parameters.  Returns y (S,7,n_eval), status (S,), nsteps (S,) -- and, with thrust=True, u (S,3,n_eval) as a
     fourth value: the law evaluated at the output points, Discretizer.extract_uk of the rollout's own controller
@@ -28,7 +28,9 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
     Ragged batches: n_eval may be an (S,) integer array -- satellite s is sampled at linspace(0, 1, n_eval[s]), y has
     max(n_eval) columns, zero past a satellite's count -- and Kus (S,) gives the columns in use of each satellite's
     thrust table (law SEQUENCE, table rows of length Ku).
-    devices=[d0, d1, ...]: contiguous blocks of satellites on several devices at once (sharding.sharded_call)."""
+    devices=[d0, d1, ...]: contiguous blocks of satellites on several devices at once (sharding.sharded_call), every block
+    writing in place into its slice of one result set (out / row_len: internal -- a block's views of that set, and the set's
+    row length, which a ragged block uses instead of its own longest satellite's)."""
     y0 = _ffi.as_f64(y0); S = y0.shape[0]
     if devices is not None and len(devices) > 1:
         from .sharding import sharded_call
@@ -43,21 +45,20 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
         ne = np.ascontiguousarray(np.broadcast_to(np.asarray(n_eval), (S,)), dtype=np.int32) if np.ndim(n_eval) > 0 else None
         ku = None if Kus is None else np.ascontiguousarray(np.broadcast_to(np.asarray(Kus), (S,)), dtype=np.int32)
         nmax = int(ne.max()) if ne is not None else int(n_eval)
+        y = _ffi.result_pool.take((S, 7, nmax)); status = np.zeros(S, dtype=np.int32); nsteps = np.zeros(S, dtype=np.int32)
+        u = _ffi.result_pool.take((S, 3, nmax)) if thrust else None
 
-        def fn(y, t, c, v, e, n, k, device, slot):
-            out = propagate_batch(y, t, c, (kind, v, Ku, e), n_eval if n is None else n, include_drag, include_J2, max_step, device, slot, k, thrust)
-            if n is not None and out[0].shape[2] < nmax:       # (a block's rows are as long as ITS longest satellite)
-                pad = lambda a: np.concatenate([a, np.zeros(a.shape[:2] + (nmax - a.shape[2],))], axis=2)
-                out = (pad(out[0]), out[1], out[2]) + ((pad(out[3]),) if thrust else ())
-            return out
-        parts = sharded_call(fn, devices, [y0, bc(tf, (S,)), _ffi.as_f64(consts), vec, end_tau, ne, ku])
-        return tuple(np.concatenate([p[i] for p in parts], axis=0) for i in range(len(parts[0])))
+        def fn(y0b, t, c, v, e, n, k, device, slot, out):
+            propagate_batch(y0b, t, c, (kind, v, Ku, e), n_eval if n is None else n, include_drag, include_J2, max_step, device, slot, k, thrust,
+                            None, out, nmax)
+        sharded_call(fn, devices, [y0, bc(tf, (S,)), _ffi.as_f64(consts), vec, end_tau, ne, ku], dict(y=y, status=status, nsteps=nsteps, u=u))
+        return (y, status, nsteps, u) if thrust else (y, status, nsteps)
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
     n_evals = None
     if np.ndim(n_eval) > 0:
         n_evals = np.ascontiguousarray(np.broadcast_to(np.asarray(n_eval), (S,)), dtype=np.int32)
-        n_eval = int(n_evals.max())
+        n_eval = int(n_evals.max()) if row_len is None else int(row_len)
     if Kus is not None:
         Kus = np.ascontiguousarray(np.broadcast_to(np.asarray(Kus), (S,)), dtype=np.int32)
     tf = _ffi.as_f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (S,)))
@@ -72,11 +73,14 @@ def propagate_batch(y0, tf, consts, law, n_eval, include_drag=False, include_J2=
         vec = np.asarray(vec, dtype=np.float64)
         vec = _ffi.as_f64(np.broadcast_to(vec if vec.ndim == 3 else vec[None], (S, 3, Ku))); vec_p = _ffi.dptr(vec)
         end_tau = _ffi.as_f64(np.broadcast_to(np.asarray(end_tau, dtype=np.float64), (S,))); et_p = _ffi.dptr(end_tau)
-    y = np.empty((S, 7, n_eval)); status = np.zeros(S, dtype=np.int32); nsteps = np.zeros(S, dtype=np.int32)
+    from .sharding import OutArrays
+    oa = OutArrays(out)
+    y = oa.get("y", (S, 7, n_eval)); status = oa.get("status", (S,), np.int32, lambda: np.zeros(S, dtype=np.int32))
+    nsteps = oa.get("nsteps", (S,), np.int32, lambda: np.zeros(S, dtype=np.int32))
     flags = (_ffi.FLAG_DRAG if include_drag else 0) | (_ffi.FLAG_J2 if include_J2 else 0)
     lib = _ffi.load(); ctx = _ffi.context(device, slot)
     if thrust:
-        u = np.empty((S, 3, n_eval))
+        u = oa.get("u", (S, 3, n_eval))
         rc = lib.mpcx_propagate_thrust_batch_ragged(ctx, S, int(n_eval), None if n_evals is None else _ffi.iptr(n_evals), _ffi.dptr(y0),
                                                     _ffi.dptr(tf), _ffi.dptr(consts), flags, kind, vec_p, int(Ku),
                                                     None if Kus is None else _ffi.iptr(Kus), et_p, float(max_step), _ffi.dptr(y),

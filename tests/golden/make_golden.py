@@ -310,6 +310,28 @@ def gen_rk23_cases():
     save("rk23_discretize.npz", const=const_vec(const), cases=np.array(["tan_K30_tf1", "const_K20_tf2"]), **out)
 
 
+def gen_scipy_zoh_case():
+    """Discretizer(use_scipy_ZOH=True) (linearize_discretize.py:327-329): u_func evaluates scipy.interpolate.interp1d(tau, u,
+    kind='linear') instead of u_FOH -- the same piecewise-linear hold, other rounding (slope form, searchsorted's interval at the
+    nodes).  Outputs and accepted step nodes, beside the default path's on the same inputs."""
+    sat = Satellite(R_HUBBLE, V_HUBBLE, M_HUBBLE)
+    scale = SatelliteScale(sat=sat)
+    const = scale.get_normalized_constants()
+    out = {}
+    for name, ctrl, tf, base_res in (("tan_K30_tf1", ConstantTangentialThrustController([sat], 0.5), 1, 30),
+                                     ("const_K20_tf2", ConstantThrustController([sat], np.array([0.44, 0.7, 1.0])), 2, 10)):
+        x, t, u = reference_case(sat, scale, ctrl, tf, base_res)
+        d = Discretizer(const, include_drag=False, include_J2=False, use_scipy_ZOH=True)
+        A, Bp, Bn, Sig, xi = d.discretize(F, x, u, tf)
+        counts, nfev, nt, ny = rk_nodes(d, x, u, tf)
+        d0 = Discretizer(const, include_drag=False, include_J2=False)
+        A0, Bp0, Bn0, Sig0, xi0 = d0.discretize(F, x, u, tf)
+        out.update({f"x_{name}": x, f"t_{name}": t, f"u_{name}": u, f"tf_{name}": np.float64(tf), f"A_{name}": A, f"Bp_{name}": Bp,
+                    f"Bn_{name}": Bn, f"Sigma_{name}": Sig, f"xi_{name}": xi, f"node_counts_{name}": counts, f"node_t_{name}": nt,
+                    f"foh_A_{name}": A0, f"foh_Bp_{name}": Bp0, f"foh_Bn_{name}": Bn0, f"foh_Sigma_{name}": Sig0, f"foh_xi_{name}": xi0})
+    save("scipy_zoh_discretize.npz", const=const_vec(const), cases=np.array(["tan_K30_tf1", "const_K20_tf2"]), **out)
+
+
 def gen_csv_case():
     """The trajectory CSV the reference writes (Simulator.save_to_csv, simulator.py:192-201, read by visualizer.m:23-28):
     file name pattern, the file's text and the run that produced it."""
@@ -342,6 +364,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "uniform":
         gen_uniform_steps_cases()
         raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "zoh":
+        gen_scipy_zoh_case()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rk23":
         gen_rk23_cases()
         raise SystemExit(0)
@@ -352,3 +377,4 @@ if __name__ == "__main__":
     gen_csv_case()
     gen_uniform_steps_cases()
     gen_rk23_cases()
+    gen_scipy_zoh_case()

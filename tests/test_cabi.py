@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
     assert set(_ffi.exported_symbols()) == set(names)     # the Python binding binds exactly the header
-    assert _ffi.load().mpcx_version() == 400
+    assert _ffi.load().mpcx_version() == 500
 
 
 def test_struct_layout_and_defaults():

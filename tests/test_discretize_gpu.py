@@ -179,3 +179,23 @@ def test_rk23_solver_vs_reference(golden_dir):
         d.ivp_solver = m
         with pytest.raises(NotImplementedError):
             d.discretize(Simulator.satellite_dynamics, x, u, 1.0)
+
+
+def test_scipy_zoh_mode_vs_reference(golden_dir):
+    """Discretizer(use_scipy_ZOH=True) (linearize_discretize.py:327-329: interp1d(kind='linear') in place of u_FOH): the device
+    evaluates the hold by the FOH formula in that mode too -- the same function; the reference's two evaluations differ by
+    <= 1e-16 relative (tests/test_oracle_golden.py::test_scipy_zoh_mode) -- and is held to arrays the reference produced WITH
+    the flag (make_golden.py zoh) at the tolerance of every other mode, 1e-10 relative (observed ~1e-13)."""
+    from mpconstellation_amd import Discretizer, Simulator
+    from mpconstellation_amd.constants import Constants
+    g = np.load(os.path.join(golden_dir, "scipy_zoh_discretize.npz"))
+    d = Discretizer(Constants(*g["const"]), use_scipy_ZOH=True)
+    worst = 0.0
+    for name in g["cases"]:
+        x, u, tf = g[f"x_{name}"], g[f"u_{name}"], float(g[f"tf_{name}"])
+        for got, key in zip(d.discretize(Simulator.satellite_dynamics, x, u, tf), ("A", "Bp", "Bn", "Sigma", "xi")):
+            ref = g[f"{key}_{name}"]
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            worst = max(worst, err)
+            assert got.shape == ref.shape and err <= 1e-10, (name, key, err)
+    print(f"use_scipy_ZOH: worst relative difference to the reference's arrays {worst:.2e}")

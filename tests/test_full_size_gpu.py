@@ -377,27 +377,45 @@ def test_off_nominal_option_sets():
 
 
 def test_host_pointer_calls_have_no_stragglers():
-    """BENCH_r03 held one 53 ms call among 1.5 ms ones.  50 consecutive host-pointer calls (numpy in, numpy out) at 64 and at
-    4096 satellites after three warm-up calls: the calls are uniform -- 90 % of them within 1.25 x the median -- and at most
-    one may take longer than 1.5 x the median, in at least one of three such rounds.  (One may: in some 2 000 probe calls of round 4 a single 67 ms call turned up
-    among 1.4 ms ones, on a box whose device-side time stamps put every extra millisecond BEFORE the stream executed the
-    call's first packet -- below the library; what is known is in DESIGN.md section 5 and profiles/r04/host_wait.txt.  The
-    large result arrays are recycled once the caller has dropped the previous results, _ffi.result_pool: no fresh pages to
-    fault in, which were 3-5 ms now and then.)"""
-    import time
-    from mpconstellation_amd import mpc_step_batch
+    """BENCH_r03 held one 53 ms call among 1.5 ms ones; round 4 saw 67 ms among 1.4 ms at 64 satellites and 11-13 ms among 7.4 ms
+    at 4096, and explained them as "before the stream executes the call's first packet" -- in a docstring, behind a retry.  Now
+    the explanation is the assertion: ONE round of 50 consecutive host-pointer calls (numpy in, numpy out) at 64 and at 4096
+    satellites with the library's call trace armed (include/mpcx.h: mpcx_trace_enable / mpcx_last_call_trace), no retry:
+      (i)   the device's own span of every call (first marker -> last download done, from events on the call's stream) is
+            within 1.25 x the median: the device work of a call does not straggle;
+      (ii)  what the library does on the host AFTER its first packet ran -- staging copies, enqueueing, waits for the device,
+            copy-out -- is within 1.5 x its median for every call;
+      (iii) so whatever else a slow call spends lies in MPCX_TR_FIRST_MARKER, the time the queue took to pick up the call's first
+            packet, before any work of this library ran (checked: the fields add up to the call's wall time).
+    A slow call that does not fit (iii) fails (i) or (ii) and is the library's to fix.  Wall-clock outliers are REPORTED (printed
+    with their breakdown), not asserted: on a shared box the first-marker wait is not ours."""
+    from mpconstellation_amd import mpc_step_batch, _ffi
+    lines = []
     for S in (64, 4096):
         xbar, ubar, consts, r_des = workload(4096, 30, first=0, count=S)
         tf = np.ones(S)
         for _ in range(3): r = mpc_step_batch(xbar, ubar, tf, consts, r_des)
-        seen = []
-        for attempt in range(3):          # (a box shared with other tenants: the bound must hold in one of three rounds of 50)
-            ms = []
+        _ffi.trace_enable(True)
+        try:
+            recs = []
             for _ in range(50):
-                t0 = time.perf_counter(); r = mpc_step_batch(xbar, ubar, tf, consts, r_des); ms.append((time.perf_counter() - t0) * 1e3)
-            assert (r.status == 0).all()
-            ms = np.array(ms); med = np.median(ms)
-            seen.append((S, round(float(med), 3), np.round(np.sort(ms)[-5:], 3).tolist(), int(np.argmax(ms))))
-            if np.percentile(ms, 90) <= 1.25 * med and (ms > 1.5 * med).sum() <= 1: break
-        else:
-            raise AssertionError(seen)
+                r = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+                recs.append(_ffi.last_call_trace())
+        finally:
+            _ffi.trace_enable(False)
+        assert (r.status == 0).all() and all(t is not None for t in recs)
+        f = {k: np.array([t[k] for t in recs]) for k in _ffi.TRACE_FIELDS}
+        wall, first = f["wall_ms"], f["first_marker_ms"]
+        after = f["host_stage_ms"] + f["host_wait_ms"] + f["host_copyout_ms"]
+        assert np.abs(first + after - wall).max() < 0.02 * np.median(wall) + 0.01        # the fields account for the whole call
+        dev = f["dev_span_ms"]
+        lines.append(f"S {S}: wall median {np.median(wall):.3f} max {wall.max():.3f} | device span median {np.median(dev):.3f} max {dev.max():.3f} | "
+                     f"host after first packet median {np.median(after):.3f} max {after.max():.3f} | first marker median {np.median(first):.3f} max {first.max():.3f}")
+        for i in np.nonzero(wall > 1.5 * np.median(wall))[0]:
+            lines.append(f"   slow call {i}: " + ", ".join(f"{k} {recs[i][k]:.3f}" for k in _ffi.TRACE_FIELDS[:-1]))
+        print("\n".join(lines))
+        assert (dev <= 1.25 * np.median(dev)).all(), lines                                   # (i)
+        assert (after <= 1.5 * np.median(after)).all(), lines                                # (ii)
+    # an untraced call leaves no record behind a disabled trace, and tracing does not change results
+    r0 = mpc_step_batch(xbar, ubar, tf, consts, r_des)
+    assert np.array_equal(r0.X, r.X) and _ffi.last_call_trace() is None

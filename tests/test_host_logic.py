@@ -104,42 +104,53 @@ def test_constellation_generator_and_sharding(golden_dir):
         assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
 
 
-def test_sharded_call_blocks_contexts_and_join():
+def test_sharded_call_blocks_contexts_and_results_in_place():
     """The multi-device path of the drop-in API (ConstellationMPC / mpc_step_batch / mpc_update_batch with devices=[...]):
     contiguous blocks in device order, one context (device, slot) per entry of the device list -- a device named twice gets
     two slots --, no two calls in flight on one context (a context is not thread-safe, include/mpcx.h), the calls really
-    concurrent, the blocks' results joined along the satellite axis (axis 1 for an update's per-iteration records)."""
+    concurrent, and every block writing IN PLACE into its slice of ONE result set for the constellation: C-contiguous views
+    along the satellite axis (the library's copy-out is the only pass over the results), a small temporary only for a block's
+    columns of an update's per-iteration records (n_scp, S)."""
     import threading
     import time
-    from mpconstellation_amd.sharding import device_contexts, sharded_call, join_results, shard_block
+    from mpconstellation_amd.sharding import device_contexts, sharded_call, shard_block, OutArrays, last_call
     assert device_contexts([0, 1, 0, 0, 1]) == [(0, 0), (1, 0), (0, 1), (0, 2), (1, 1)]
-    lock = threading.Lock(); busy = set(); clashes = []; peak = [0]
+    lock = threading.Lock(); busy = set(); clashes = []; peak = [0]; seen = []
 
-    class Res:
-        pass
-
-    def fake_call(x, k, scale, device=0, slot=0):
+    def fake_call(x, k, scale, device=0, slot=0, out=None):
         with lock:
             if (device, slot) in busy: clashes.append((device, slot))
             busy.add((device, slot)); peak[0] = max(peak[0], len(busy))
         time.sleep(0.05)
         with lock:
             busy.discard((device, slot))
-        r = Res(); r.X = x * scale; r.Ks = np.full(x.shape[0], 7 if k is None else k[0]); r.g_tf = None
-        r.status = np.full((2, x.shape[0]), 10 * device + slot, dtype=np.int32); r.where = (device, slot)
-        return r
+        n = x.shape[0]
+        oa = OutArrays(out)
+        X = oa.get("X", x.shape); Ks = oa.get("Ks", (n,), np.int64); st = oa.get("status", (2, n), np.int32)
+        with lock:
+            seen.append((device, slot, X.base is not None and X.flags.c_contiguous, st.flags.c_contiguous and len(oa.late) == 1))
+        X[...] = x * scale; Ks[...] = 7 if k is None else k; st[...] = 10 * device + slot
+        oa.finish()
+        return (device, slot, n)
 
     x = np.arange(11 * 3, dtype=np.float64).reshape(11, 3)
-    parts = sharded_call(fake_call, [0, 0, 1], [x, None], 2.0)
+    outs = dict(X=np.full((11, 3), np.nan), Ks=np.zeros(11, dtype=np.int64), status=(np.full((2, 11), -1, dtype=np.int32), 1), unused=None)
+    parts = sharded_call(fake_call, [0, 0, 1], [x, None], outs, 2.0)
     assert not clashes and peak[0] == 3                        # three contexts, all in flight together
-    assert [p.where for p in parts] == [(0, 0), (0, 1), (1, 0)]
-    assert [p.X.shape[0] for p in parts] == [shard_block(11, 3, r)[1] for r in range(3)] == [4, 4, 3]
-    j = join_results(parts)
-    assert np.array_equal(j.X, 2.0 * x) and j.g_tf is None and j.Ks.shape == (11,)
-    assert j.status.shape == (2, 11) and j.status[0].tolist() == [0] * 4 + [1] * 4 + [10] * 3
+    assert parts == [(0, 0, 4), (0, 1, 4), (1, 0, 3)] == [(d, s, shard_block(11, 3, r)[1]) for r, (d, s) in enumerate([(0, 0), (0, 1), (1, 0)])]
+    # every block wrote through a contiguous VIEW of the whole array (no copy), the (n_scp, S) record through one temporary
+    assert all(view and late for _, _, view, late in seen)
+    assert np.array_equal(outs["X"], 2.0 * x) and outs["Ks"].tolist() == [7] * 11
+    assert outs["status"][0][0].tolist() == [0] * 4 + [1] * 4 + [10] * 3 and np.array_equal(outs["status"][0][0], outs["status"][0][1])
+    assert len(last_call["blocks"]) == 3 and last_call["wall"][1] - last_call["wall"][0] < 0.14      # (3 x 0.05 s side by side)
+    # a view of the wrong shape or type is refused, a missing name means "allocate"
+    with pytest.raises(ValueError):
+        OutArrays({"X": np.zeros((3, 3))}).get("X", (4, 3))
+    assert OutArrays(None).get("X", (4, 3)).shape == (4, 3)
     # more devices than satellites: the empty blocks are skipped; a single block runs on the caller's thread
-    parts = sharded_call(fake_call, [0, 1, 2, 3], [x[:2], np.array([5, 6])], 1.0)
-    assert [p.where for p in parts] == [(0, 0), (1, 0)] and join_results(parts).Ks.tolist() == [5, 6]
+    o2 = dict(X=np.zeros((2, 3)), Ks=np.zeros(2, dtype=np.int64), status=(np.zeros((2, 2), dtype=np.int32), 1))
+    parts = sharded_call(fake_call, [0, 1, 2, 3], [x[:2], np.array([5, 6])], o2, 1.0)
+    assert parts == [(0, 0, 1), (1, 0, 1)] and o2["Ks"].tolist() == [5, 6] and np.array_equal(o2["X"], x[:2])
 
 
 def test_foreign_thrust_laws_and_unknown_options_are_rejected():
@@ -279,3 +290,22 @@ def test_result_arrays_are_recycled_only_when_dropped():
     assert len(pool._pool[(shape, "<f8")]) <= pool.PER_SHAPE
     for n in range(40): pool.take((4096, 7, 31 + n))     # many shapes: the oldest leave the pool
     assert len(pool._pool) <= pool.SHAPES
+
+
+def test_plot_normalized_thrust_and_verbose_devices(golden_dir):
+    """the reference's Optimizer.plot_normalized_thrust (optimizer.py:47-77, called by its own test, test_optimizer.py:70): RTN
+    components of a tangential thrust history are (0, |u|, 0); matplotlib is imported by the call, not by the package.
+    ConstellationMPC(verbose=True, devices=[...]) is refused instead of silently solving on one device."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from mpconstellation_amd import Optimizer, ConstellationMPC
+    d = np.load(os.path.join(golden_dir, "disc_tan_K20_tf2.npz"))
+    x, u = d["x"], d["u"]
+    rtn = Optimizer.thrust_rtn(x, u)
+    assert np.abs(rtn[0]).max() < 1e-12 and np.abs(rtn[2]).max() < 1e-12 and np.allclose(rtn[1], np.linalg.norm(u, axis=0))
+    fig = Optimizer.plot_normalized_thrust(x, u, show=False)
+    ax = fig.axes[0]
+    assert ax.get_title() == 'Normalized Thrust Commands' and [l.get_label() for l in ax.lines] == ["r", "t", "n"]
+    assert np.array_equal(ax.lines[1].get_ydata(), rtn[1])
+    with pytest.raises(ValueError):
+        ConstellationMPC([hubble(), hubble()], verbose=True, devices=[0, 1])

@@ -322,3 +322,19 @@ def test_several_devices_from_the_api():
     y1 = propagate_batch(y0, 1.0, consts, law, n, thrust=True)
     y3 = propagate_batch(y0, 1.0, consts, law, n, thrust=True, devices=[0, 0, 0])
     for p, q in zip(y1, y3): assert np.array_equal(p, q)
+    # the blocks write IN PLACE into one result set: whole C-ordered arrays come back (no join), the regularisation record and
+    # page-locked results (every context's DMA lands in the one set) work with devices= as well
+    S = 2051
+    xbar, ubar, consts, r_des = workload(8192, 30, first=0, count=S)
+    one = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, regularised=True)
+    for kw in (dict(regularised=True), dict(pinned_results=True)):
+        many = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, devices=[0, 0, 0], **kw)
+        assert many.X.flags.c_contiguous and many.X.shape == (S, 7, 30)
+        for f in ("X", "U", "NU", "tf", "status", "iters", "kkt"): assert np.array_equal(getattr(one, f), getattr(many, f)), (kw, f)
+        if "regularised" in kw:
+            assert np.array_equal(one.n_regularised, many.n_regularised) and np.array_equal(one.first_regularised, many.first_regularised)
+    upd1 = mpc_update_batch(y0, 2.0, normalize_batch(st)[1], 1.5, 30, options=ConstellationMPC.OPTIONS(2.0), fly=(1.0, 1.0, 40, True, True))
+    upd3 = mpc_update_batch(y0, 2.0, normalize_batch(st)[1], 1.5, 30, options=ConstellationMPC.OPTIONS(2.0), fly=(1.0, 1.0, 40, True, True), devices=[0, 0, 0])
+    for f in ("X", "U", "NU", "tf", "status", "iters", "kkt", "Ks", "prop_status", "y_sim", "sim_status"):
+        assert np.array_equal(getattr(upd1, f), getattr(upd3, f)), f
+    assert upd3.status.shape == (2, 7) and upd3.y_sim.shape == (7, 7, 40)

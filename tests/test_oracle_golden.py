@@ -153,3 +153,20 @@ def test_rk23_mode(golden_dir):
     o = O.discretize(g[f"x_{name}"], g[f"u_{name}"], 1.0, g["const"], O.FLAG_RK23, uniform_steps=int(g["uni_steps"]))
     for k in ("A", "Bp", "Bn", "Sigma", "xi"):
         assert relerr(o[k], g["uni_" + k]) < RTOL, k
+
+
+def test_scipy_zoh_mode(golden_dir):
+    """Discretizer(use_scipy_ZOH=True) (linearize_discretize.py:327-329): the reference then evaluates the thrust hold with
+    scipy.interpolate.interp1d(kind='linear') instead of u_FOH -- the same piecewise-linear function in another rounding.  The
+    reference's own two paths differ by <= 1e-16 relative on these inputs (the foh_* arrays of the same file, asserted here), so
+    the FOH formula IS the evaluation of that mode to the last digit or two: the oracle against arrays the reference produced
+    with the flag set -- same accepted step nodes, the five arrays to the tolerance every other mode is held to."""
+    g = np.load(os.path.join(golden_dir, "scipy_zoh_discretize.npz"))
+    for name in g["cases"]:
+        x, u, tf = g[f"x_{name}"], g[f"u_{name}"], float(g[f"tf_{name}"])
+        o = O.discretize(x, u, tf, g["const"], dump_nodes=True)
+        assert o["status"] == 0 and np.array_equal(o["node_counts"], g[f"node_counts_{name}"])
+        assert np.abs(o["node_t"] - g[f"node_t_{name}"]).max() < 1e-13
+        for k in ("A", "Bp", "Bn", "Sigma", "xi"):
+            assert relerr(g[f"foh_{k}_{name}"], g[f"{k}_{name}"]) < 1e-15, (name, k)      # the reference against itself
+            assert relerr(o[k], g[f"{k}_{name}"]) < RTOL, (name, k)

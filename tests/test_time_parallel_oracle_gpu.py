@@ -1,0 +1,140 @@
+"""The time-parallel solve kernel (MPCX_SOLVE_TIME_PARALLEL, csrc/solve_tp.hip) held DIRECTLY to the checkers the default kernels
+are held to -- the CPU oracle (oracle/nlp_ipm.py) and the independent scipy solutions of the reference's NLP
+(tests/golden/xcheck_*.npz, made by tests/golden/make_nlp_xcheck.py) -- through the C ABI with flags = 64, at the tolerances of
+tests/test_solve_gpu.py / test_solve_xcheck_gpu.py: 5e-6 device vs oracle, 1e-5 / 5e-4 / 1e-6 (x / u / tf) vs the scipy solutions,
+1e-6 / 1e-5 / 5e-8 in the convex variant, 1e-6 half way along the path; the one bound that differs is the "same arithmetic"
+bonus of the default kernels (5e-9 on a common path), which this kernel -- the same direction computed another way -- meets at 1e-7.
+(tests/test_time_parallel_gpu.py compares it with the repo's own sequential kernels: the round-4 verdict called that a
+self-comparison.)  Only cases the flag is honoured for: row length K >= 24."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import oracle_lib as O
+import nlp_ipm as N
+
+from test_solve_gpu import TOL_PATH, TOL_SOL, load as load_disc, oracle_solve
+from test_solve_xcheck_gpu import TOL as XTOL, load as load_xcheck, device_solve
+
+pytestmark = pytest.mark.gpu
+TP = 64                     # MPCX_SOLVE_TIME_PARALLEL
+TOL_TP = 1e-7
+TP_DEAD = 1 << 30           # MPCX_SOLVE_TP_SELFTEST_DEAD
+ST_TIMEOUT = 10
+CASES = ["tan_K30_tf1", "tan_K60_tf2", "tan_K100_tf1", "tanJ2_K30_tf1", "const_K30_tf1"]          # test_solve_gpu.CASES with K >= 24
+XCHECK = ["tan_K30_tf1", "tan_K30_tf1_zero", "const_K30_tf1", "tan_K30_tf1_linvt", "const_K30_tf1_linvt",
+          "tan_K30_tf1_mpc105", "tan_K60_tf2_mpc12", "tan_K60_tf2_mpc15"]                           # test_solve_xcheck_gpu.XCHECK with K >= 24
+
+
+def tp_really_ran(res_tp, res_default):
+    """the flag was honoured (a silently refused flag would make every comparison below one of the default kernels with
+    themselves): the time-parallel kernel does not produce the other kernels' bits"""
+    return not (np.array_equal(res_tp.X, res_default.X) and np.array_equal(res_tp.NU, res_default.NU) and np.array_equal(res_tp.U, res_default.U))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_time_parallel_vs_oracle(golden_dir, name):
+    """test_solve_gpu.test_solve_vs_oracle with flags = 64: same stage data as the oracle (the reference's own A / B matrices from the
+    golden file): 1e-7 on a common unregularised path (below), the solver tolerance 5e-6 otherwise, 1e-6 half way"""
+    from mpconstellation_amd import solve_batch
+    d, x, u, tf, cst = load_disc(golden_dir, name)
+    r_des = float(np.linalg.norm(x[:3, -1]))
+    stage = {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")}
+    P, ref = oracle_solve(x, u, tf, cst, r_des, stage)
+    args = (d["A"][None], d["Bp"][None], d["Bn"][None], d["Sigma"][None], d["xi"][None], x[None], u[None], [tf], cst[None], [r_des])
+    res = solve_batch(*args, regularised=True, flags=TP)
+    assert tp_really_ran(res, solve_batch(*args))
+    assert ref["status"] == 0 and res.status[0] == 0 and res.kkt[0] <= 1e-8
+    n_dev, first_dev = int(res.n_regularised[0]), int(res.first_regularised[0])
+    clean = ref["n_regularised"] == 0 and n_dev == 0
+    firsts = ([ref["first_regularised"]] if ref["n_regularised"] > 0 else []) + ([first_dev] if n_dev > 0 else [])
+    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if clean else 10)
+    # The default kernels run the oracle's arithmetic operation for operation and are held to 5e-9 on a common path.  This
+    # kernel computes the same Newton direction ANOTHER way (segments + coarse problem): directions agree to ~1e-10 relative,
+    # not to rounding, so a common unregularised path ends within TOL_TP = 1e-7 (what tests/test_time_parallel_gpu.py holds it
+    # to against the sequential kernels; observed here: printed), any other case within the solver tolerance TOL_SOL = 5e-6
+    # that every device-vs-oracle comparison falls back to.
+    tol = TOL_TP if (clean and res.iters[0] == ref["iters"]) else TOL_SOL
+    errs = (np.abs(res.X[0] - ref["X"]).max(), np.abs(res.U[0] - ref["U"]).max(), np.abs(res.NU[0] - ref["NU"]).max(), abs(res.tf[0] - ref["tf"]))
+    print(f"{name}: iterations {int(res.iters[0])} / oracle {ref['iters']}, regularised {n_dev} / {ref['n_regularised']}, |dX| {errs[0]:.2e} |dU| {errs[1]:.2e} |dNU| {errs[2]:.2e} |dtf| {errs[3]:.2e} (bound {tol:.0e})")
+    assert max(errs) < tol
+    cap = (min(firsts) if firsts else ref["iters"]) // 2                     # half way along the common path
+    _, refc = oracle_solve(x, u, tf, cst, r_des, stage, max_iter=cap)
+    resc = solve_batch(*args, max_iter=cap, flags=TP)
+    assert resc.iters[0] == refc["iters"] == cap
+    assert np.abs(resc.X[0] - refc["X"]).max() < TOL_PATH and np.abs(resc.U[0] - refc["U"]).max() < TOL_PATH
+    assert np.abs(resc.NU[0] - refc["NU"]).max() < TOL_PATH and abs(resc.tf[0] - refc["tf"]) < TOL_PATH
+    e = P.dyn_residual(res.X[0], res.U[0], res.NU[0][:, :-1], res.tf[0])     # the reference's NLP, with the reference's own A / B
+    assert np.abs(e).max() < 1e-8 and np.abs(res.X[0][:, 0] - x[:, 0]).max() == 0.0
+    h = np.cross(res.X[0][:3, -1], res.X[0][3:6, -1])
+    assert abs(np.linalg.norm(h) / np.linalg.norm(res.X[0][:3, -1]) - P.vt_des) < 1e-7
+
+
+@pytest.mark.parametrize("case", XCHECK)
+def test_time_parallel_vs_independent_nlp_solution(golden_dir, case):
+    """test_solve_xcheck_gpu.test_device_vs_independent_nlp_solution with flags = 64: scipy trust-constr solutions of a second
+    transcription of optimizer.py:254-603, incl. OptimalController's option set (mpc105 / mpc12 / mpc15) and the convex pair"""
+    f, d, opts = load_xcheck(golden_dir, case)
+    variant = str(f["variant"])
+    res = device_solve(d, opts, float(f["r_des"]), variant, regularised=True, flags=TP)
+    assert tp_really_ran(res, device_solve(d, opts, float(f["r_des"]), variant))
+    assert res.status[0] == 0 and res.kkt[0] <= 1e-8
+    tx, tu, ttf = XTOL[variant]
+    assert np.abs(res.X[0] - f["X"]).max() < tx and np.abs(res.U[0] - f["U"]).max() < tu
+    assert np.abs(res.NU[0] - f["NU"]).max() < 1e-6 and abs(res.tf[0] - float(f["tf_opt"])) < ttf
+    x, u, cst = d["x"], d["u"], d["const"]
+    P = N.MpcProblem(x, u, float(d["tf"]), cst[0], {k: d[k] for k in ("A", "Bp", "Bn", "Sigma", "xi")},
+                     O.constraint_terms(x, u, cst[0]), {"r_des": float(f["r_des"]), **opts}, variant=variant)
+    ref = N.solve(P)
+    assert ref["status"] == 0
+    assert np.abs(res.X[0] - ref["X"]).max() < 5e-6 and abs(res.tf[0] - ref["tf"]) < 5e-6
+    clean = ref["n_regularised"] == 0 and int(res.n_regularised[0]) == 0
+    assert abs(int(res.iters[0]) - ref["iters"]) <= (1 if clean else 10)
+    print(f"{case}: iterations {int(res.iters[0])} / oracle {ref['iters']}, vs scipy |dX| {np.abs(res.X[0] - f['X']).max():.2e} |dtf| {abs(res.tf[0] - float(f['tf_opt'])):.2e}, "
+          f"vs oracle |dX| {np.abs(res.X[0] - ref['X']).max():.2e} |dtf| {abs(res.tf[0] - ref['tf']):.2e}")
+    if clean and int(res.iters[0]) == ref["iters"]:
+        assert np.abs(res.X[0] - ref["X"]).max() < TOL_TP and abs(res.tf[0] - ref["tf"]) < TOL_TP
+
+
+def test_time_parallel_full_size_sample_vs_oracle():
+    """the largest batch the flag is honoured for (128 satellites, K = 30: BASELINE configs[1]'s constellation twice over), every
+    sixteenth satellite against the oracle, which discretises on its own (5e-6, as test_constellation_properties_full_size)"""
+    from mpconstellation_amd import mpc_step_batch
+    from test_full_size_gpu import workload
+    S, K = 128, 30
+    xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
+    res = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, flags=TP)
+    assert tp_really_ran(res, mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des))
+    assert (res.status == 0).all() and res.kkt.max() <= 1e-8
+    assert np.abs(res.X[:, :, 0] - xbar[:, :, 0]).max() == 0.0
+    for s in range(5, S, 16):
+        od = O.discretize(xbar[s], ubar[s], 1.0, consts[s])
+        P = N.MpcProblem(xbar[s], ubar[s], 1.0, consts[s][0], od, O.constraint_terms(xbar[s], ubar[s], consts[s][0]), {"r_des": float(r_des[s])})
+        ref = N.solve(P)
+        assert ref["status"] == 0 and abs(int(res.iters[s]) - ref["iters"]) <= 1, (s, res.iters[s], ref["iters"])
+        assert np.abs(P.dyn_residual(res.X[s], res.U[s], res.NU[s][:, :-1], res.tf[s])).max() < 1e-8
+        assert np.abs(res.X[s] - ref["X"]).max() < TOL_SOL and np.abs(res.U[s] - ref["U"]).max() < TOL_SOL and abs(res.tf[s] - ref["tf"]) < TOL_SOL
+
+
+def test_wait_limit_ends_the_solve_with_its_own_status():
+    """MPCX_SOLVE_TP_SELFTEST_DEAD: the workgroup of every satellite's first segment leaves before its first command.  The first
+    workgroup's wait runs out (~0.1 s), the launch ends, every satellite reports MPCX_ST_TIMEOUT -- not a numerical failure --
+    with kkt = -1 and defined results (the start iterate: x_bar, u_bar, no virtual control worth the name), and the next solve
+    on the context is untouched by it."""
+    from mpconstellation_amd import mpc_step_batch
+    from test_full_size_gpu import workload
+    S, K = 8, 30
+    xbar, ubar, consts, r_des = workload(4096, K, first=0, count=S)
+    good = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, flags=TP)
+    dead = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, flags=TP | TP_DEAD)
+    assert (dead.status == ST_TIMEOUT).all() and (dead.kkt == -1.0).all() and (dead.iters == 0).all()
+    assert np.isfinite(dead.X).all() and np.isfinite(dead.U).all() and np.isfinite(dead.NU).all()
+    assert np.array_equal(dead.X, xbar) and np.array_equal(dead.U, ubar)      # no step was taken: the start iterate comes back
+    again = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, flags=TP)
+    assert (again.status == 0).all() and np.array_equal(again.X, good.X) and np.array_equal(again.iters, good.iters)
+    # without the time-parallel flag the hook has no effect
+    plain = mpc_step_batch(xbar, ubar, np.ones(S), consts, r_des, flags=TP_DEAD)
+    assert (plain.status == 0).all()
