@@ -101,8 +101,9 @@ int mpcx_set_stream(mpcx_ctx *ctx, void *stream);
  *   MPCX_TR_HOST_STAGE    host copies into the staging pool + enqueueing of transfers and kernels
  *   MPCX_TR_HOST_WAIT     host blocked on the stream (events of the downloads, final synchronisation)
  *   MPCX_TR_HOST_COPYOUT  staging -> the caller's result arrays
- *   MPCX_TR_DEV_SPAN      the device's own time stamps: first marker -> last download done
- *   MPCX_TR_DEV_KERNELS   ... first marker -> first download queued (uploads + kernels)
+ *   MPCX_TR_DEV_SPAN      the device's own time stamps: first marker -> last download done (includes any time the stream sat
+ *                         waiting for the host to enqueue the next transfer)
+ *   MPCX_TR_DEV_KERNELS   ... last upload done -> kernels done: the call's kernels alone, as the device ran them
  *   MPCX_TR_VALID         1 when the record belongs to a traced call
  * mpcx_last_call_trace copies the record of the context's last traced call (n <= MPCX_TRACE_N doubles).  The same marks are
  * printed to stderr for calls slower than MPCX_HOST_TRACE=<ms> (environment), with or without mpcx_trace_enable. */

@@ -28,12 +28,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
+    """hipcc every translation unit to an object file side by side (the solver's headers are compiled four times -- solve.hip,
+    solve2w.hip, solve_lds.hip, solve_tp.hip: one after the other they were a 46 s build), then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f not in ("-shared",)]
+    srcs = sources()
+    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [HIPCC] + cflags + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=jobs or min(len(srcs), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_one, zip(srcs, objs)))
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -35,7 +35,9 @@ extern "C" int mpcx_create(int device, mpcx_ctx **out)
     mpcx_ctx *c = new mpcx_ctx();
     c->device = device; c->err[0] = 0; c->ws = nullptr; c->ws_bytes = 0;
     c->prev_iters = nullptr; c->order = nullptr; c->pred_hist = nullptr; c->order_S = 0; c->order_valid = 0; c->order_cap = 0;
-    c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0;
+    c->nreg = nullptr; c->nreg_cap = 0; c->nreg_S = 0; c->nreg_first = 0; c->nreg_total = 0;
+    c->ord2 = {nullptr, nullptr, nullptr, 0, 0, 0}; c->cur_lane = 0;
+    c->stream2 = nullptr; c->ev_fork = c->ev_join = c->ev_stagger = nullptr;
     c->copier = nullptr;
     c->counter = nullptr; c->launch_seq = 0; c->n_slots = prop.multiProcessorCount * 8;
     c->red = nullptr; c->red_cap = 0; c->coop_max = 0; c->tp_max = 0;
@@ -62,6 +64,11 @@ extern "C" void mpcx_destroy(mpcx_ctx *ctx)
     if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->pred_hist) (void)hipFree(ctx->pred_hist);
     if (ctx->nreg) (void)hipFree(ctx->nreg);
+    if (ctx->ord2.prev_iters) (void)hipFree(ctx->ord2.prev_iters);
+    if (ctx->ord2.order) (void)hipFree(ctx->ord2.order);
+    if (ctx->ord2.pred_hist) (void)hipFree(ctx->ord2.pred_hist);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_stagger}) if (e) (void)hipEventDestroy(e);
     if (ctx->counter) (void)hipFree(ctx->counter);
     if (ctx->red) (void)hipFree(ctx->red);
     pool_free(ctx->pool_dev); pool_free(ctx->pool_host);

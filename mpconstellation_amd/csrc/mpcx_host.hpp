@@ -127,9 +127,16 @@ struct mpcx_ctx {
     // longest first; valid only for a following solve of the same batch size
     int32_t *prev_iters, *order, *pred_hist;     // prev_iters: the prediction the order is sorted by; pred_hist: the last solves' counts
     int order_S, order_valid, order_cap;
+    // the same state for the SECOND half of a split update (mpcx_mpc_update_batch runs the two halves of a large batch as two
+    // chains on two streams: each half is its own sequence of solves of its own batch size)
+    struct OrderState { int32_t *prev_iters, *order, *pred_hist; int order_S, order_valid, order_cap; } ord2;
+    int cur_lane;             // 0: the state above; 1: ord2 (set around the second half's solves only)
     // regularisation counts of the last solve ([S][2] int32, include/mpcx.h: mpcx_solve_regularised)
     int32_t *nreg;
     int nreg_cap, nreg_S;
+    int nreg_first, nreg_total;        // split update: this solve's satellites start at nreg_first of a record of nreg_total
+    hipStream_t stream2;               // the second half's stream and the events that fork / join it (created on first use)
+    hipEvent_t ev_fork, ev_join, ev_stagger;
     int32_t *counter;         // ring of work-queue counters of the solver's persistent workgroups (one per launch in flight)
     unsigned launch_seq;      // solves launched so far: selects the counter
     int n_slots;              // single-wave workgroups of solve_kernel the device holds at once (compute units x 8)
@@ -229,11 +236,12 @@ class DeviceArena {
         if (trace.on && dev_ev_[0]) { while (hipEventQuery(dev_ev_[0]) == hipErrorNotReady) {} trace.mark("q:first-marker"); }
     }
     HostTrace trace;
-    // tracing only: device-side time stamps on the context's stream -- 0 call start, 1 uploads queued (kernels follow),
+    // tracing only: device-side time stamps on the context's stream -- 0 call start, 1 last upload done (kernels follow),
     // 2 first download queued (kernels done), 3 last download queued -- so that a slow call can be split into transfer in,
     // kernels and transfer out AS THE DEVICE SAW THEM, beside the host's view of the same call
     hipEvent_t dev_ev_[4];
     int dev_stage_ = 0;
+    bool have_up_ = false;
     void dev_mark(int i) { if (trace.on && dev_ev_[i]) (void)hipEventRecord(dev_ev_[i], ctx_->stream); }
     // A call that returns early (an error after its first transfer was queued) leaves copies from / to the staging pools in
     // flight; the next call resets the pools and would overwrite them.  The stream is drained before that can happen.
@@ -269,6 +277,7 @@ class DeviceArena {
             trace.mark("up:attr");
             hipError_t e = hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
             trace.mark("up:enq");
+            dev_mark(1); have_up_ = true;
             if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
             return d;
         }
@@ -280,6 +289,7 @@ class DeviceArena {
         trace.mark("up:copy");
         hipError_t e = hipMemcpyAsync(d, pin, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream);
         trace.mark("up:enq");
+        dev_mark(1); have_up_ = true;          // (re-recorded by every upload: it ends up behind the LAST one, in front of the kernels)
         if (e != hipSuccess) code_ = ctx_fail(ctx_, MPCX_E_HIP, hipGetErrorString(e));
         return d;
     }
@@ -347,8 +357,10 @@ class DeviceArena {
             r[MPCX_TR_HOST_STAGE] = trace.sum("up:") + trace.sum("kernels") + trace.sum("down:");
             r[MPCX_TR_HOST_WAIT] = trace.sum("fin:event") + trace.sum("fin:sync");
             r[MPCX_TR_HOST_COPYOUT] = trace.sum("fin:copy") + trace.sum("fin:small");
+            float kk = a;                                   // kernels alone: last upload done -> first download queued
+            if (have_up_ && dev_ev_[1]) (void)hipEventElapsedTime(&kk, dev_ev_[1], dev_ev_[2]);
             r[MPCX_TR_DEV_SPAN] = (double)a + (double)b;
-            r[MPCX_TR_DEV_KERNELS] = (double)a;
+            r[MPCX_TR_DEV_KERNELS] = (double)kk;
             r[MPCX_TR_VALID] = 1.0;
         }
         trace.report("host-pointer call");

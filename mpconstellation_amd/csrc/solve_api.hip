@@ -122,36 +122,44 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     a.X = X; a.U = U; a.NU = NU; a.tf_out = tf_out; a.kkt = kkt; a.status = status; a.iters = iters;
     a.ws = (double *)workspace; a.ws_stride = ws_doubles(K);
     // per-satellite regularisation counts of this solve (library-owned, grow-only; read back by mpcx_solve_regularised)
-    if (ctx->nreg_cap < S) {
+    // (a split update -- two halves of one batch solved on two streams -- has sized the record for the whole batch beforehand and
+    //  names this half's place in it: nreg_first / nreg_total)
+    const int nreg_need = ctx->nreg_total > 0 ? ctx->nreg_total : S;
+    if (ctx->nreg_cap < nreg_need) {
         if (ctx->nreg) (void)hipFree(ctx->nreg);
         ctx->nreg = nullptr; ctx->nreg_cap = 0;
-        MPCX_HIP(ctx, hipMalloc((void **)&ctx->nreg, (size_t)S * 2 * sizeof(int32_t)));
-        ctx->nreg_cap = S;
+        MPCX_HIP(ctx, hipMalloc((void **)&ctx->nreg, (size_t)nreg_need * 2 * sizeof(int32_t)));
+        ctx->nreg_cap = nreg_need;
     }
-    a.nreg = ctx->nreg; ctx->nreg_S = S;
+    a.nreg = ctx->nreg + (ctx->nreg_total > 0 ? 2 * (size_t)ctx->nreg_first : 0); ctx->nreg_S = nreg_need;
     // longest-first launch order from the previous solve's iteration counts (include/mpcx.h, MPCX_SOLVE_INDEX_ORDER)
     // (a batch the device holds at once has no order to choose: every satellite starts at time 0)
     const bool adaptive = !(opts->flags & MPCX_SOLVE_INDEX_ORDER) && S > ctx->n_slots;
     a.order = nullptr;
+    // the launch-order state of this sequence of solves: the context's, or -- second half of a split update -- its twin
+    int32_t *&o_prev = ctx->cur_lane ? ctx->ord2.prev_iters : ctx->prev_iters, *&o_order = ctx->cur_lane ? ctx->ord2.order : ctx->order;
+    int32_t *&o_hist = ctx->cur_lane ? ctx->ord2.pred_hist : ctx->pred_hist;
+    int &o_S = ctx->cur_lane ? ctx->ord2.order_S : ctx->order_S, &o_valid = ctx->cur_lane ? ctx->ord2.order_valid : ctx->order_valid;
+    int &o_cap = ctx->cur_lane ? ctx->ord2.order_cap : ctx->order_cap;
     if (adaptive) {
         // grow-only buffers (a smaller batch reuses them: no free / allocation, hence no implicit device synchronisation,
         // when ConstellationMPC alternates group sizes on one context); the stored counts are valid only for a following
         // solve of the same batch size
-        if (ctx->order_cap < S) {
-            if (ctx->prev_iters) (void)hipFree(ctx->prev_iters);
-            if (ctx->pred_hist) (void)hipFree(ctx->pred_hist);
-            ctx->pred_hist = nullptr;
-            if (ctx->order) (void)hipFree(ctx->order);
-            ctx->prev_iters = ctx->order = nullptr; ctx->order_cap = 0; ctx->order_S = 0; ctx->order_valid = 0;
-            MPCX_HIP(ctx, hipMalloc((void **)&ctx->prev_iters, (size_t)S * sizeof(int32_t)));
-            MPCX_HIP(ctx, hipMalloc((void **)&ctx->pred_hist, (size_t)kPredHist * S * sizeof(int32_t)));
-            MPCX_HIP(ctx, hipMalloc((void **)&ctx->order, (size_t)S * sizeof(int32_t)));
-            ctx->order_cap = S;
+        if (o_cap < S) {
+            if (o_prev) (void)hipFree(o_prev);
+            if (o_hist) (void)hipFree(o_hist);
+            o_hist = nullptr;
+            if (o_order) (void)hipFree(o_order);
+            o_prev = o_order = nullptr; o_cap = 0; o_S = 0; o_valid = 0;
+            MPCX_HIP(ctx, hipMalloc((void **)&o_prev, (size_t)S * sizeof(int32_t)));
+            MPCX_HIP(ctx, hipMalloc((void **)&o_hist, (size_t)kPredHist * S * sizeof(int32_t)));
+            MPCX_HIP(ctx, hipMalloc((void **)&o_order, (size_t)S * sizeof(int32_t)));
+            o_cap = S;
         }
-        if (ctx->order_S != S) { ctx->order_S = S; ctx->order_valid = 0; }
-        if (ctx->order_valid) {
-            mpcx_launch::launch_order(S, ctx->prev_iters, ctx->order, (hipStream_t)stream);
-            a.order = ctx->order;
+        if (o_S != S) { o_S = S; o_valid = 0; }
+        if (o_valid) {
+            mpcx_launch::launch_order(S, o_prev, o_order, (hipStream_t)stream);
+            a.order = o_order;
         }
     }
     if (opts->flags & MPCX_SOLVE_SHARED_TF) {
@@ -178,7 +186,7 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
         a.counter = nullptr; a.order = nullptr;
         MPCX_HIP(ctx, hipMemsetAsync(a.arrive, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
         MPCX_HIP(ctx, mpcx_launch::solve_shared(a, (hipStream_t)stream));
-        ctx->order_valid = 0;
+        o_valid = 0;
         return MPCX_OK;
     }
     // the launch's own work-queue counter: one of a ring, so that two solves of one context enqueued on different streams
@@ -221,11 +229,11 @@ extern "C" int mpcx_solve_batch_ragged_dev(mpcx_ctx *ctx, int S, int K, const in
     MPCX_HIP(ctx, hipGetLastError());
     if (adaptive) {
         // (order_valid counts the solves of this batch size recorded so far)
-        const int slot = ctx->order_valid % kPredHist, n_valid = ctx->order_valid + 1 < kPredHist ? ctx->order_valid + 1 : kPredHist;
-        mpcx_launch::update_prediction(S, iters, ctx->pred_hist, ctx->prev_iters, slot, n_valid, (hipStream_t)stream);
+        const int slot = o_valid % kPredHist, n_valid = o_valid + 1 < kPredHist ? o_valid + 1 : kPredHist;
+        mpcx_launch::update_prediction(S, iters, o_hist, o_prev, slot, n_valid, (hipStream_t)stream);
         MPCX_HIP(ctx, hipGetLastError());
-        ctx->order_valid += 1;
-        if (ctx->order_valid >= 2 * kPredHist) ctx->order_valid -= kPredHist;     // (keeps slot and n_valid as they are)
+        o_valid += 1;
+        if (o_valid >= 2 * kPredHist) o_valid -= kPredHist;     // (keeps slot and n_valid as they are)
     }
     return MPCX_OK;
 }
@@ -389,10 +397,31 @@ extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, dou
     if (y_sim && (sim_n_eval < 1 || !(sim_tf > 0.0) || !(sim_interval > 0.0) || !sim_status))
         return ctx_fail(ctx, MPCX_E_BADARG, "mpc_update: segment flight needs sim_tf>0, sim_interval>0, sim_n_eval>=1, sim_status");
     MPCX_HIP(ctx, hipSetDevice(ctx->device));
-    void *ws = ctx_workspace(ctx, mpcx_mpc_step_workspace_bytes_ctx(ctx, S, K));
-    if (!ws) return MPCX_E_NOMEM;
+    // MPCX_UPDATE_SPLIT=1 / 2 (default 0): the batch as TWO chains -- the two halves of the satellites, each rollout -> discretise ->
+    // solve -> ... -> flight on its own stream (satellites are independent: every satellite gets the bits the one-chain call
+    // gives it, tests/test_mpc_loop_gpu.py::test_split_update_two_chains_equal_one), so that one half's rollouts (a sequential
+    // chain of ~1000 RK steps on a quarter of the SIMDs whatever S: 13.5 of 79.5 ms of kernels per two segments at 4096
+    // satellites) run under the other half's solve; =2 also delays the second chain's start until the first has reached its
+    // first solve.  Round-4 verdict item 5; built, measured (profiles/r05/update_split.txt) and NOT the default: the kernels do
+    // overlap, and the closed loop is exactly as fast -- 45.0 against 45.1 ms per segment at 4096 satellites, 80.9 / 79.7 at
+    // 8192, 28.1 / 33.1 at 2048 -- because two launches of 2048 satellites fill the 2048 wave slots in index order, which gives
+    // back what the longest-first order of ONE launch of 4096 had gained (9.5 against 10.3 ms per solve).
+    const char *split_env = getenv("MPCX_UPDATE_SPLIT");            // (read per call: a test switches it inside one process)
+    const int split_mode = split_env ? atoi(split_env) : 0;
+    const bool split = split_mode > 0 && S >= 2 * kTwoWaveMax && !(opts->flags & MPCX_SOLVE_TIME_PARALLEL);
+    const int nhalf = split ? 2 : 1;
+    const int cnt[2] = {split ? (S + 1) / 2 : S, split ? S / 2 : 0}, fst[2] = {0, cnt[0]};
+    size_t ws_bytes[2] = {mpcx_mpc_step_workspace_bytes_ctx(ctx, cnt[0], K), split ? mpcx_mpc_step_workspace_bytes_ctx(ctx, cnt[1], K) : 0};
+    ws_bytes[0] = (ws_bytes[0] + 255) & ~(size_t)255;
+    char *wsb = (char *)ctx_workspace(ctx, ws_bytes[0] + ws_bytes[1]);
+    if (!wsb) return MPCX_E_NOMEM;
+    if (split && !ctx->stream2) {
+        MPCX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger, hipEventDisableTiming));
+    }
     DeviceArena ar(ctx);
-    hipStream_t st = ctx->stream;
     double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf0 = ar.upload(tf0, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
     const size_t n7 = (size_t)S * 7 * K, n3 = (size_t)S * 3 * K;
     double *dx = ar.alloc<double>(n7), *du = ar.alloc<double>(n3);                      // reference trajectory / thrust of the iteration
@@ -406,51 +435,91 @@ extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, dou
     double *dys = y_sim ? ar.alloc<double>((size_t)S * 7 * sim_n_eval) : nullptr;
     int32_t *dss = y_sim ? ar.alloc<int32_t>(S) : nullptr;
     if (ar.failed()) return ar.code();
-    mpcx_launch::fill_f64(S, ref_thrust, dmag, st);
-    mpcx_launch::fill_f64(S, 1.0, done, st);
-    MPCX_HIP(ctx, hipMemsetAsync(dps, 0, sizeof(int32_t) * S, st));
-    const double *tf_cur = dtf0;
-    const int32_t *Ks = nullptr;            // node counts of the current iteration (nullptr: K for everybody)
+    if (split) {
+        // (the regularisation record is sized for the whole batch BEFORE anything is enqueued: no allocation under a running half)
+        if (ctx->nreg_cap < S) {
+            if (ctx->nreg) (void)hipFree(ctx->nreg);
+            ctx->nreg = nullptr; ctx->nreg_cap = 0;
+            MPCX_HIP(ctx, hipMalloc((void **)&ctx->nreg, (size_t)S * 2 * sizeof(int32_t)));
+            ctx->nreg_cap = S;
+        }
+        MPCX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));                   // the uploads are behind this point of the first stream
+        MPCX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    const double *tf_fin = dtf0;
+    const int32_t *Ks_fin = nullptr;
+    const double *Uplan = dU[(n_scp - 1) & 1];
+    // one half's chain: satellites f .. f + n - 1 on stream st, with its own workspace and (second half) launch-order state
+    auto chain = [&](int f, int n, hipStream_t st, void *ws, int lane) -> int {
+        const size_t o1 = (size_t)f, o7 = (size_t)f * 7 * K, o3 = (size_t)f * 3 * K;
+        mpcx_launch::fill_f64(n, ref_thrust, dmag + o1, st);
+        mpcx_launch::fill_f64(n, 1.0, done + o1, st);
+        MPCX_HIP(ctx, hipMemsetAsync(dps + o1, 0, sizeof(int32_t) * n, st));
+        const double *tf_cur = dtf0 + o1;
+        const int32_t *Ks = nullptr;            // node counts of the current iteration (nullptr: K for everybody)
+        int rc = MPCX_OK;
+        ctx->cur_lane = lane; ctx->nreg_first = f; ctx->nreg_total = split ? S : 0;
+        for (int it = 0; it < n_scp && rc == MPCX_OK; ++it) {
+            double *Uw = dU[it & 1] + o3, *tfw = dtfu[it & 1] + o1;
+            if (Ks) {                                                                         // ragged rows: the unused columns
+                MPCX_HIP(ctx, hipMemsetAsync(dx + o7, 0, (size_t)n * 7 * K * sizeof(double), st));
+                MPCX_HIP(ctx, hipMemsetAsync(du + o3, 0, (size_t)n * 3 * K * sizeof(double), st));
+            }
+            // control.py:178-180 / :217-227: rollout under the tangential reference law, then under the sequence just optimised,
+            // played over its own horizon (end_tau = 1) and sampled at int(base_res * tf_u) nodes; u_bar = extract_uk (:188)
+            if (it == 0)
+                rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, n, K, nullptr, dy0 + o1 * 7, tf_cur, dc + o1 * MPCX_NCONST, 0, MPCX_CTRL_TANGENTIAL,
+                                                            dmag + o1, 0, nullptr, nullptr, prop_max_step, dx + o7, du + o3, dps2 + o1, dpn + o1, st);
+            else
+                rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, n, K, Ks, dy0 + o1 * 7, tf_cur, dc + o1 * MPCX_NCONST, 0, MPCX_CTRL_SEQUENCE,
+                                                            dU[(it - 1) & 1] + o3, K, it >= 2 ? dKn[(it - 1) & 1] + o1 : nullptr, done + o1,
+                                                            prop_max_step, dx + o7, du + o3, dps2 + o1, dpn + o1, st);
+            if (rc) break;
+            mpcx_launch::merge_status(n, dps2 + o1, dps + o1, st);                          // (any rollout's failure is the update's)
+            if (split && lane == 0 && it == 0 && split_mode == 2) MPCX_HIP(ctx, hipEventRecord(ctx->ev_stagger, st));
+            rc = mpcx_mpc_step_batch_ragged_dev(ctx, n, K, Ks, dx + o7, du + o3, tf_cur, dc + o1 * MPCX_NCONST, drd + o1, disc_flags, disc_max_step,
+                                                opts, dX + o7, Uw, dNU + o7, tfw, dst + (size_t)it * S + o1, dit + (size_t)it * S + o1, dk + o1, ws, st);
+            if (rc) break;
+            tf_cur = tfw;
+            if (it + 1 < n_scp) {
+                int32_t *kn = dKn[(it + 1) & 1] + o1;
+                mpcx_launch::node_count(n, base_res, tfw, kn, st);
+                Ks = kn;
+            }
+        }
+        ctx->cur_lane = 0; ctx->nreg_first = 0; ctx->nreg_total = 0;
+        if (rc) return rc;
+        MPCX_HIP(ctx, hipGetLastError());
+        if (f == 0) { tf_fin = tf_cur; Ks_fin = Ks; }                                       // (the whole-batch arrays the downloads read)
+        if (y_sim) {
+            // Simulator.run_segment (simulator.py:58-65): fly sim_tf under the truth model with SequenceController(u_opt, tf_u,
+            // tf_sim = sim_interval): end_tau = tf_u / sim_interval (control.py:102), the plan's table with its own column count
+            // (end_tau as the host computes it: a division, not a product with the reciprocal)
+            mpcx_launch::divide_f64(n, tf_cur, sim_interval, dend + o1, st);
+            mpcx_launch::fill_f64(n, sim_tf, dmag + o1, st);           // (dmag is free again: the flight time per satellite)
+            rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, n, sim_n_eval, nullptr, dy0 + o1 * 7, dmag + o1, dc + o1 * MPCX_NCONST, sim_flags,
+                                                        MPCX_CTRL_SEQUENCE, Uplan + o3, K, Ks, dend + o1, sim_max_step, dys + o1 * 7 * sim_n_eval, nullptr,
+                                                        dss + o1, dpn + o1, st);
+            if (rc) return rc;
+        }
+        return MPCX_OK;
+    };
     int rc = MPCX_OK;
-    for (int it = 0; it < n_scp && rc == MPCX_OK; ++it) {
-        double *Uw = dU[it & 1], *tfw = dtfu[it & 1];
-        if (Ks) {                                                                         // ragged rows: the unused columns
-            MPCX_HIP(ctx, hipMemsetAsync(dx, 0, n7 * sizeof(double), st));
-            MPCX_HIP(ctx, hipMemsetAsync(du, 0, n3 * sizeof(double), st));
-        }
-        // control.py:178-180 / :217-227: rollout under the tangential reference law, then under the sequence just optimised,
-        // played over its own horizon (end_tau = 1) and sampled at int(base_res * tf_u) nodes; u_bar = extract_uk (:188)
-        if (it == 0)
-            rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, K, nullptr, dy0, tf_cur, dc, 0, MPCX_CTRL_TANGENTIAL, dmag, 0, nullptr, nullptr,
-                                                        prop_max_step, dx, du, dps2, dpn, st);
-        else
-            rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, K, Ks, dy0, tf_cur, dc, 0, MPCX_CTRL_SEQUENCE, dU[(it - 1) & 1], K,
-                                                        it >= 2 ? dKn[(it - 1) & 1] : nullptr, done, prop_max_step, dx, du, dps2, dpn, st);
-        if (rc) break;
-        mpcx_launch::merge_status(S, dps2, dps, st);                                    // (any rollout's failure is the update's)
-        rc = mpcx_mpc_step_batch_ragged_dev(ctx, S, K, Ks, dx, du, tf_cur, dc, drd, disc_flags, disc_max_step, opts, dX, Uw, dNU, tfw,
-                                            dst + (size_t)it * S, dit + (size_t)it * S, dk, ws, st);
-        if (rc) break;
-        tf_cur = tfw;
-        if (it + 1 < n_scp) {
-            int32_t *kn = dKn[(it + 1) & 1];
-            mpcx_launch::node_count(S, base_res, tfw, kn, st);
-            Ks = kn;
-        }
+    rc = chain(fst[0], cnt[0], ctx->stream, wsb, 0);
+    if (rc == MPCX_OK && split) {
+        // (mode 2: the second chain starts when the first has reached its first solve -- its rollout and discretisation then run UNDER it)
+        if (split_mode == 2) MPCX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_stagger, 0));
+        rc = chain(fst[1], cnt[1], ctx->stream2, wsb + ws_bytes[0], 1);
+    }
+    if (split) {
+        // join: the downloads on the first stream follow everything of the second (also on an error path: nothing of this call
+        // is left running on the second stream when the arena's buffers are handed to the next call)
+        (void)hipEventRecord(ctx->ev_join, ctx->stream2);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
     }
     if (rc) return rc;
-    MPCX_HIP(ctx, hipGetLastError());
-    const double *Uplan = dU[(n_scp - 1) & 1];
-    if (y_sim) {
-        // Simulator.run_segment (simulator.py:58-65): fly sim_tf under the truth model with SequenceController(u_opt, tf_u,
-        // tf_sim = sim_interval): end_tau = tf_u / sim_interval (control.py:102), the plan's table with its own column count
-        // (end_tau as the host computes it: a division, not a product with the reciprocal)
-        mpcx_launch::divide_f64(S, tf_cur, sim_interval, dend, st);
-        mpcx_launch::fill_f64(S, sim_tf, dmag, st);           // (dmag is free again: the flight time per satellite)
-        rc = mpcx_propagate_thrust_batch_ragged_dev(ctx, S, sim_n_eval, nullptr, dy0, dmag, dc, sim_flags, MPCX_CTRL_SEQUENCE, Uplan, K, Ks, dend,
-                                                    sim_max_step, dys, nullptr, dss, dpn, st);
-        if (rc) return rc;
-    }
+    const double *tf_cur = tf_fin;
+    const int32_t *Ks = Ks_fin;
     ar.download(X, dX, n7); ar.download(U, (const double *)Uplan, n3); ar.download(NU, dNU, n7);
     ar.download(tf_out, tf_cur, S);
     if (Ks) ar.download(Ks_out, Ks, S);

@@ -151,7 +151,11 @@ __device__ __forceinline__ ChanIn chan_mask(const ChanRaw &cr, int c, int r, boo
 // P_k += om v v^T  -- the weight enters only through 1/ex, nothing of size ex is ever formed (condensed into the
 // blocks, 1e14 r r^T would leave no digit of the trust-region curvature 2 w_tr in the other directions).  Position term
 // first, thrust ball second (on the once-updated quantities).  Same arithmetic as the oracle's riccati_factor.
-__device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, wf64 *fac, int lane)
+// Pdst: the buffer of P_k the update goes to in the two-wave factorisation (its double-buffered copy; the one-wave one updates w.Pn).  fac: the node's factor
+// record -- the one-wave factorisation stores the updated gain and Q_uu^-1 there itself; nullptr in the two-wave factorisation,
+// where they go to the node's LDS copies (o.Kg, o.Qi) and the second wave stores them.  One body for both (round 4 had it twice).
+template <bool TO_RECORD>
+__device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, double *Pdst, wf64 *fac, int lane)
 {
     double Qi[9];
     (void)inv3_spd(w.Quu, Qi);
@@ -193,67 +197,9 @@ __device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, wf64 *f
         for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
         double v1l, v2l, v1h, v2h;
         sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
-        w.Pn[lane] += om1 * (v1l * v1h) + om2 * (v2l * v2h);
-    }
-    if (lane < 21) {
-        const int r = lane / 7, c = lane - 7 * r;
-        const double qc[3] = {w.Quy[c], w.Quy[7 + c], w.Quy[14 + c]};
-        double v1, v2;
-        sm_v(qc, c, v1, v2);
-        const double kg = o.Kg[lane] + om1 * t1[r] * v1 + om2 * t2[r] * v2;
-        o.Kg[lane] = kg; fac[F_KG + lane] = kg;
-    }
-    if (lane < 9) {
-        const int r = lane / 3, c = lane - 3 * r;
-        fac[F_QI + lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
-    }
-}
-
-#ifdef MPCX_TWO_WAVE
-// (two-wave build: the same update on the node's LDS copies -- P_k's buffer, gain, Q_uu^-1 -- which the second wave stores)
-__device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double *PnT, int lane)
-{
-    double Qi[9];
-    (void)inv3_spd(w.Quu, Qi);
-    const double ex_x = o.SX[SX_EX], ex_u = o.SX[SX_EU];
-    double om1 = 0.0, om2 = 0.0, t1[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, tc = 0.0;
-    double ax[3], cu[3], c1[3];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) { ax[l] = o.SX[SX_A + l]; cu[l] = o.SX[SX_CU + l]; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) c1[j] = o.Bpm[j] * ax[0] + o.Bpm[3 + j] * ax[1] + o.Bpm[6 + j] * ax[2];
-    if (ex_x > 0.0) {
-#pragma unroll
-        for (int l = 0; l < 3; ++l) t1[l] = Qi[l * 3] * c1[0] + Qi[l * 3 + 1] * c1[1] + Qi[l * 3 + 2] * c1[2];
-        om1 = 1.0 / (1.0 / ex_x + (c1[0] * t1[0] + c1[1] * t1[1] + c1[2] * t1[2]));
-    }
-    if (ex_u > 0.0) {
-        double q2[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) q2[l] = Qi[l * 3] * cu[0] + Qi[l * 3 + 1] * cu[1] + Qi[l * 3 + 2] * cu[2];
-        tc = t1[0] * cu[0] + t1[1] * cu[1] + t1[2] * cu[2];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) t2[l] = q2[l] - om1 * tc * t1[l];                  // Qi' c_u with Qi' = Qi - om1 t1 t1^T
-        om2 = 1.0 / (1.0 / ex_u + (cu[0] * t2[0] + cu[1] * t2[1] + cu[2] * t2[2]));
-    }
-    // component j of v1 = a - Quy^T t1 and of v2 = -Kg'^T c_u = -(Quy^T q2) - om1 (t1.c_u) v1, from column j of Quy
-    // (Quy^T q2 = Quy^T (t2 + om1 tc t1))
-    auto sm_v = [&](const double (&qc)[3], int j, double &v1, double &v2) {
-        const double cyj = (j < 3) ? o.SX[SX_A + j] : 0.0;
-        const double qt1 = qc[0] * t1[0] + qc[1] * t1[1] + qc[2] * t1[2];
-        v1 = (ex_x > 0.0) ? cyj - qt1 : 0.0;
-        v2 = -(qc[0] * t2[0] + qc[1] * t2[1] + qc[2] * t2[2]) - om1 * tc * qt1 - om1 * tc * v1;
-    };
-    wsync();                                       // every lane has read what it needs of the un-updated values
-    if (lane < 49) {
-        const int mi = lane / 7, mj = lane - 7 * mi;
-        const int lo = (mi < mj) ? mi : mj, hi = (mi < mj) ? mj : mi;
-        double qi[3], qj[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) { qi[l] = w.Quy[l * 7 + lo]; qj[l] = w.Quy[l * 7 + hi]; }
-        double v1l, v2l, v1h, v2h;
-        sm_v(qi, lo, v1l, v2l); sm_v(qj, hi, v1h, v2h);
-        PnT[lane] += om1 * (v1l * v1h) + om2 * (v2l * v2h);
+        double *P = Pdst;
+        if constexpr (TO_RECORD) P = w.Pn;          // (the one-wave factorisation's own buffer: an LDS address the compiler knows)
+        P[lane] += om1 * (v1l * v1h) + om2 * (v2l * v2h);
     }
     if (lane < 21) {
         const int r = lane / 7, c = lane - 7 * r;
@@ -262,13 +208,17 @@ __device__ __noinline__ void stiff_stage_update2(StageOps &o, Scratch &w, double
         sm_v(qc, c, v1, v2);
         const double kg = o.Kg[lane] + om1 * t1[r] * v1 + om2 * t2[r] * v2;
         o.Kg[lane] = kg;
+        if constexpr (TO_RECORD) fac[F_KG + lane] = kg;
     }
     if (lane < 9) {
         const int r = lane / 3, c = lane - 3 * r;
-        o.Qi[lane] = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
+        const double qv = Qi[lane] - om1 * t1[r] * t1[c] - om2 * t2[r] * t2[c];
+        if constexpr (TO_RECORD) fac[F_QI + lane] = qv;
+#ifdef MPCX_TWO_WAVE
+        else o.Qi[lane] = qv;
+#endif
     }
 }
-#endif
 
 
 #ifdef MPCX_TWO_WAVE
@@ -560,7 +510,7 @@ __device__ __noinline__ bool riccati_factor2(const Sat &s_in, SatData &sd, Scrat
             // second wave writes to the record afterwards
             if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) {
                 wsync();
-                stiff_stage_update2(o, w, w.Pn2[k & 1], lane);
+                stiff_stage_update<false>(o, w, w.Pn2[k & 1], nullptr, lane);
             }
             if (!__all(good) && lane == 0) RF_GOOD = 0;
         } else {
@@ -954,7 +904,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         }
         // stiff stage terms (rare: an active r_min plane / radius or thrust ball late in the iteration): rank-1 update of
         // what was just written; out of line so that the common path keeps its register allocation
-        if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) stiff_stage_update(o, w, fac, lane);
+        if (o.SX[SX_EX] > 0.0 || o.SX[SX_EU] > 0.0) stiff_stage_update<true>(o, w, nullptr, fac, lane);
         FT_MARK(6)
         FT_MARK(7)
         // inputs of node k for its sweep in the next iteration (the terminal node's come from LDS)

@@ -338,3 +338,38 @@ def test_several_devices_from_the_api():
     for f in ("X", "U", "NU", "tf", "status", "iters", "kkt", "Ks", "prop_status", "y_sim", "sim_status"):
         assert np.array_equal(getattr(upd1, f), getattr(upd3, f)), f
     assert upd3.status.shape == (2, 7) and upd3.y_sim.shape == (7, 7, 40)
+
+
+def test_split_update_two_chains_equal_one():
+    """mpcx_mpc_update_batch runs a large batch (>= 2048 satellites) as TWO chains -- its halves, each rollout -> discretise ->
+    solve -> re-rollout -> ... -> flight on its own stream, so that one half's rollouts and the tail of its solve launch run under
+    the other half's solve (control.py:178-180,221-227 are the rollouts; satellites are independent).  Same bits as ONE chain
+    (MPCX_UPDATE_SPLIT=0), with and without the delayed start of the second chain (=2), three SCP iterations (a ragged table
+    played back), an odd batch size, the regularisation record of both halves in one array."""
+    import os
+    from mpconstellation_amd import mpc_update_batch, ConstellationMPC, _ffi
+    from mpconstellation_amd.constellation import constellation_states, normalize_batch
+    S = 2049
+    y0, consts = normalize_batch(constellation_states(4096, first=100, count=S))
+    kw = dict(n_scp=3, options=ConstellationMPC.OPTIONS(2.0), fly=(1.0, 1.0, 25, True, True))
+    res = {}
+    old = os.environ.get("MPCX_UPDATE_SPLIT")
+    try:
+        for mode in ("0", "1", "2"):
+            os.environ["MPCX_UPDATE_SPLIT"] = mode
+            r = mpc_update_batch(y0, 2.0, consts, 1.5, 30, **kw)
+            reg = np.zeros((S, 2), dtype=np.int32)
+            lib = _ffi.load(); ctx = _ffi.context(0)
+            _ffi.check(lib.mpcx_solve_regularised(ctx, S, _ffi.iptr(reg)), ctx, "mpcx_solve_regularised")
+            res[mode] = (r, reg)
+    finally:
+        if old is None: os.environ.pop("MPCX_UPDATE_SPLIT", None)
+        else: os.environ["MPCX_UPDATE_SPLIT"] = old
+    one = res["0"][0]
+    assert np.isin(one.status, (0, 7)).mean() > 0.99 and (one.prop_status == 0).all() and (one.sim_status == 0).all()
+    assert len(set(one.Ks.tolist())) > 1
+    for mode in ("1", "2"):
+        two, reg = res[mode]
+        for f in ("X", "U", "NU", "tf", "status", "iters", "kkt", "Ks", "prop_status", "y_sim", "sim_status"):
+            assert np.array_equal(getattr(one, f), getattr(two, f)), (mode, f)
+        assert np.array_equal(reg, res["0"][1]), mode
