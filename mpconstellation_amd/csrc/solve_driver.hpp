@@ -22,6 +22,14 @@ namespace MPCX_NS {
 #define MPCX_SOLVE_WAVES 2     // waves per SIMD the register allocation is bounded for (256 registers; 3 was measured slower)
 #endif
 
+// The two kernels' LDS working set: ONE pair of module-scope objects, so that it sits at the same LDS address in both and
+// the out-of-line phase functions (which take it by reference) keep addressing it with compile-time offsets -- with a
+// pair per kernel the addresses reach them as run-time pointers (measured: solve_kernel 6.85 -> 8.4 ms at S4096).
+#ifndef MPCX_TP          // (the time-parallel build defines them ahead of its own functions: solve_tp.hpp)
+__shared__ SatData g_sd;
+__shared__ Scratch g_w;
+#endif
+
 // View of satellite `sat`'s problem and of workspace slot `slot` (K: its node count, Kmax: the row length of the arrays)
 __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const int slot, const int K, const int Kmax)
 {
@@ -45,9 +53,9 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     s.nb = wl; wl += (size_t)K * NB_N;
     s.fac = wl; wl += (size_t)K * FAC_N;
     s.ch = wl; wl += (size_t)K * CH_N;
-    s.itg = wl; wl += GL_N;
-    s.drg = wl; wl += GL_N;
-    s.itgB = wl; wl += GL_N;
+    s.itg = (lf64 *)wl; wl += GL_N;
+    s.drg = (lf64 *)wl; wl += GL_N;
+    s.itgB = (lf64 *)wl; wl += GL_N;
     s.sink = wl;
     s.o_fac = (int)(KP * (3 * IT_N + 3) + K * NB_N);
     s.o_ch = s.o_fac + K * FAC_N; s.o_sink = s.o_ch + K * CH_N + 3 * GL_N;
@@ -71,9 +79,10 @@ __device__ __forceinline__ Sat sat_view(const SolveArgs &a, const int sat, const
     s.fac = ws; ws += (size_t)K * FAC_N;
     s.ch = ws; ws += (size_t)K * CH_N;
     s.traj = ws; ws += (size_t)K * NCH * TR_N;
-    s.itg = ws; ws += GL_N;
-    s.drg = ws; ws += GL_N;
-    s.itgB = ws; ws += GL_N;
+    // (the global part of iterate / direction / candidate lives in LDS, SatData::gl; its three slots in the workspace stay
+    //  where they were, unused, so that every offset of the layout is the other rounds')
+    s.itg = (lf64 *)g_sd.gl[0]; s.drg = (lf64 *)g_sd.gl[1]; s.itgB = (lf64 *)g_sd.gl[2];
+    ws += 3 * GL_N;
     s.sink = ws;
     // (offsets as integers computed from the layout, not as pointer differences: the compiler would fold base + (sink -
     //  base) back into a second pointer and emit a branch with one store per path)
@@ -525,7 +534,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
         n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
-        { wf64 *q = s.it; s.it = s.itB; s.itB = q; q = s.itg; s.itg = s.itgB; s.itgB = q; }
+        { wf64 *q = s.it; s.it = s.itB; s.itB = q; lf64 *g = s.itg; s.itg = s.itgB; s.itgB = g; }
         if (SHARED) { gs[0] = gst[0]; gs[1] = gst[1]; gz[0] = gzt[0]; gz[1] = gzt[1]; }
         r0 = rt;
         r0.sq = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;
@@ -569,13 +578,5 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
     }
 }
-
-// The two kernels' LDS working set: ONE pair of module-scope objects, so that it sits at the same LDS address in both and
-// the out-of-line phase functions (which take it by reference) keep addressing it with compile-time offsets -- with a
-// pair per kernel the addresses reach them as run-time pointers (measured: solve_kernel 6.85 -> 8.4 ms at S4096).
-#ifndef MPCX_TP          // (the time-parallel build defines them ahead of its own functions: solve_tp.hpp)
-__shared__ SatData g_sd;
-__shared__ Scratch g_w;
-#endif
 
 }  // namespace MPCX_NS

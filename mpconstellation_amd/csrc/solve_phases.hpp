@@ -29,6 +29,12 @@ struct SatData {
     double sol[NBD];
     double zeta[NTERM];      // border unknowns of the terminal terms accumulated over the passes of one linear solve
     double red[8];
+    // the "global" part of iterate, direction and candidate iterate (GL_N doubles each: slacks / multipliers of the terminal rows
+    // and of the tf range, tf, lam_vt).  Round 5: they live HERE, in LDS, in every build -- until then they were three small
+    // arrays of the satellite's global workspace, and the terminal-node sections of the node-parallel phases read and wrote them
+    // one row at a time in loops the compiler cannot batch (a store to itgB between two loads of itg): seven dependent memory
+    // round trips per trial evaluation and per step-limit pass, which is what those phases waited for under load.
+    double gl[3][GL_N];
     double infeas;           // > 0: the constraint set is empty whatever the dynamics (structural_violation)
     int flag;
 #ifdef MPCX_PHASE_TIMING
@@ -244,6 +250,7 @@ typedef __attribute__((address_space(3))) double wf64;
 typedef gf64 wf64;
 #endif
 typedef const wf64 cwf64;
+typedef __attribute__((address_space(3))) double lf64;      // LDS in every build (SatData::gl: the global part of iterate / direction)
 // the byte type of a pointer's address space (Col, ustore: base + byte offset)
 template <typename T> struct as_bytes { typedef __attribute__((address_space(1))) char type; };
 #ifdef MPCX_WS_LDS
@@ -328,9 +335,10 @@ struct Sat {
     cgf64 *stage, *xbar, *ubar;   // stage (K-1,105) record per node; xbar (7,K); ubar (3,K)
     wf64 *it, *dr, *rbh;                        // field-major [field][KP]: iterate, direction, r-hat
     gf64 *nbs, *stT;                            // ... Newton scalars, stage copy (global in every build)
-    wf64 *itg, *drg, *nb, *fac, *ch;            // globals; record-per-node arrays read by the recursion (one wave, one record)
+    lf64 *itg, *drg, *itgB;                     // global part of iterate, direction, candidate iterate: LDS (SatData::gl)
+    wf64 *nb, *fac, *ch;                        // record-per-node arrays read by the recursion (one wave, one record)
     gf64 *traj;                                 // ... the channels' trajectories (global in every build)
-    wf64 *itB, *itgB;                           // the candidate iterate of the line search (swapped with it, itg on acceptance)
+    wf64 *itB;                                  // the candidate iterate of the line search (swapped with it -- and itgB with itg -- on acceptance)
     wf64 *sink;                                 // 64 doubles nobody reads: target of the lanes a branch-free store leaves idle
     wf64 *ws;                                   // base of the satellite's workspace and the element offsets of the arrays the
     int o_fac, o_ch, o_traj, o_sink;            // recursions store to (plain integers: see ustore)
@@ -473,12 +481,13 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
         const auto pn = p.node(dyn ? 1 : 0), dn = d.node(dyn ? 1 : 0);
         const auto rb = s.rbn(k);
         const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+        double xb[7], ub[3];       // reference row of the node: loaded with the first batch (behind it they were a memory round trip of their own)
         {
             double x0[7], dx[7], u0[3], du[3], bs[6];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { x0[i] = p[I_X + i]; dx[i] = d[I_X + i]; }
+            for (int i = 0; i < 7; ++i) { x0[i] = p[I_X + i]; dx[i] = d[I_X + i]; xb[i] = s.xbar[(size_t)i * s.ldk + k]; }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { u0[i] = p[I_U + i]; du[i] = d[I_U + i]; }
+            for (int i = 0; i < 3; ++i) { u0[i] = p[I_U + i]; du[i] = d[I_U + i]; ub[i] = s.ubar[(size_t)i * s.ldk + k]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
 #pragma unroll
@@ -508,9 +517,9 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
             if (has_prev && dyn) POST(srmin, zrmin, g_rmin);
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - s.xbar[(size_t)i * s.ldk + k]);
+        for (int i = 0; i < 7; ++i) gx[i] = 2.0 * w_tr * (x[i] - xb[i]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - s.ubar[(size_t)i * s.ldk + k]) + 2.0 * u[i] * zu;
+        for (int i = 0; i < 3; ++i) gu[i] = 2.0 * w_tr * (u[i] - ub[i]) + 2.0 * u[i] * zu;
         if (has_prev) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) gx[i] += 2.0 * x[i] * zrmax;
@@ -561,6 +570,8 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                 const double sg = Sg[i], xv = xi[i];
                 const double nu0 = p[I_NU + i], dnu_ = d[I_NU + i], tt0 = p[I_T + i], lam = TRIAL(p, d, I_LAM + i);
                 const double stp0 = p[I_STP + i], ztp0 = p[I_ZTP + i], stn0 = p[I_STN + i], ztn0 = p[I_ZTN + i];
+                const double xn = TRIAL(pn, dn, I_X + i);           // (with the round's other loads: one round trip per round, not two)
+                const double lmv = TRIAL(pm, dm, I_LAM + i);
                 const double dnu = z ? 0.0 : dnu_;
                 const L1Dir ld = l1_dir(nu0, tt0, stp0, ztp0, stn0, ztn0, dnu, mu, w_nu);
                 const bool lon = !z && dyn;                                   // (the terminal node has no virtual control)
@@ -568,8 +579,6 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
                 double stp = fma(a, lon ? ld.dstp : 0.0, stp0), ztp = fma(a, lon ? ld.dztp : 0.0, ztp0);
                 double stn = fma(a, lon ? ld.dstn : 0.0, stn0), ztn = fma(a, lon ? ld.dztn : 0.0, ztn0);
                 if (WRITE && dyn) { POST(stp, ztp, nu - tt); POST(stn, ztn, -nu - tt); }
-                const double xn = TRIAL(pn, dn, I_X + i);
-                const double lmv = TRIAL(pm, dm, I_LAM + i);
                 const double lm = (valid && has_prev) ? lmv : 0.0;
                 // previous row's multiplier
                 gx[r] += half ? 0.0 : lm; gx[(4 + r) % 7] += (half && valid) ? lm : 0.0;
@@ -728,6 +737,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
         // (chunk 0 is computed by both halves and stored by half 0)
         double x[7], u[3], gx[7], gu[3], Wx3[9];
         double zh_rmax = 0.0, sig_rmax = 0.0, zrmax;
+        double rv[4][7];           // the four rounds' inputs, loaded with chunk 0's: one memory round trip per node instead of five
         {
             double bs[6], xb[7], ub[3];
 #pragma unroll
@@ -737,6 +747,14 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
 #pragma unroll
             for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
             const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int iv = 4 * half + r;
+                const int i = (iv < 7) ? iv : 6;
+                rv[r][0] = p[I_NU + i]; rv[r][1] = p[I_T + i]; rv[r][2] = p[I_STP + i]; rv[r][3] = p[I_ZTP + i];
+                rv[r][4] = p[I_STN + i]; rv[r][5] = p[I_ZTN + i]; rv[r][6] = ns[NS_E + i];
+            }
+            CHUNK_END
             const double rbv[3] = {rb0, rb1, rb2};
             const double su = bs[0], zu = bs[1], srmax = bs[2], srmin = bs[4], zrmin = bs[5];
             zrmax = bs[3];
@@ -828,8 +846,8 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
                 const int iv = 4 * half + r;
                 const bool valid = (iv < 7) && dyn;
                 const int i = (iv < 7) ? iv : 6;
-                const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
-                const double stn = p[I_STN + i], ztn = p[I_ZTN + i];
+                const double nu = rv[r][0], tt = rv[r][1], stp = rv[r][2], ztp = rv[r][3];
+                const double stn = rv[r][4], ztn = rv[r][5];
                 const double g1 = nu - tt, g2 = -nu - tt;
                 const double ip = rcp_pos(stp), in = rcp_pos(stn);      // slacks are positive: reciprocal + products
                 const double s1 = ztp * ip, s2 = ztn * in;
@@ -837,7 +855,7 @@ __device__ __noinline__ void newton_blocks(const Sat &s, SatData &sd, double *st
                 const double aa = s1 + s2, bb = s2 - s1, gt = w_nu - zh1 - zh2;
                 const double ia = rcp_pos(aa);
                 const double dd = 4.0 * s1 * s2 * ia;
-                const double ek = ns[NS_E + i];
+                const double ek = rv[r][6];
                 const double rho = (zh1 - zh2) - (bb * ia) * gt;
                 if (valid) {
                     nb[N_D + i] = dd;
@@ -982,11 +1000,14 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int nk = (K - k0 < 32) ? K - k0 : 32;
         const int n = nk * TR_N;
-        for (int e0 = 0; e0 < n; e0 += 256) {
-            double v[4];
-            int slot[4];
+        // (eight entries per lane and step: the 8 x 8 trajectory loads of a step are in flight together -- a round of 30 nodes is
+        //  one step, i.e. one memory round trip where four entries per step made two)
+        constexpr int CQ = 8;
+        for (int e0 = 0; e0 < n; e0 += 64 * CQ) {
+            double v[CQ];
+            int slot[CQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CQ; ++q) {
                 const int e = e0 + 64 * q + lane;
                 const int ec = (e < n) ? e : 0;
                 const int kl = ec / TR_N, i = ec - kl * TR_N;
@@ -998,21 +1019,37 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
                 v[q] = acc; slot[q] = (e < n) ? i * CMB_LD + kl : -1;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
+            for (int q = 0; q < CQ; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
         WG_SYNC();
-        for (int e = lane; e < DIR_N * 32; e += 64) {
+        // (the 24 x 32 entries of the round in 12 steps of 64 lanes: the three loads of ALL steps are issued first -- as a loop of
+        //  load, load, load, wait, store this was twelve dependent memory round trips per round of nodes)
+        constexpr int NQ = DIR_N * 32 / 64;
+        double curv[NQ], Dv[NQ], rv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q;
+            const int i = e >> 5, kl = e & 31, k = k0 + kl;
+            const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
+            const int dst = off * KP + (kl < nk ? k : k0);
+            const int kc = (kl < nk) ? k : k0, j = (i >= T_LAM) ? i - T_LAM : 0;
+            curv[q] = first ? it[dst] : dr[dst];
+            Dv[q] = s.nb[(size_t)kc * NB_N + N_D + j]; rv[q] = s.ch[(size_t)kc * CH_N + C_RHS + R_RHO + j];
+        }
+        CHUNK_END
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q;
             const int i = e >> 5, kl = e & 31, k = k0 + kl;
             const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
             const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
             const int dst = off * KP + (kl < nk ? k : k0);
             // starting value: -lam for the multiplier part of the first solve, the current direction when refining
-            const double cur = first ? it[dst] : dr[dst];
+            const double cur = curv[q];
             const double base = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
             // multiplier part: D_k nu_k + rho_k from the combined nu
-            const int kc = (kl < nk) ? k : k0, j = (i >= T_LAM) ? i - T_LAM : 0;
-            const double Dj = s.nb[(size_t)kc * NB_N + N_D + j], rj = s.ch[(size_t)kc * CH_N + C_RHS + R_RHO + j];
-            const double val = (i >= T_LAM) ? fma(Dj, stg[(T_NU + j) * CMB_LD + kl], rj) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
+            const int j = (i >= T_LAM) ? i - T_LAM : 0;
+            const double val = (i >= T_LAM) ? fma(Dv[q], stg[(T_NU + j) * CMB_LD + kl], rv[q]) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
             if (act) dr[dst] = base + val;
         }
         WG_SYNC();
@@ -1225,21 +1262,31 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
     for (int k = NODE_OF(lane); k < K; k += 32) {
         const auto p = s.itn(k), d = s.drn(k);
         const auto rb = s.rbn(k);
+        // ALL of the node's loads are issued together -- chunk 0's 29 and 8 for each of the four rounds (component i = 4*half + r of
+        // the eliminated t and of the two L1 slack pairs): one memory round trip per node instead of five.  (Round 4 had a
+        // scheduling barrier behind every round; under load this pass spent most of its time waiting for memory.)
+        double x[7], dx[7], u[3], du[3], bs[6], rv[4][8];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; dx[i] = d[I_X + i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; du[i] = d[I_U + i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
+        const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iv = 4 * half + r;
+            const int i = (iv < 7) ? iv : 6;
+            rv[r][0] = p[I_NU + i]; rv[r][1] = p[I_T + i]; rv[r][2] = p[I_STP + i]; rv[r][3] = p[I_ZTP + i];
+            rv[r][4] = p[I_STN + i]; rv[r][5] = p[I_ZTN + i]; rv[r][6] = d[I_NU + i]; rv[r][7] = d[I_LAM + i];
+        }
+        CHUNK_END
         // chunk 0 (both halves compute; the step limit and the finite flag are idempotent): the ball pairs
-        double x[7], dx[7];
         {
-            double u[3], du[3], bs[6];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) { x[i] = p[I_X + i]; dx[i] = d[I_X + i]; }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { u[i] = p[I_U + i]; du[i] = d[I_U + i]; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) bs[i] = p[I_SU + i];
 #pragma unroll
             for (int i = 0; i < 7; ++i) CHK(dx[i]);
 #pragma unroll
             for (int i = 0; i < 3; ++i) CHK(du[i]);
-            const double rb0 = rb[0], rb1 = rb[1], rb2 = rb[2];
             {
                 const PairDir q = pair_dir(bs[0], bs[1], u[0] * u[0] + u[1] * u[1] + u[2] * u[2] - b_u,
                                            2.0 * (u[0] * du[0] + u[1] * du[1] + u[2] * du[2]), mu);
@@ -1256,24 +1303,20 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
                 LIM(bs[4], q.ds); LIM(bs[5], q.dz);
             }
         }
-        CHUNK_END
-        // four rounds: component i = 4*half + r of the eliminated t and of the two L1 slack pairs
         {
             const bool dyn = (k <= K - 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int iv = 4 * half + r;
                 const bool valid = (iv < 7) && dyn;
-                const int i = (iv < 7) ? iv : 6;
-                const double nu = p[I_NU + i], tt = p[I_T + i], stp = p[I_STP + i], ztp = p[I_ZTP + i];
-                const double stn = p[I_STN + i], ztn = p[I_ZTN + i], dnu = d[I_NU + i], dlam = d[I_LAM + i];
+                const double nu = rv[r][0], tt = rv[r][1], stp = rv[r][2], ztp = rv[r][3];
+                const double stn = rv[r][4], ztn = rv[r][5], dnu = rv[r][6], dlam = rv[r][7];
                 const L1Dir q = l1_dir(nu, tt, stp, ztp, stn, ztn, dnu, mu, w_nu);
                 if (valid) {
                     CHK(dnu); CHK(dlam); CHK(q.dt);
                     LIM(stp, q.dstp); LIM(ztp, q.dztp);
                     LIM(stn, q.dstn); LIM(ztn, q.dztn);
                 }
-                CHUNK_END
             }
         }
         if (h0 && k == K - 1) {

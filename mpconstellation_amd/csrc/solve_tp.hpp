@@ -563,16 +563,31 @@ __device__ __noinline__ void tp_combine(const Sat &s_in, SatData &sd, TpData &tp
             for (int q = 0; q < 4; ++q) if (slot[q] >= 0) stg[slot[q]] = v[q];
         }
         WG_BARRIER();
-        for (int e = lane + 64 * wave; e < DIR_N * 32; e += 128) {
+        // (this wave's 6 of the round's 12 steps of 64 entries: the three loads of all of them first, as in combine_channels)
+        constexpr int NQ = DIR_N * 32 / 128;
+        double curv[NQ], Dv[NQ], rv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * wave + 128 * q;
+            const int i = e >> 5, kl = e & 31, k = k0 + kl;
+            const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
+            const int dst = off * KP + (kl < nk ? k : k0);
+            const int kc = (kl < nk) ? k : k0, jj = (i >= T_LAM) ? i - T_LAM : 0;
+            curv[q] = first ? it[dst] : dr[dst];
+            Dv[q] = s.nb[(size_t)kc * NB_N + N_D + jj]; rv[q] = s.ch[(size_t)kc * CH_N + C_RHS + R_RHO + jj];
+        }
+        CHUNK_END
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * wave + 128 * q;
             const int i = e >> 5, kl = e & 31, k = k0 + kl;
             const bool act = kl < nk && !(k == K - 1 && i >= T_NU);
             const int off = (i < T_U) ? I_X + i : (i < T_NU ? I_U + (i - T_U) : (i < T_LAM ? I_NU + (i - T_NU) : I_LAM + (i - T_LAM)));
             const int dst = off * KP + (kl < nk ? k : k0);
-            const double cur = first ? it[dst] : dr[dst];
+            const double cur = curv[q];
             const double base = first ? ((i >= T_LAM) ? -cur : 0.0) : cur;
-            const int kc = (kl < nk) ? k : k0, jj = (i >= T_LAM) ? i - T_LAM : 0;
-            const double Dj = s.nb[(size_t)kc * NB_N + N_D + jj], rj = s.ch[(size_t)kc * CH_N + C_RHS + R_RHO + jj];
-            const double val = (i >= T_LAM) ? fma(Dj, stg[(T_NU + jj) * CMB_LD + kl], rj) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
+            const int jj = (i >= T_LAM) ? i - T_LAM : 0;
+            const double val = (i >= T_LAM) ? fma(Dv[q], stg[(T_NU + jj) * CMB_LD + kl], rv[q]) : stg[(i < T_LAM ? i : 0) * CMB_LD + kl];
             if (act) dr[dst] = base + val;
         }
         WG_BARRIER();
