@@ -288,9 +288,14 @@ def also_workload(name, steps, warmup, local_rank, note, with_host=False, flags=
            "solver": {"converged": int(((st == 0) | (st == 7)).sum()), "of": S, "ipm_iterations_mean": float(it.mean()),
                       "ipm_iterations_max": int(it.max()), "kkt_max": float(kk.max())}, "note": note}
     if flags:
-        # (the committed counters are the default kernels': nothing is echoed for a launch that ran another one)
-        out["roofline"]["traffic"] = None; out["roofline"].pop("traffic_source", None); out["roofline"].pop("valu_f64", None)
-        out["roofline"]["kernel"] = "mpcx::solve_kernel_tp" if flags & 64 else out["roofline"].get("kernel")
+        # (the counters committed for the workload's own name are the default kernels'; the time-parallel kernel's are under
+        #  <name>_tp -- profiles/collect.sh -- and nothing is echoed for any other flag set)
+        out["roofline"].pop("valu_f64", None)
+        if flags == 64:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(name + "_tp", "solve_kernel_tp")
+            out["roofline"]["kernel"] = "mpcxtp::solve_kernel_tp"
+        else:
+            out["roofline"]["traffic"] = None; out["roofline"].pop("traffic_source", None)
     if n_scp > 1:
         out["scp_iterations_per_s"] = out["value"] * n_scp
     if with_host:

@@ -21,6 +21,9 @@
 #define WG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define MPCX_NS mpcx
+// (measured in round 5, profiles/r05/streaming_phases_ab.txt: a fence + wave barrier here instead of __syncthreads() -- which for
+//  this one-wave workgroup is "s_waitcnt vmcnt(0) lgkmcnt(0)", a drain of every outstanding store at each phase boundary --
+//  gives the same bits and the same time, 5.32 against 5.32 ms at S4096_K30: the second wave of the SIMD hides the drains)
 #define WG_SYNC() __syncthreads()
 #endif
 #define WG_BARRIER() __syncthreads()

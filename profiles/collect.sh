@@ -5,7 +5,7 @@
 #   3. two passes of 8 SQ counters each: instruction mix / fp64 operation counts, and wait / active cycles
 # Raw output goes to gpurun_out/prof/<round>/ ; profiles/summarize.py turns it into the committed summaries.
 set -e
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof/$ROUND
 mkdir -p "$OUT"
@@ -30,4 +30,13 @@ for W in S4096_K30 S64_K30 S4096_K100_scp2; do
       python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --no-also --no-cpu-baseline > "$OUT/$W.$C.log" 2>&1
     echo "pmc $C $W done"
   done
+done
+# the time-parallel kernel's counters (round-4 verdict: its bench line had no traffic figure).  Last, each pass under its own
+# time limit: the profiled process of a cooperative launch has been seen to fault in its exit handlers under rocprofv3.
+for C in FETCH_SIZE WRITE_SIZE SQ_A SQ_B; do
+  case $C in SQ_A) LIST=$SQ_A;; SQ_B) LIST=$SQ_B;; *) LIST=$C;; esac
+  timeout -k 10 180 rocprofv3 --kernel-trace --pmc $LIST --output-format csv -d "$OUT/S64_K30_tp/$C" -o pmc -- \
+    python3 "$REPO/bench.py" --workload S64_K30 --solve-flags 64 --steps 1 --warmup 1 --no-also --no-cpu-baseline > "$OUT/S64_K30_tp.$C.log" 2>&1 \
+    || echo "(pmc $C S64_K30_tp: profiled process ended with an error after the run -- see the log)"
+  echo "pmc $C S64_K30_tp done"
 done
