@@ -113,7 +113,7 @@ class OptimalController(Controller):
     opt_trajectory, sequence_controller."""
 
     def __init__(self, sats=[], objective=None, base_res=100, tf_horizon=1, tf_interval=1, plot_inter=True,
-                 opt_verbose=True, r_des=1.5, strict=False, device=0, time_parallel=False):
+                 opt_verbose=True, r_des=1.5, strict=False, device=0, time_parallel=None):
         super().__init__(sats)
         from .satellite_scale import SatelliteScale
         self.u = np.zeros((3, 1))
@@ -132,10 +132,14 @@ class OptimalController(Controller):
         # instead of flying an unconverged plan.
         self.strict = strict
         self.device = device
-        # the plan's solves on the time-parallel kernel (include/mpcx.h, MPCX_SOLVE_TIME_PARALLEL: the horizon in four segments
-        # side by side -- this controller plans for ONE satellite, the case that kernel is for; same iterations, not the bits
-        # the satellite gets as part of a large batch, hence not the default)
-        self.time_parallel = time_parallel
+        # The plan's solves run on the time-parallel kernel (include/mpcx.h, MPCX_SOLVE_TIME_PARALLEL: the horizon in four segments
+        # side by side) BY DEFAULT since round 5: this controller plans for ONE satellite (control.py:162), the case that kernel
+        # is for -- 1.19 against 1.39 ms per solve at 30 nodes, 1.33 / 1.86 at 60 -- and the kernel is pinned directly against the
+        # oracle and the independent scipy solutions (tests/test_time_parallel_oracle_gpu.py: 4e-15 ... 1e-12 on the 30-node
+        # fixtures and OptimalController's stiff option set).  It needs the device to itself while it runs: a solve whose
+        # workgroups could not all become resident reports MPCX_ST_TIMEOUT and the update is repeated on the default kernels
+        # (ConstellationMPC.update).  time_parallel=False: the default kernels, whose bits do not depend on the batch size.
+        self.time_parallel = True if time_parallel is None else bool(time_parallel)
 
     def update(self):
         from .constellation_mpc import ConstellationMPC

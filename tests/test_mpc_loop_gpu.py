@@ -186,7 +186,7 @@ def test_constellation_mpc_equals_single_satellite_loops():
     single = []
     for sat in make():
         c = OptimalController(sats=[sat], base_res=base_res, tf_horizon=tf, tf_interval=tf / nseg, plot_inter=False,
-                              opt_verbose=False, r_des=r_des)
+                              opt_verbose=False, r_des=r_des, time_parallel=False)      # (the default kernels: one set of bits per satellite)
         sim = Simulator(sats=[sat], controller=c, scale=SatelliteScale(sat=sat), base_res=sim_res, verbose=False)
         sim.run_segments(tf=tf, num_segments=nseg)
         single.append((sim.sim_data[sat.id], sim.sim_time[sat.id], c.opt_trajectory, sat.get_state_vector().copy(), c.last_status))

@@ -110,3 +110,28 @@ def test_optimal_controller_on_the_time_parallel_kernel():
         assert all(code in (0, 7) for code in c.last_status)
         plans.append((c.opt_trajectory.copy(), c.sequence_controller.u.copy(), c.sequence_controller.end_tau))
     assert np.abs(plans[0][0] - plans[1][0]).max() < 1e-6 and np.abs(plans[0][1] - plans[1][1]).max() < 1e-6 and abs(plans[0][2] - plans[1][2]) < 1e-8
+    # ... and it is the controller's default (round 5): one satellite is the case the kernel is for
+    sat = Satellite(st[:3].copy(), st[3:6].copy(), float(st[6]))
+    c = OptimalController([sat], base_res=30, tf_horizon=2, tf_interval=1, r_des=1.5, opt_verbose=False, plot_inter=False)
+    assert c.time_parallel is True
+    c.update()
+    assert np.array_equal(c.opt_trajectory, plans[1][0])
+
+
+def test_timed_out_time_parallel_update_is_repeated_on_the_default_kernels():
+    """MPCX_ST_TIMEOUT (a workgroup of a time-parallel solve did not become resident in time: forced here with the library's
+    self-test flag) is not a failed plan: ConstellationMPC.update warns and repeats the update on the default kernels."""
+    import warnings
+    from mpconstellation_amd import Satellite, ConstellationMPC, _ffi
+    from mpconstellation_amd.constellation import constellation_states
+    st = constellation_states(3)
+    make = lambda: [Satellite(s[:3].copy(), s[3:6].copy(), float(s[6])) for s in st]
+    kw = dict(base_res=30, tf_horizon=1, tf_interval=1, r_des=1.2, sim_base_res=40)
+    ref = ConstellationMPC(make(), **kw); ref.update()
+    b = ConstellationMPC(make(), time_parallel=True, **kw)
+    b.solver_flags |= _ffi.SOLVE_TP_SELFTEST_DEAD
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        b.update()
+    assert any("timed out" in str(w.message) for w in wl)
+    assert (b.last_status == 0).all() and all(np.array_equal(p, q) for p, q in zip(ref.plan_x, b.plan_x))
