@@ -122,7 +122,8 @@ extern "C" void *mpcx_host_alloc(mpcx_ctx *ctx, size_t bytes)
     if (!ctx || !bytes) return nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess)        // (portable: a multi-device call's result set is the DMA target of every device) { ctx_fail(ctx, MPCX_E_NOMEM, "page-locked allocation failed"); return nullptr; }
+    // (portable: a multi-device call's result set is the DMA target of every device)
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { ctx_fail(ctx, MPCX_E_NOMEM, "page-locked allocation failed"); return nullptr; }
     return p;
 }
 
