@@ -391,6 +391,10 @@ int mpcx_scp_iteration_batch_ragged(mpcx_ctx *ctx, int S, int K, const int32_t *
  * Segment flight (y_sim != NULL): from y0 over sim_tf under the truth model sim_flags (MPCX_FLAG_DRAG | MPCX_FLAG_J2) with
  * SequenceController(u_opt, tf_u, tf_sim = sim_interval) (end_tau = tf_u / sim_interval, control.py:102,217),
  * y_sim [S][7][sim_n_eval] = sol.y at linspace(0, 1, sim_n_eval), sim_status [S].
+ * Environment (measurement switch, read per call): MPCX_UPDATE_SPLIT=1 runs a batch of 2048 or more satellites as two chains --
+ * its halves, each on its own stream, so that one half's rollouts run under the other half's solve -- and =2 also delays the
+ * second chain to the first's first solve; same bits either way; measured no faster than one chain, hence
+ * not the default.
  */
 int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, double base_res, const double *y0, const double *tf0,
                           const double *consts, const double *r_des, double ref_thrust, double prop_max_step, int disc_flags,
