@@ -409,7 +409,6 @@ extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, dou
     const char *split_env = getenv("MPCX_UPDATE_SPLIT");            // (read per call: a test switches it inside one process)
     const int split_mode = split_env ? atoi(split_env) : 0;
     const bool split = split_mode > 0 && S >= 2 * kTwoWaveMax && !(opts->flags & MPCX_SOLVE_TIME_PARALLEL);
-    const int nhalf = split ? 2 : 1;
     const int cnt[2] = {split ? (S + 1) / 2 : S, split ? S / 2 : 0}, fst[2] = {0, cnt[0]};
     size_t ws_bytes[2] = {mpcx_mpc_step_workspace_bytes_ctx(ctx, cnt[0], K), split ? mpcx_mpc_step_workspace_bytes_ctx(ctx, cnt[1], K) : 0};
     ws_bytes[0] = (ws_bytes[0] + 255) & ~(size_t)255;
@@ -506,10 +505,12 @@ extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, dou
     };
     int rc = MPCX_OK;
     rc = chain(fst[0], cnt[0], ctx->stream, wsb, 0);
+    ctx->cur_lane = 0; ctx->nreg_first = 0; ctx->nreg_total = 0;          // (also when the chain left early on an error)
     if (rc == MPCX_OK && split) {
         // (mode 2: the second chain starts when the first has reached its first solve -- its rollout and discretisation then run UNDER it)
         if (split_mode == 2) MPCX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_stagger, 0));
         rc = chain(fst[1], cnt[1], ctx->stream2, wsb + ws_bytes[0], 1);
+        ctx->cur_lane = 0; ctx->nreg_first = 0; ctx->nreg_total = 0;
     }
     if (split) {
         // join: the downloads on the first stream follow everything of the second (also on an error path: nothing of this call

@@ -213,8 +213,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         const double rn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         const auto rb = s.rbn(k);
         for (int i = 0; i < 3; ++i) rb[i] = x[i] / rn;           // optimizer.py:129-130
-        const auto p = s.itn(k), d = s.drn(k);
-        for (int i = 0; i < IT_N; ++i) { p[i] = 0.0; d[i] = 0.0; }
+        const auto p = s.itn(k);
+        // (only the rows of the iterate that nothing below writes are zeroed -- nu, lambda, and t of the terminal node -- and the
+        //  direction not at all: until the first solve has written it, it is read only where a step length of 0 masks it
+        //  (trial_value).  Rounds 1-4 stored all 2 x 66 rows of zeros here: 130 of the start-up's 190 store instructions)
+        for (int i = 0; i < 7; ++i) { p[I_NU + i] = 0.0; p[I_LAM + i] = 0.0; }
+        if (k == K - 1) for (int i = 0; i < 7; ++i) p[I_T + i] = 0.0;
         for (int i = 0; i < 7; ++i) p[I_X + i] = x[i];
         for (int i = 0; i < 3; ++i) p[I_U + i] = u[i];
         // slacks pushed into the interior (bound_push); the multipliers follow below, once the start value of mu is known
@@ -284,6 +288,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     // follows ipopt's monotone Fiacco-McCormick rule from then on.  kFbN = 8: benchmark problems at K = 100 take up to seven
     // short regularised steps in a row and recover by themselves in 16 / 25 iterations (the monotone rule: 32 / 41).
     bool mono = false;
+    bool refined_prev = false;      // the last iteration's unregularised solve ran refinement passes
     int n_small = 0;
     double E0 = 0.0;
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
@@ -327,7 +332,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         // the last value that worked (1e-4 the first time), growing by 8 (by 100 until some value has worked), up to 1e40
         while (!have_dir && delta_w <= kDwMax) {
             PT_BEGIN
-            newton_blocks<false>(s, sd, (double *)&w, mu, delta_w, lane);
+            // (an iteration that follows a refining one almost always refines too -- the barrier weights grow as mu falls -- and then
+            //  needs the Newton scalars kept: newton_blocks<true> at once, instead of <false> now and <true> again below.  Same
+            //  records either way: <true> is <false> plus the stores of the scalars)
+            const bool ns_kept = refined_prev && delta_w == 0.0;
+            if (ns_kept) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);
+            else newton_blocks<false>(s, sd, (double *)&w, mu, delta_w, lane);
             PT_END(1)
             double gtf_rhs, rvt_rhs, gex[NTERM];
             first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
@@ -350,7 +360,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 gr_clear(gr); gr[GR_SUM] = twmax;
                 grid_reduce(g, gr, lane);                         // every satellite refines, or none
                 const int passes = 1 + ((delta_w == 0.0 && gr[GR_SUM] > kRefineTw) ? o.n_refine : 0);
-                if (passes > 1) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);
+                if (passes > 1 && !ns_kept) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);
+                refined_prev = passes > 1;
                 bool okl = riccati_factor(s, sd, w, lane, true, passes > 1);     // (a local breakdown is reported through the border's reduction)
                 bool ok = true;
                 for (int pass = 0; pass < passes && ok; ++pass) {
@@ -393,7 +404,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             double twmax = sd.sigmax;
             for (int t = 0; t < NTERM; ++t) twmax = fmax(twmax, sd.tw[t]);
             const int passes = 1 + ((delta_w == 0.0 && twmax > kRefineTw) ? o.n_refine : 0);
-            if (passes > 1) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);      // (the scalars reduced_residual reads)
+            if (passes > 1 && !ns_kept) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);      // (the scalars reduced_residual reads)
+            if (delta_w == 0.0) refined_prev = passes > 1;
             PT_BEGIN
 #ifdef MPCX_TP
             bool ok = tp_cmd_factor(s, sd, g_tp, lane, passes > 1);       // every segment's factorisation + fused backward sweeps, side by side

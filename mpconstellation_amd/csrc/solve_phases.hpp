@@ -1082,9 +1082,13 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
     // terminal-node completion terms (the rank-1 terms and the AL shift): from the direction at node K-1, known up front
     double gin[NTERM], rvt_x;
     {
-        const auto dK = s.drn(K - 1);
+        const auto dKc = s.drn(K - 1);
+        double dK[7];              // the terminal node's direction, loaded once (the loops below re-read it per term)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dK[i] = dKc[I_X + i];
         double av = 0.0;
-        for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[I_X + i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) av += sd.avt[i] * dK[i];
         rvt_rhs = -sd.cv - av;
         rvt_x = rvt_rhs;            // what the x_K row's shift -gam * rvt_x * a_vt uses (the same value for the equality)
         if (sd.linvt) {
@@ -1096,7 +1100,8 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
         }
         for (int t = 0; t < NTERM; ++t) {   // coefficient of a_t in the x_K row: gh share + win a.dx + zeta
             double adx = 0.0;
-            for (int i = 0; i < 7; ++i) adx += sd.ta[t][i] * dK[I_X + i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) adx += sd.ta[t][i] * dK[i];
             const double wex = sd.tw[t] - sd.twin[t];
             const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
             const bool on = wex > 0.0;
@@ -1108,41 +1113,62 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
       const int k = k0 + lane;
       double *rec = stg + lane * RHS_LD;
       if (k < K) {
+        // Four batches of loads per node (round 5): the node's ~230 loads were issued one at a time, each waited for before the
+        // next (the function holds its 248 registers' worth of live values and the scheduler sank every load to its use): ~150
+        // dependent memory round trips per call -- the refinement passes of the stiff-window solves waited here longer than a
+        // factorisation takes.  Loads from clamped (always valid) addresses, selected afterwards; every sum in its old order.
         cwf64 *nb = s.nb + (size_t)k * NB_N;
         const auto ns = s.nsn(k);
         const auto p = s.itn(k), d = s.drn(k);
-        double lt[7], ltm[7];     // total multipliers lam + dlam of rows k and k-1
+        const bool hp = (k >= 1), dyn = (k <= K - 2), term = (k == K - 1);
+        const auto pm = p.node(hp ? -1 : 0), dm = d.node(hp ? -1 : 0), dn = d.node(dyn ? 1 : 0);
+        // ---- batch 1: multipliers of rows k and k-1 ----
+        double lt[7], ltm[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            lt[i] = (k <= K - 2) ? p[I_LAM + i] + d[I_LAM + i] : 0.0;
-            ltm[i] = (k >= 1) ? p.node(-1)[I_LAM + i] + d.node(-1)[I_LAM + i] : 0.0;
+            const double a0 = p[I_LAM + i], a1 = d[I_LAM + i], b0 = pm[I_LAM + i], b1 = dm[I_LAM + i];
+            lt[i] = dyn ? a0 + a1 : 0.0;        // total multipliers lam + dlam of rows k and k-1
+            ltm[i] = hp ? b0 + b1 : 0.0;
         }
+        CHUNK_END
+        // ---- batch 2: the node's direction, Newton scalars and record ----
+        double dx[7], du[3], dnu[7], nsgx[7], nsgu[3], w3[9], wu[9], sx[SX_N];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { dx[i] = d[I_X + i]; dnu[i] = d[I_NU + i]; nsgx[i] = ns[NS_GX + i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { du[i] = d[I_U + i]; nsgu[i] = ns[NS_GU + i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { w3[i] = nb[N_W3 + i]; wu[i] = nb[N_WU + i]; }
+#pragma unroll
+        for (int i = 0; i < SX_N; ++i) sx[i] = nb[N_SX + i];
+        const double dg = nb[N_DIAG];
+        CHUNK_END
         double gx[7], gu[3];
-        if (k >= 1) {
-            if (k == K - 1) {
+        if (hp) {
+            if (term) {
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     double acc = sd.gxKsoft[i] + ltm[i];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) acc += sd.WxKsoft[i * 7 + j] * d[I_X + j];
+                    for (int j = 0; j < 7; ++j) acc += sd.WxKsoft[i * 7 + j] * dx[j];
                     gx[i] = acc;
                 }
             } else {
                 // stage Hessian in its compact form: the 3x3 position block, the common diagonal value elsewhere (the
                 // entries left out are exact zeros: same sums as with the full matrix)
-                const double dg = nb[N_DIAG];
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
-                    double acc = ns[NS_GX + i] + ltm[i];
+                    double acc = nsgx[i] + ltm[i];
                     if (i < 3) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) acc += nb[N_W3 + i * 3 + j] * d[I_X + j];
-                    } else acc += dg * d[I_X + i];
+                        for (int j = 0; j < 3; ++j) acc += w3[i * 3 + j] * dx[j];
+                    } else acc += dg * dx[i];
                     gx[i] = acc;
                 }
             }
-            if (k == K - 1) {
+            if (term) {
                 const double lvt = s.itg[G_LVT] + s.drg[G_LVT];
+#pragma unroll
                 for (int i = 0; i < 7; ++i) gx[i] += sd.avt[i] * lvt;
             }
         } else {
@@ -1151,68 +1177,119 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double acc = ns[NS_GU + i];
+            double acc = nsgu[i];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += nb[N_WU + i * 3 + j] * d[I_U + j];
+            for (int j = 0; j < 3; ++j) acc += wu[i * 3 + j] * du[j];
             gu[i] = acc;
         }
         {
             // the stiff stage terms' excess weight, which the blocks N_W3 / N_WU do not carry (newton_blocks)
-            const double ex_x = nb[N_SX + SX_EX], ex_u = nb[N_SX + SX_EU];
-            const double a0 = nb[N_SX + SX_A], a1 = nb[N_SX + SX_A + 1], a2 = nb[N_SX + SX_A + 2];
-            const double c0 = nb[N_SX + SX_CU], c1 = nb[N_SX + SX_CU + 1], c2 = nb[N_SX + SX_CU + 2];
-            const double px = ex_x * (a0 * d[I_X] + a1 * d[I_X + 1] + a2 * d[I_X + 2]);
-            const double pu = ex_u * (c0 * d[I_U] + c1 * d[I_U + 1] + c2 * d[I_U + 2]);
-            if (k >= 1 && k <= K - 2) { gx[0] += px * a0; gx[1] += px * a1; gx[2] += px * a2; }
+            const double ex_x = sx[SX_EX], ex_u = sx[SX_EU];
+            const double a0 = sx[SX_A], a1 = sx[SX_A + 1], a2 = sx[SX_A + 2];
+            const double c0 = sx[SX_CU], c1 = sx[SX_CU + 1], c2 = sx[SX_CU + 2];
+            const double px = ex_x * (a0 * dx[0] + a1 * dx[1] + a2 * dx[2]);
+            const double pu = ex_u * (c0 * du[0] + c1 * du[1] + c2 * du[2]);
+            if (hp && dyn) { gx[0] += px * a0; gx[1] += px * a1; gx[2] += px * a2; }
             gu[0] += pu * c0; gu[1] += pu * c1; gu[2] += pu * c2;
         }
-        if (k >= 1) {
-            const auto Bp = s.Bpt(k - 1);
+        // ---- batch 3: B_kp of the interval before, Sigma, the next node's direction ----
+        double sg[7], dnx[7], dnuu[3];
+        {
+            double bm[21];
+            const auto Bm = s.Bpt(hp ? k - 1 : 0), Sg = s.Sigt(dyn ? k : 0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double acc = 0.0;
+            for (int e = 0; e < 21; ++e) bm[e] = Bm[e];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) acc += Bp[i * 3 + j] * ltm[i];
-                gu[j] -= acc;
-            }
-        }
-        if (k <= K - 2) {
-            const auto A = s.At(k), Bn = s.Bnt(k), Bp = s.Bpt(k), Sg = s.Sigt(k);
-            const auto dn = d.node(1);
-            if (k >= 1) {
+            for (int i = 0; i < 7; ++i) { sg[i] = Sg[i]; dnx[i] = dn[I_X + i]; }
 #pragma unroll
-                for (int j = 0; j < 7; ++j) {
+            for (int i = 0; i < 3; ++i) dnuu[i] = dn[I_U + i];
+            CHUNK_END
+            if (hp) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) acc += A[i * 7 + j] * lt[i];
-                    gx[j] -= acc;
+                    for (int i = 0; i < 7; ++i) acc += bm[i * 3 + j] * ltm[i];
+                    gu[j] -= acc;
                 }
             }
+        }
+        // ---- batches 4, 5: A in two halves of rows (the column sums A^T lt run over the rows in order, across the halves) ----
+        double aff[7], atl[7];      // aff: dn_x - Sigma dtf - dnu - A dx (- Bn du - Bp dn_u below); atl: A^T lt
+#pragma unroll
+        for (int j = 0; j < 7; ++j) atl[j] = 0.0;
+        {
+            const auto A = s.At(dyn ? k : 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = h ? 4 : 0, r1 = h ? 7 : 4;
+                double am[28];
+#pragma unroll
+                for (int i = r0; i < r1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) am[(i - r0) * 7 + j] = A[i * 7 + j];
+                CHUNK_END
+#pragma unroll
+                for (int i = r0; i < r1; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) atl[j] += am[(i - r0) * 7 + j] * lt[i];
+                    double acc = dnx[i] - sg[i] * dtf - dnu[i];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc -= am[(i - r0) * 7 + j] * dx[j];
+                    aff[i] = acc;
+                }
+            }
+        }
+        if (dyn && hp) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) gx[j] -= atl[j];
+        }
+        // ---- batch 6: B_kn, B_kp of this interval ----
+        {
+            double bn[21], bp[21];
+            const auto Bn = s.Bnt(dyn ? k : 0), Bp = s.Bpt(dyn ? k : 0);
+#pragma unroll
+            for (int e = 0; e < 21; ++e) { bn[e] = Bn[e]; bp[e] = Bp[e]; }
+            CHUNK_END
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) acc += Bn[i * 3 + j] * lt[i];
-                gu[j] -= acc;
+                for (int i = 0; i < 7; ++i) acc += bn[i * 3 + j] * lt[i];
+                if (dyn) gu[j] -= acc;
             }
-            double sl = 0.0;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                rec[R_RHO + i] = ns[NS_RHO + i] + ns[NS_D + i] * d[I_NU + i] - lt[i];
-                double acc = dn[I_X + i] - Sg[i] * dtf - d[I_NU + i];
+                double acc = aff[i];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc -= A[i * 7 + j] * d[I_X + j];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc -= Bn[i * 3 + j] * d[I_U + j] + Bp[i * 3 + j] * dn[I_U + j];
-                rec[R_AFF + i] = -ns[NS_E + i] - acc;
-                sl += Sg[i] * lt[i];
+                for (int j = 0; j < 3; ++j) acc -= bn[i * 3 + j] * du[j] + bp[i * 3 + j] * dnuu[j];
+                aff[i] = acc;
             }
-            gtf_part -= sl;
         }
-        if (k == K - 1) {
+        // ---- batch 7: the node's rho, D, e ----
+        {
+            double rho[7], dd[7], ee[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { rho[i] = ns[NS_RHO + i]; dd[i] = ns[NS_D + i]; ee[i] = ns[NS_E + i]; }
+            CHUNK_END
+            if (dyn) {
+                double sl = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    rec[R_RHO + i] = rho[i] + dd[i] * dnu[i] - lt[i];
+                    rec[R_AFF + i] = -ee[i] - aff[i];
+                    sl += sg[i] * lt[i];
+                }
+                gtf_part -= sl;
+            }
+        }
+        if (term) {
             // terminal-node completion: the rank-1 terms and the AL shift; its rho / aff slots are zero as in the first record
-            for (int t = 0; t < NTERM; ++t)
+            for (int t = 0; t < NTERM; ++t) {
+#pragma unroll
                 for (int i = 0; i < 7; ++i) gx[i] += gin[t] * sd.ta[t][i];
+            }
+#pragma unroll
             for (int i = 0; i < 7; ++i) gx[i] -= sd.gam * rvt_x * sd.avt[i];
 #pragma unroll
             for (int i = 0; i < 7; ++i) { rec[R_RHO + i] = 0.0; rec[R_AFF + i] = 0.0; }

@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=gpurun_out/r5j; mkdir -p $OUT
+timeout -k 10 1100 python -m pytest tests -m gpu -q -x --durations=8 > $OUT/pytest.log 2>&1; rc=$?
+tail -16 $OUT/pytest.log
+if [ $rc -ge 124 ]; then echo "pytest killed ($rc)"; exit $rc; fi
+timeout -k 10 900 python bench.py > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+head -c 1800 $OUT/bench.log; echo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /proc/self/cgroup | head -3
