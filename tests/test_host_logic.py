@@ -309,3 +309,33 @@ def test_plot_normalized_thrust_and_verbose_devices(golden_dir):
     assert np.array_equal(ax.lines[1].get_ydata(), rtn[1])
     with pytest.raises(ValueError):
         ConstellationMPC([hubble(), hubble()], verbose=True, devices=[0, 1])
+
+
+def test_bench_line_carries_its_summary_ahead_of_the_lists():
+    """bench.py's JSON line: the contract's keys first, then ONE short `summary` object with the secondary headline numbers
+    (value_pcie, also.*, closed_loop.*, the multi-device host overhead), then roofline and cpu_baseline, then everything else --
+    so that a reader of a truncated tail still finds them (round-4 verdict, bench item)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    out = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1.0, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "S4096_K30"},
+           "host_pointer_entry": {"calls_ms": {"timed": [7.0] * 20}}, "value_pcie": 5.6e5,
+           "roofline": {"kernel_ms": 5.33, "frac": 0.0053, "traffic": 1.3e10},
+           "also": {"S64_K30": {"value": 46000.0, "roofline": {"kernel_ms": 1.31}},
+                    "api_devices8": {"value": 6.7e5, "api_devices8_host_overhead_ms": 0.42}},
+           "closed_loop": {"S4096": {"value": 96800.0}}, "cpu_baseline": {"value": 197.0, "all_cores": {"value": None}}}
+    o = bench.with_summary(out)
+    keys = list(o)
+    assert keys[:len(bench.CONTRACT_KEYS)] == list(bench.CONTRACT_KEYS) and keys[len(bench.CONTRACT_KEYS)] == "summary"
+    assert keys.index("roofline") < keys.index("host_pointer_entry") and keys.index("cpu_baseline") < keys.index("also")
+    s = o["summary"]
+    assert s["value_pcie"] == 560000.0 and s["also.S64_K30"] == 46000.0 and s["also.S64_K30.kernel_ms"] == 1.31
+    assert s["also.api_devices8_host_overhead_ms"] == 0.42 and s["closed_loop.S4096"] == 96800.0 and s["cpu_baseline"] == 197.0
+    assert "cpu_baseline_all_cores" not in s                      # (not run: nothing to show)
+    line = json.dumps(o)
+    assert line.index('"summary"') < 700 and set(out) <= set(o)   # within the first few hundred characters; nothing dropped
+    # the CPU quota of the process's cgroup: a number of CPUs or None, never an exception
+    q = bench.cpu_quota()
+    assert q is None or q > 0
