@@ -77,7 +77,7 @@ static inline void merge_status_kernel_launch(int S, const int32_t *dstat, int32
 // counts are known).  A workgroup keeps ONE workspace slot for all its satellites: the solver's working set is
 // slots x 206 KB whatever the batch size (8192 satellites: 0.44 GB instead of 1.8 GB), and a slot's lines are rewritten
 // by the next satellite while they are still cached instead of being written back as dead data.
-__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a)
+__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) MPCX_NO_TAIL void solve_kernel(SolveArgs a)
 {
     SatData &sd = g_sd;
     Scratch &w = g_w;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_kernel(SolveArgs a
 }
 
 // Shared final time: one workgroup per satellite, all resident (cooperative launch), one lock-step iteration.
-__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) void solve_shared_kernel(SolveArgs a)
+__global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) MPCX_NO_TAIL void solve_shared_kernel(SolveArgs a)
 {
     SatData &sd = g_sd;
     Scratch &w = g_w;

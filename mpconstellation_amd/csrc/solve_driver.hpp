@@ -28,6 +28,11 @@ namespace MPCX_NS {
 #ifndef MPCX_TP          // (the time-parallel build defines them ahead of its own functions: solve_tp.hpp)
 __shared__ SatData g_sd;
 __shared__ Scratch g_w;
+// ... and the view of the satellite's problem and workspace (round 5): until then a struct on the driver's stack that every phase
+// function received by reference -- its ~50 dwords were read back with flat loads (10-15 per call, some 135 per iteration) and
+// the driver's pointer swaps went to scratch.  In LDS, at one address in every kernel, the phase functions address it with
+// compile-time offsets like the other two objects.
+__shared__ Sat g_s;
 #endif
 
 // View of satellite `sat`'s problem and of workspace slot `slot` (K: its node count, Kmax: the row length of the arrays)
@@ -135,7 +140,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 {
     PT_DECL
     const int Kmax = a.K;
-    const int K = a.Ks ? a.Ks[sat] : Kmax;        // (wave-uniform: one satellite per workgroup)
+    const int K = uni(a.Ks ? a.Ks[sat] : Kmax);   // (wave-uniform: one satellite per workgroup)
     if (K < 3 || K > Kmax) {                      // ragged batch with a node count the solver cannot take
         // defined results all the same (as on the INFEASIBLE exit): the reference rows back, no virtual control, tf_bar
         cgf64 *xb = (cgf64 *)a.xbar + (size_t)sat * 7 * Kmax, *ub = (cgf64 *)a.ubar + (size_t)sat * 3 * Kmax;
@@ -148,8 +153,10 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         }
         return;
     }
-    Sat s = sat_view(a, sat, slot, K, Kmax);
-    const int KP = s.KP;
+    { const Sat sv = sat_view(a, sat, slot, K, Kmax); if (lane == 0) g_s = sv; }
+    WG_SYNC();
+    Sat &s = g_s;                                 // (one copy per workgroup, in LDS: see g_s)
+    const int KP = uni(s.KP);
     const SolveOpts &o = a.o;
 
     // ---- problem constants (constraint terms) and the initial iterate ----
@@ -232,7 +239,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     // A clean start ("Solver algorithm"): the reference strictly inside its stage constraints and the tf range
     // begins at mu = kMuInitClean and lets mu fall superlinearly; any other start, a fixed-tf solve and the shared-tf launch
     // (one mu for all its satellites) keep kMuInit and the kSigma rule.
-    bool clean = !SHARED && !sd.fixed_tf && !__any(pushed);      // (fixed-tf solves feed a host root search with their g_tf: left as they were)
+    int &clean = sd.dv.clean;
+    clean = !SHARED && !sd.fixed_tf && !__any(pushed);      // (fixed-tf solves feed a host root search with their g_tf: left as they were)
     if (clean) {
         const double tf = sd.tfbar;
         if (-(-tf - sd.b_tf[0]) < kBoundPush * fmax(1.0, fabs(sd.b_tf[0])) || -(tf - sd.b_tf[1]) < kBoundPush * fmax(1.0, fabs(sd.b_tf[1])))
@@ -244,7 +252,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #ifdef MPCX_NO_CLEAN_START      // measurement builds only (profiles/tools): every start treated as it was before round 3
     clean = false;
 #endif
-    const double mu0 = clean ? kMuInitClean : kMuInit;
+    const double mu0 = uni(clean ? kMuInitClean : kMuInit);
     for (int k = lane; k < K; k += 64) {
         const auto p = s.itn(k);
         // L1 slack pairs start dual feasible and centred: z+ = z- = w_nu/2, s = t = mu/z
@@ -270,10 +278,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     }
     WG_SYNC();
 
-    double mu = mu0, dw_last = 0.0;            // mu: this iteration's complementarity target
+    // (the loop state lives in LDS, SatData::dv: see there)
+    double &mu = sd.dv.mu, &dw_last = sd.dv.dw_last;            // mu: this iteration's complementarity target
+    mu = mu0; dw_last = 0.0;
     // (shared tf: the counts of the whole launch -- S satellites without their own tf rows plus tf's two range inequalities)
-    const int nzc = SHARED ? a.S * n_ineq(K, sd.nT, 1) + 2 : n_ineq(K, sd.nT, sd.fixed_tf);
-    const int nlc = (SHARED ? a.S : 1) * (7 * (K - 1) + (sd.nT == 6 ? 1 : 0));
+    const int nzc = uni(SHARED ? a.S * n_ineq(K, sd.nT, 1) + 2 : n_ineq(K, sd.nT, sd.fixed_tf));
+    const int nlc = uni((SHARED ? a.S : 1) * (7 * (K - 1) + (sd.nT == 6 ? 1 : 0)));
     // shared tf: slacks / multipliers of 0 <= tf <= tf_max, their trial values, and the launch's part of the tf row
     double gs[2] = {0.0, 0.0}, gz[2] = {0.0, 0.0}, gst[2] = {0.0, 0.0}, gzt[2] = {0.0, 0.0}, gds[2] = {0.0, 0.0}, gdz[2] = {0.0, 0.0};
     if (SHARED) {
@@ -282,26 +292,27 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         gs[1] = fmax(-(tf - sd.b_tf[1]), kBoundPush * fmax(1.0, fabs(sd.b_tf[1]))); gz[1] = kMuInit / gs[1];
     }
     const double b_tf2[2] = {sd.b_tf[0], sd.b_tf[1]};
-    int n_acc = 0, status = MPCX_ST_MAXITER, it_count = 0, n_reg = 0, first_reg = -1;
+    int &n_acc = sd.dv.n_acc, &status = sd.dv.status, &it_count = sd.dv.it_count, &n_reg = sd.dv.n_reg, &first_reg = sd.dv.first_reg;
+    n_acc = 0; status = MPCX_ST_MAXITER; it_count = 0; n_reg = 0; first_reg = -1;
     // second safeguard of the adaptive barrier rule (the first is the kMuErr bound below): after kFbN consecutive accepted
     // steps shorter than kFbAlpha -- the iterate is jammed against its bounds -- mu is lifted to kFbBoost * mean(s z) and
     // follows ipopt's monotone Fiacco-McCormick rule from then on.  kFbN = 8: benchmark problems at K = 100 take up to seven
     // short regularised steps in a row and recover by themselves in 16 / 25 iterations (the monotone rule: 32 / 41).
-    bool mono = false;
-    bool refined_prev = false;      // the last iteration's unregularised solve ran refinement passes
-    int n_small = 0;
-    double E0 = 0.0;
+    int &mono = sd.dv.mono, &refined_prev = sd.dv.refined_prev, &n_small = sd.dv.n_small;      // refined_prev: the last iteration's unregularised solve ran refinement passes
+    double &E0 = sd.dv.E0;
+    mono = 0; refined_prev = 0; n_small = 0; E0 = 0.0;
     // residual of the start point; afterwards the accepted trial of the line search is the next iteration's evaluation
     // (sq in its mu = 0 form: it serves E_0 and, for any mu, the line search's ||F_mu||)
-    ResAcc r0;
+    ResAcc &r0 = sd.racc[0], &rt = sd.racc[1];       // (in LDS: eval_residual<false> writes the first, <true> the second)
     PT_END(6)
     PT_BEGIN
-    eval_residual<false>(s, sd, 0.0, 0.0, 0.0, lane, r0);
+    eval_residual<false>(s, sd, 0.0, 0.0, 0.0, lane);
     PT_END(0)
     if (SHARED) shared_fold(*gsync, r0, sd.tfbar, b_tf2, gs, gz, 0.0, lane);
-    for (int iter = 0;; ++iter) {
+    int &iter = sd.dv.iter;
+    for (iter = 0;; ++iter) {
         it_count = iter;
-        E0 = scaled_error_n(r0, nzc, nlc, 0.0);
+        E0 = uni(scaled_error_n(r0, nzc, nlc, 0.0));
         if (SHARED && gsync->aborted) { status = MPCX_ST_NUMERIC; break; }
         if (!(E0 == E0) || !(E0 < 1e300)) { status = MPCX_ST_NUMERIC; break; }
         if (E0 <= o.tol) { status = MPCX_ST_OK; break; }
@@ -309,25 +320,28 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         if (n_acc >= o.acc_iter) { status = MPCX_ST_ACCEPTABLE; break; }
         if (iter >= o.max_iter) { status = (E0 <= o.acc_tol) ? MPCX_ST_ACCEPTABLE : MPCX_ST_MAXITER; break; }
         // adaptive barrier parameter: a fixed fraction of the iterate's mean complementarity ("Solver algorithm")
-        const double mu_cur = r0.prod_sum / (double)nzc;
+        double &mu_cur = sd.dv.mu_cur;
+        mu_cur = uni(r0.prod_sum / (double)nzc);
         if (!mono && n_small >= kFbN) {
-            mono = true;
-            mu = fmax(o.tol / 10.0, fmin(kMuInit, kFbBoost * mu_cur));
+            mono = 1;
+            mu = uni(fmax(o.tol / 10.0, fmin(kMuInit, kFbBoost * mu_cur)));
         }
         // (never below kMuErr * E_0: the mean complementarity may collapse while the iterate is still infeasible)
-        if (!mono) mu = fmax(fmax(clean ? fmin(kSigma * mu_cur, mu_cur * sqrt(mu_cur)) : kSigma * mu_cur, o.tol / 10.0), kMuErr * E0);
+        if (!mono) mu = uni(fmax(fmax(clean ? fmin(kSigma * mu_cur, mu_cur * sqrt(mu_cur)) : kSigma * mu_cur, o.tol / 10.0), kMuErr * E0));
         else {
             // mu moves on only when the barrier problem is solved to E_mu <= 10 mu: mu <- max(tol/10, min(0.2 mu, mu^1.5))
             for (int lv = 0; lv < 64 && mu > o.tol / 10.0 && scaled_error_n(r0, nzc, nlc, mu) <= 10.0 * mu; ++lv)
-                mu = fmax(o.tol / 10.0, fmin(0.2 * mu, mu * sqrt(mu)));
+                mu = uni(fmax(o.tol / 10.0, fmin(0.2 * mu, mu * sqrt(mu))));
         }
         // Newton direction, with Hessian regularisation retries on breakdown
-        bool have_dir = false;
-        double delta_w = 0.0, alpha = 1.0;
+        int &have_dir = sd.dv.have_dir;
+        double &delta_w = sd.dv.delta_w, &alpha = sd.dv.alpha;
+        have_dir = 0; delta_w = 0.0; alpha = 1.0;
 #ifdef MPCX_ITER_LOG
         int fail_mask = 0;     // decimal digits: factor, border, finite-check failures of this iteration
 #endif
-        const double tau = fmax(0.99, 1.0 - mu);
+        double &tau = sd.dv.tau;
+        tau = uni(fmax(0.99, 1.0 - mu));
         // Hessian regularisation on breakdown follows ipopt's inertia-correction schedule: 0 first, then a third of
         // the last value that worked (1e-4 the first time), growing by 8 (by 100 until some value has worked), up to 1e40
         while (!have_dir && delta_w <= kDwMax) {
@@ -339,8 +353,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             if (ns_kept) newton_blocks<true>(s, sd, (double *)&w, mu, delta_w, lane);
             else newton_blocks<false>(s, sd, (double *)&w, mu, delta_w, lane);
             PT_END(1)
-            double gtf_rhs, rvt_rhs, gex[NTERM];
-            first_rhs_scalars(sd, gtf_rhs, rvt_rhs, gex);    // (the node records of the first right-hand side: newton_blocks)
+            first_rhs_scalars(sd);    // (sd.rs_*; the node records of the first right-hand side: newton_blocks)
 #ifndef MPCX_TP                 // (the shared-tf launch has its own kernel, solve.hip)
             if (SHARED) {
                 // ---- the same direction computation in lock step with the other satellites of the launch ----
@@ -365,19 +378,19 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 bool okl = riccati_factor(s, sd, w, lane, true, passes > 1);     // (a local breakdown is reported through the border's reduction)
                 bool ok = true;
                 for (int pass = 0; pass < passes && ok; ++pass) {
-                    if (okl && pass > 0) { reduced_residual(s, sd, (double *)&w, lane, gtf_rhs, rvt_rhs, gex); sweep_backward(s, sd, w, 0, 1, lane); }
+                    if (okl && pass > 0) { reduced_residual(s, sd, (double *)&w, lane); sweep_backward(s, sd, w, 0, 1, lane); }
                     if (okl) {
                         sweep_forward(s, sd, w, 0, (pass == 0) ? NCH : 1, lane);
                         if (pass == 0) okl = border_factor_shared(sd, lane);
                     }
                     const double dtf_cur = (pass == 0) ? 0.0 : s.drg[G_TF];
-                    ok = border_solve_shared(sd, g, gtf_rhs, rvt_rhs, gex, W_glob, -(g_glob + W_glob * dtf_cur), !okl, lane);
+                    ok = border_solve_shared(sd, g, W_glob, -(g_glob + W_glob * dtf_cur), !okl, lane);
                     if (!ok) break;
                     combine_channels(s, sd, (double *)&w, lane, pass == 0);
                 }
                 if (ok) {
-                    bool fin = true;
-                    alpha = finish_direction(s, sd, mu, tau, lane, fin);
+                    alpha = uni(finish_direction(s, sd, mu, tau, lane));
+                    const bool fin = sd.dir_finite != 0;
                     const double dtf = s.drg[G_TF];
                     const double dgv[2] = {-dtf, dtf};
 #pragma unroll
@@ -392,7 +405,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                     alpha = gr[GR_SUM + GR_MAX];
                     ok = (gr[0] == 0.0) && !g.aborted;
                 }
-                if (ok) have_dir = true;
+                if (ok) have_dir = 1;
                 else if (g.aborted) break;
                 else if (delta_w == 0.0) delta_w = (dw_last == 0.0) ? kDwFirst : fmax(kDwMin, dw_last / 3.0);
                 else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
@@ -423,7 +436,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                 for (int pass = 0; pass < passes && ok; ++pass) {
                     if (pass > 0) {
                         PT_BEGIN
-                        reduced_residual(s, sd, (double *)&w, lane, gtf_rhs, rvt_rhs, gex);
+                        reduced_residual(s, sd, (double *)&w, lane);
                         PT_END(5)
                     }
                     // pass 0: all 8 channels (right-hand side + the 7 border columns); refinement: channel 0 only
@@ -456,7 +469,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
                     if (!ok) break;
                     PT_BEGIN
-                    border_solve(sd, gtf_rhs, rvt_rhs, gex, lane);
+                    border_solve(sd, lane);
 #if defined(MPCX_ITER_LOG) && defined(MPCX_LOG_IT)
                     // diagnostic build only: the border system of one chosen iteration into this satellite's NU block
                     if (iter == MPCX_LOG_IT && pass == 0 && lane == 0) {
@@ -466,8 +479,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
                         for (int j = 0; j < NTERM; ++j) lg[n++] = sd.twin[j];
                         for (int j = 0; j < NCH; ++j) lg[n++] = sd.siglam[j];
                         for (int c = 0; c < NCH; ++c) for (int j = 0; j < 7; ++j) lg[n++] = sd.xK[c][j];
-                        lg[n++] = gtf_rhs; lg[n++] = rvt_rhs;
-                        for (int j = 0; j < NTERM; ++j) lg[n++] = gex[j];
+                        lg[n++] = sd.rs_gtf; lg[n++] = sd.rs_rvt;
+                        for (int j = 0; j < NTERM; ++j) lg[n++] = sd.rs_gex[j];
                         lg[n++] = sd.Wtf; lg[n++] = sd.gam; lg[n++] = delta_w;
                     }
 #endif
@@ -482,13 +495,14 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             if (ok) {
                 // dt, ds, dz, the fraction-to-the-boundary step and the finite check on the direction
                 PT_BEGIN
-                alpha = finish_direction(s, sd, mu, tau, lane, ok);
+                alpha = uni(finish_direction(s, sd, mu, tau, lane));
+                ok = sd.dir_finite != 0;
                 PT_END(8)
 #ifdef MPCX_ITER_LOG
                 if (!ok) fail_mask += 10000;
 #endif
             }
-            if (ok) have_dir = true;
+            if (ok) have_dir = 1;
             else if (delta_w == 0.0) delta_w = (dw_last == 0.0) ? kDwFirst : fmax(kDwMin, dw_last / 3.0);
             else delta_w *= (dw_last == 0.0) ? 100.0 : 8.0;
         }
@@ -501,11 +515,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         }
         // backtracking on ||F_mu||_2 with the N_-inf(gamma) neighbourhood
         // ||F_mu||^2 of the iterate from the mu = 0 evaluation: sum (s z - mu)^2 = sum (s z)^2 - 2 mu sum s z + n mu^2
-        const double rn0 = sqrt(fmax(0.0, r0.sq - 2.0 * mu * r0.prod_sum + (double)nzc * mu * mu));
+        double &rn0 = sd.dv.rn0;
+        rn0 = uni(sqrt(fmax(0.0, r0.sq - 2.0 * mu * r0.prod_sum + (double)nzc * mu * mu)));
         // every trial is evaluated as the iterate it would become (slack reset and multiplier safeguard applied) and
         // left in the second iterate buffer
-        const double mu_clip = fmax(mu, mu_cur);
-        ResAcc rt;
+        double &mu_clip = sd.dv.mu_clip;
+        mu_clip = uni(fmax(mu, mu_cur));
         // shared tf: the trial values of the range constraint's pairs (slack reset and multiplier safeguard like every
         // other pair), then the launch's residual from the satellites' (a reduction: every workgroup decides alike)
         auto shared_trial = [&]() {
@@ -518,11 +533,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             }
             shared_fold(*gsync, rt, tft, b_tf2, gst, gzt, mu, lane);
         };
-        bool have_trial = false;
-        for (int ls = 0; ls < 30; ++ls) {
+        int &have_trial = sd.dv.have_trial, &ls = sd.dv.ls;
+        have_trial = 0;
+        for (ls = 0; ls < 30; ++ls) {
             if (0.5 * alpha < kAlphaFloor) break;      // a rejection could not shorten the step any more: take it
             PT_BEGIN
-            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
+            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane);
             PT_END(10)
             if (SHARED) shared_trial();
             const bool dec = sqrt(rt.sq) <= (1.0 - 1e-4 * alpha) * rn0;
@@ -531,12 +547,12 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             // diagnostic build only: the first trial's margins into this satellite's U block
             if (ls == 0 && lane == 0 && 3 * iter + 2 < 3 * K) { double *lg = a.U + (size_t)sat * 3 * Kmax + 3 * iter; lg[0] = alpha; lg[1] = sqrt(rt.sq) / rn0; lg[2] = rt.prod_min / (kGammaNbhd * fmin(mu, rt.prod_sum / (double)nzc)); }
 #endif
-            if (dec && cen) { have_trial = true; break; }
-            alpha *= 0.5;
+            if (dec && cen) { have_trial = 1; break; }
+            alpha = uni(alpha * 0.5);
         }
         if (!have_trial) {                              // the step taken untested
             PT_BEGIN
-            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane, rt);
+            eval_residual<true>(s, sd, alpha, mu, mu_clip, lane);
             PT_END(9)
             if (SHARED) shared_trial();
         }
@@ -546,10 +562,16 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
         n_small = (alpha < kFbAlpha) ? n_small + 1 : 0;
         // accept: the candidate becomes the iterate, its residual (sq back in the mu = 0 form) the next iteration's
-        { wf64 *q = s.it; s.it = s.itB; s.itB = q; lf64 *g = s.itg; s.itg = s.itgB; s.itgB = g; }
+        if (lane == 0) { wf64 *q = s.it; s.it = s.itB; s.itB = q; lf64 *g = s.itg; s.itg = s.itgB; s.itgB = g; }
+        WG_SYNC();
         if (SHARED) { gs[0] = gst[0]; gs[1] = gst[1]; gz[0] = gzt[0]; gz[1] = gzt[1]; }
-        r0 = rt;
-        r0.sq = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;
+        {   // (both records are in LDS: the next iteration's evaluation is a copy of the accepted trial's, by the wave's first lanes)
+            const double sq0 = rt.sq + 2.0 * mu * rt.prod_sum - (double)nzc * mu * mu;
+            const ResAcc t = rt;
+            WG_SYNC();
+            r0 = t; r0.sq = sq0;
+            WG_SYNC();
+        }
     }
 
     // ---- results in the reference's shapes: X (7,K), U (3,K), NU (7,K) ----

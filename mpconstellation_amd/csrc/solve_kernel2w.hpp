@@ -6,7 +6,7 @@ namespace MPCX_NS {
 
 // Two waves per satellite.  The first runs solve_satellite exactly as the one-wave kernel's wave does; the second waits in a
 // command loop and joins it for every factorisation (riccati_factor2).  Same work queue, same slot workspaces.
-__global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void MPCX_KERNEL2W_NAME(SolveArgs a)
+__global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) MPCX_NO_TAIL void MPCX_KERNEL2W_NAME(SolveArgs a)
 {
     SatData &sd = g_sd;
     Scratch &w = g_w;
@@ -25,11 +25,8 @@ __global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void MPCX_KERNEL2W_NAME(Solv
             if (lane == 0) w.cmd = CMD_EXIT;
             WG_BARRIER();
         } else {
-            const int Kmax = a.K;
-            int K = a.Ks ? a.Ks[sat] : Kmax;
-            if (K < 3 || K > Kmax) K = Kmax;                       // (the first wave reports MPCX_ST_BADK and sends CMD_EXIT at once)
-            const Sat s = sat_view(a, sat, (int)blockIdx.x, K, Kmax);
-            for (;;) {
+            const Sat &s = g_s;                                    // (written by the first wave before its first command; a satellite
+            for (;;) {                                             //  refused as MPCX_ST_BADK sends CMD_EXIT at once)
                 WG_BARRIER();
                 if (w.cmd == CMD_EXIT) break;
                 (void)riccati_factor2(s, sd, w, lane, 1, w.cmd_arg != 0);

@@ -10,6 +10,11 @@ using namespace mpcx;          // (the device helpers of mpcx_device.hpp, the la
 #endif
 
 // ---- per-satellite constant data kept in LDS --------------------------------------------
+struct ResAcc {   // accumulators of one residual evaluation
+    double dual_max, prim_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
+    double g_tf;      // the satellite's term of the tf stationarity row, 2 w_tr (tf - tf_bar) - sum_k Sigma_k . lam_k
+};
+
 struct SatData {
     double aT[8][7], bT[8];
     int nT, linvt;           // terminal inequality rows (6, or 8 with the linearised tangential pair); convex variant flag
@@ -35,6 +40,20 @@ struct SatData {
     // one row at a time in loops the compiler cannot batch (a store to itgB between two loads of itg): seven dependent memory
     // round trips per trial evaluation and per step-limit pass, which is what those phases waited for under load.
     double gl[3][GL_N];
+    // What the phases hand back to the driver (round 5: here, in LDS; they were reference parameters into the driver's stack --
+    // flat stores in the phase functions, scratch reloads in the driver): the residual evaluation of the iterate ([0]) and of
+    // the line search's trial ([1]); the scalars of a right-hand side (first_rhs_scalars / reduced_residual -> border_solve);
+    // the finite flag of finish_direction.
+    ResAcc racc[2];
+    double rs_gtf, rs_rvt, rs_gex[NTERM];
+    int dir_finite;
+    // ... and the driver's own loop state (solve_satellite): every lane holds the same values, and as local variables they lived
+    // in vector registers, which every phase function clobbers -- a scratch store before and a scratch load behind each call.
+    // Here a call costs them nothing and a use is an LDS read.
+    struct Drv {
+        double mu, dw_last, E0, delta_w, alpha, tau, mu_cur, rn0, mu_clip;
+        int n_acc, status, it_count, n_reg, first_reg, mono, refined_prev, n_small, iter, have_dir, have_trial, clean, ls;
+    } dv;
     double infeas;           // > 0: the constraint set is empty whatever the dynamics (structural_violation)
     int flag;
 #ifdef MPCX_PHASE_TIMING
@@ -88,6 +107,17 @@ __device__ __forceinline__ void wsync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// A value that is the same in all 64 lanes, moved to scalar registers (two v_readfirstlane for a double).  The driver of a solve
+// (solve_satellite) keeps its loop state -- mu, step length, error, counters -- across the calls of the phase functions, which
+// clobber every vector register: as vector values each of them is a scratch store before a call and a scratch load behind it.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // 1/d for d > 0 well inside the normal range: hardware seed + two Newton steps (the full IEEE division sequence
@@ -429,10 +459,6 @@ __device__ __forceinline__ double trial_value(const Col<wf64> &p, const Col<wf64
     return fma(a, z ? 0.0 : dv, pv);
 }
 
-struct ResAcc {   // accumulators of one residual evaluation
-    double dual_max, prim_max, sq, zsum, lsum, prod_min, prod_max, prod_sum;
-    double g_tf;      // the satellite's term of the tf stationarity row, 2 w_tr (tf - tf_bar) - sum_k Sigma_k . lam_k
-};
 
 // The node-parallel phases are written as chunks "loads -> arithmetic (-> stores)" separated by scheduling
 // barriers: a chunk's loads are all in flight together (one memory latency per chunk instead of one per access,
@@ -454,8 +480,9 @@ struct ResAcc {   // accumulators of one residual evaluation
 // iterate buffer (s.itB, s.itgB): accepting the trial is a swap of the two buffers, and its residual is the next
 // iteration's.
 template <bool WRITE>
-__device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, double mu_clip, int lane, ResAcc &out)
+__device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, double mu, double mu_clip, int lane)
 {
+    ResAcc &out = sd.racc[WRITE ? 1 : 0];          // (the start point's evaluation: [0]; a trial's: [1])
 #define POST(sv, zv, gval) { sv = fmax(sv, -(gval)); zv = fmin(zv, kKappaSigma * (mu_clip * rcp_pos(sv))); }
     const int K = s.K;
     double dual = 0.0, prim = 0.0, sq = 0.0, zsum = 0.0, lsum = 0.0, pmin = 1e300, pmax = -1e300, psum = 0.0;
@@ -684,7 +711,7 @@ __device__ __noinline__ void eval_residual(const Sat &s, SatData &sd, double a, 
     out.dual_max = wave_max(dual); out.prim_max = wave_max(prim);
     out.sq = wave_sum(sq); out.zsum = wave_sum(zsum); out.lsum = wave_sum(lsum);
     out.prod_min = wave_min(pmin); out.prod_max = wave_max(pmax); out.prod_sum = wave_sum(psum);
-    if (WRITE) WG_SYNC();            // the candidate iterate is complete before anybody reads it
+    WG_SYNC();                       // the candidate iterate (WRITE) and the record are complete before anybody reads them
 }
 
 __device__ __forceinline__ int n_ineq(int K, int nT, int fixed_tf) { return K + (K - 1) + (K - 2) + nT + 1 + 14 * (K - 1) + (fixed_tf ? 0 : 2); }
@@ -1074,8 +1101,9 @@ __device__ __noinline__ void combine_channels(const Sat &s_in, SatData &sd, doub
 // stg: LDS staging area (the recursion's scratch, idle here) of 64 right-hand-side records: they leave as coalesced blocks
 // (straight from the node lanes they were 24 eight-byte stores per node, each to its own cache line: this phase was as long
 // as a factorisation on problems that refine in most iterations -- the stiff terminal windows of OptimalController's options).
-__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double *stg, int lane, double &gtf_rhs, double &rvt_rhs, double *gex)
+__device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double *stg, int lane)
 {
+    double rvt_rhs, gex[NTERM];      // (-> sd.rs_rvt, sd.rs_gex at the end; sd.rs_gtf)
     const int K = s.K;
     double gtf_part = 0.0;
     const double dtf = s.drg[G_TF];
@@ -1307,27 +1335,31 @@ __device__ __noinline__ void reduced_residual(const Sat &s, SatData &sd, double 
       }
       WG_SYNC();
     }
-    gtf_rhs = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
+    sd.rs_gtf = sd.gtf + sd.Wtf * dtf + wave_sum(gtf_part);
+    sd.rs_rvt = rvt_rhs;
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) sd.rs_gex[t] = gex[t];
     WG_SYNC();
 }
 
 // Right-hand side of the first solve of an iteration: direction 0, total multipliers 0, i.e. the Newton blocks
 // themselves (what reduced_residual returns for d = (0, -lam, -lam_vt)).  Lane k writes node k's record.
-__device__ __forceinline__ void first_rhs_scalars(const SatData &sd, double &gtf_rhs, double &rvt_rhs, double *gex)
+__device__ __forceinline__ void first_rhs_scalars(SatData &sd)
 {
-    gtf_rhs = sd.gtf;
-    rvt_rhs = sd.linvt ? -sd.gh_vt / sd.w_vt : -sd.cv;       // (convex variant: the pair's zeta row at the zero direction)
+    sd.rs_gtf = sd.gtf;
+    sd.rs_rvt = sd.linvt ? -sd.gh_vt / sd.w_vt : -sd.cv;       // (convex variant: the pair's zeta row at the zero direction)
     for (int t = 0; t < NTERM; ++t) {
         const double share = (sd.tw[t] > 0.0) ? sd.twin[t] / sd.tw[t] : 1.0;
-        gex[t] = sd.tgh[t] * (1.0 - share);         // = wex * gh / w: the zeta row's residual at the zero direction, times wex
+        sd.rs_gex[t] = sd.tgh[t] * (1.0 - share);         // = wex * gh / w: the zeta row's residual at the zero direction, times wex
     }
+    wsync();
 }
 
 // The fraction-to-the-boundary step of the direction and the finite check on it.  The directions of the eliminated pairs
 // (dt, ds, dz by back-substitution: pair_dir, l1_dir) are formed here only to be measured against their variables; they are
 // not stored -- every trial evaluation forms them again (eval_residual).  The handful of terminal / tf pairs live in the
 // global part of the direction record, as before.
-__device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane, bool &finite)
+__device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, double mu, double tau, int lane)
 {
     const int K = s.K;
     double amax = 1.0, bad = 0.0;
@@ -1428,7 +1460,7 @@ __device__ __noinline__ double finish_direction(const Sat &s, SatData &sd, doubl
 #undef LIM
 #undef CHK
     amax = wave_min(amax);
-    finite = (wave_max(bad) == 0.0);
+    sd.dir_finite = (wave_max(bad) == 0.0) ? 1 : 0;
     WG_SYNC();
     return amax;
 }

@@ -228,7 +228,7 @@ __device__ __noinline__ void stiff_stage_update(StageOps &o, Scratch &w, double 
 // segment that is not the last: group 0 the dtf channel, groups 1..7 the unit prices e_0..e_6 on the state behind node hi-1; its
 // ninth channel, the right-hand side, rides in the lanes of group 0 a second time (results in the extra record chx).
 struct TpRange { int lo, hi; bool last; double *Wout; };
-#define RF_ARGS , const TpRange &rg
+#define RF_ARGS , const TpRange rg          /* (by value: four scalars in registers; by reference they were flat loads from the caller's stack) */
 #define RF_HI rg.hi
 #define RF_LO rg.lo
 #define RF_LAST rg.last
@@ -1248,8 +1248,10 @@ __device__ __noinline__ bool border_factor(SatData &sd, int lane)
 // Right-hand side of the border system from channel 0, then L D L^T solve with the stored factors and one step of
 // iterative refinement against the matrix itself (every lane, in registers); sd.sol in channel order (dtf, vt
 // multiplier, zeta_1..5).
-__device__ __noinline__ void border_solve(SatData &sd, double gtf_rhs, double rvt_rhs, const double *gex, int lane)
+__device__ __noinline__ void border_solve(SatData &sd, int lane)
 {
+    const double gtf_rhs = sd.rs_gtf, rvt_rhs = sd.rs_rvt;
+    const double *gex = sd.rs_gex;
     double rb[NBD], x[NBD], r[NBD];
 #pragma unroll
     for (int p = 0; p < NBD - 1; ++p) {
@@ -1439,9 +1441,10 @@ __device__ __noinline__ bool border_factor_shared(SatData &sd, int lane)
 // iterative refinement of the whole bordered system, its tf row again summed across the launch.  `fail`: this satellite
 // cannot contribute (breakdown upstream).  Returns false -- on every workgroup alike -- if any satellite failed or the
 // launch's tf pivot is not positive (wrong inertia: regularise).
-__device__ __noinline__ bool border_solve_shared(SatData &sd, GridSync &g, double gtf_share, double rvt_rhs, const double *gex,
-                                                 double W_glob, double r_glob, bool fail, int lane)
+__device__ __noinline__ bool border_solve_shared(SatData &sd, GridSync &g, double W_glob, double r_glob, bool fail, int lane)
 {
+    const double gtf_share = sd.rs_gtf, rvt_rhs = sd.rs_rvt;
+    const double *gex = sd.rs_gex;
     double rb[NBD], v[NBD], x[NBD];
 #pragma unroll
     for (int p = 0; p < NBD - 1; ++p) {

@@ -14,7 +14,7 @@ namespace MPCX_NS {
 // One workgroup of two waves per segment, TP_MAXSEG consecutive workgroups per satellite (a cooperative launch: they wait for
 // each other).  The LAST segment's workgroup is the satellite's first: its first wave runs solve_satellite as in every build
 // and sends the others their commands through the mailbox, its second wave follows through LDS as in the two-wave kernel.
-__global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel_tp(SolveArgs a)
+__global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) MPCX_NO_TAIL void solve_kernel_tp(SolveArgs a)
 {
     SatData &sd = g_sd;
     TpData &tp = g_tp;
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(128, MPCX_SOLVE_WAVES) void solve_kernel_tp(SolveAr
     const int nseg = tp_segments(K);
     if (pair >= nseg) return;
     const int j = nseg - 1 - pair;                          // this workgroup's segment
-    const Sat s = sat_view(a, sat, sat, K, Kmax);
-    if (threadIdx.x == 0) { tp_geometry(tp, K); tp.seq = 0; tp.dead = 0; tp.light = 0; }
+    if (threadIdx.x == 0) { g_s = sat_view(a, sat, sat, K, Kmax); tp_geometry(tp, K); tp.seq = 0; tp.dead = 0; tp.light = 0; }
     WG_BARRIER();
+    const Sat &s = g_s;
 #ifdef MPCX_TP_DEBUG
     if (threadIdx.x == 0) printf("[b%d] sat %d pair %d seg %d of %d K %d mail %d %d %d %d\n", (int)blockIdx.x, sat, pair, j, nseg, K, s.mail[0], s.mail[1], s.mail[2], s.mail[3]);
 #endif

@@ -56,6 +56,7 @@ static_assert(sizeof(TpXch) <= TP_XCH_N * sizeof(double), "exchange record");
 
 __shared__ SatData g_sd;
 __shared__ Scratch g_w;
+__shared__ Sat g_s;                      // (the view of the satellite's problem and workspace: solve_driver.hpp)
 __shared__ TpData g_tp;
 
 // mailbox of a satellite's workgroups (ints in global memory, zeroed by the host before the launch)
@@ -266,8 +267,12 @@ __device__ __forceinline__ bool tp_ldl7(const double *M, double (&m)[28])
 //            the cut in the early iterations -- the sequential recursion does not ask for it either: it asks for D + P > 0):
 //            N = C C' (N contains D^-1 of the segment's last node: positive definite),  S = I + C'What C ,  z = C S^-1 C^-1 r .
 // S positive definite is the cut's share of the recursion's pivot test (N^-1 + What > 0); false = breakdown, regularised by delta_w.
-__device__ __noinline__ bool tp_iface_factor(TpSeg &sj, const double *Wn, TpData &tp, int lane)
+__device__ __noinline__ bool tp_iface_factor(TpData &tp, int j, int lane)
 {
+    // (the segment's record and What_{j+1} addressed from tp, an LDS object at a known address: as reference / pointer
+    //  parameters they were generic pointers, and the 100 accesses of this function flat loads and stores)
+    TpSeg &sj = tp.seg[j];
+    const double *Wn = tp.seg[j + 1].What;
     double m[28];
     const int a = (lane < 49) ? lane / 7 : 0, b = (lane < 49) ? lane - 7 * (lane / 7) : 0;
     bool ok = true;
@@ -424,7 +429,7 @@ __device__ __noinline__ bool tp_coarse(const Sat &s, SatData &sd, TpData &tp, in
         for (int j = last - 1; j >= 0; --j) {
             TpSeg &sj = tp.seg[j];
             const double *Wn = tp.seg[j + 1].What;
-            if (!tp_iface_factor(sj, Wn, tp, lane)) ok = false;
+            if (!tp_iface_factor(tp, j, lane)) ok = false;
             // E column by column (lane i < 7 its column of the identity)
             {
                 double col[7];
