@@ -83,6 +83,10 @@ __global__ __launch_bounds__(64, MPCX_SOLVE_WAVES) MPCX_NO_TAIL void solve_kerne
     Scratch &w = g_w;
     __shared__ int next_item;
     const int lane = threadIdx.x;
+#ifdef MPCX_LDS_PAD       // occupancy experiments only (profiles/r05/occupancy_sweep.txt): LDS the kernel does not use, to hold fewer workgroups per compute unit
+    __shared__ double lds_pad[MPCX_LDS_PAD / 8];
+    if (a.S < 0) { lds_pad[lane] = 1.0; __syncthreads(); a.kkt[0] = lds_pad[63 - lane]; }
+#endif
     for (;;) {
         if (lane == 0) next_item = atomicAdd(a.counter, 1);
         __syncthreads();
