@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/r5l; mkdir -p $OUT
+OUT=gpurun_out/${RUN:-r5n}; mkdir -p $OUT
 timeout -k 10 1100 python -m pytest tests -m gpu -q -x --durations=8 > $OUT/pytest.log 2>&1; rc=$?
 tail -16 $OUT/pytest.log
 if [ $rc -ge 124 ]; then echo "pytest killed ($rc)"; exit $rc; fi
