@@ -174,6 +174,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
 #endif
     }
     WG_SYNC();
+    PT_END(11)                      // (timing build: the start-up in three parts -- terms | transposition | start point)
+    PT_BEGIN
     double gr[GR_N];                // (shared tf: operands / results of the launch-wide reductions)
     if (SHARED) {
         // the launch is ONE problem: empty if any satellite's constraint set is, or tf's own range (which build_terminal
@@ -197,6 +199,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
     // field-major copy of the stage records for the node-parallel phases (read every iteration, written once): 16 records
     // at a time through LDS -- read as one contiguous block, written field by field with 16 consecutive nodes in
     // consecutive lanes (straight from the record order it was an 8-byte store per cache line)
+    // (round 5: the next block's loads issued before a block's stores and wave-level fences in place of the barriers -- one memory
+    //  round trip instead of four -- changes nothing under load, 4.85 / 4.87 ms at S4096_K30: profiles/r05/streaming_phases_ab.txt)
     {
         double *stg = (double *)&w;
         static_assert(sizeof(Scratch) >= 16 * MPCX_STAGE_DOUBLES * sizeof(double), "stage transposition buffer");
@@ -212,6 +216,8 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
             WG_SYNC();
         }
     }
+    PT_END(9)
+    PT_BEGIN
     bool pushed = false;
     for (int k = lane; k < K; k += 64) {
         double x[7], u[3];
@@ -553,7 +559,7 @@ __device__ __forceinline__ void solve_satellite(const SolveArgs &a, const int sa
         if (!have_trial) {                              // the step taken untested
             PT_BEGIN
             eval_residual<true>(s, sd, alpha, mu, mu_clip, lane);
-            PT_END(9)
+            PT_END(10)
             if (SHARED) shared_trial();
         }
 #ifdef MPCX_ITER_LOG

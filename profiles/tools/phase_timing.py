@@ -38,7 +38,7 @@ r = solve_batch(*args, options=opts, flags=flags)
 t0 = time.perf_counter(); r = solve_batch(*args, options=opts, flags=flags); wall = time.perf_counter() - t0
 print(f"S {S}: host-pointer solve_batch wall {wall*1e3:.3f} ms (copies of {S*30*17*8/1e6:.1f} MB results included)")
 names = ["eval_res(E0,Emu,r0)", "newton_blocks", "riccati_factor", "sweep_bwd 8ch", "sweep_fwd 8ch+border", "reduced_residual",
-         "start-up (terms, transposition, start point)", "border_solve+comb fwd", "finish_direction", "apply_step", "line-search evals", "-"]
+         "start-up: start point", "border_solve+comb fwd", "finish_direction", "start-up: stage transposition", "line-search evals", "start-up: terms (lane 0)"]
 t = r.NU[0].ravel()[:24].reshape(12, 2)
 tot = t[:, 0].sum()
 rt, mt = r.NU[0].ravel()[40:42]
