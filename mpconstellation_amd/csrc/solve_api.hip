@@ -415,10 +415,11 @@ extern "C" int mpcx_mpc_update_batch(mpcx_ctx *ctx, int S, int K, int n_scp, dou
     char *wsb = (char *)ctx_workspace(ctx, ws_bytes[0] + ws_bytes[1]);
     if (!wsb) return MPCX_E_NOMEM;
     if (split && !ctx->stream2) {
+        // (the stream last: a call that failed half-way through these leaves stream2 null and the next call completes the set)
+        if (!ctx->ev_fork) MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        if (!ctx->ev_join) MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        if (!ctx->ev_stagger) MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger, hipEventDisableTiming));
         MPCX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        MPCX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger, hipEventDisableTiming));
     }
     DeviceArena ar(ctx);
     double *dy0 = ar.upload(y0, (size_t)S * 7), *dtf0 = ar.upload(tf0, S), *dc = ar.upload(consts, (size_t)S * MPCX_NCONST), *drd = ar.upload(r_des, S);
