@@ -47,6 +47,16 @@ struct StageOps {
 };
 constexpr int OPS_IN = 91 + 49 + 9 + 7 + SX_N;   // A 49 | Bn 21 | Bpm 21 | Wx 49 (expanded) | Wu 9 | D 7 | SX 8
 
+// Wave priority of the factorisation (s_setprio; 0 = off).  Two waves share a SIMD; when one is inside the recursion -- a chain of
+// dependent fp64 / LDS steps, where every lost issue slot lengthens the critical path -- and the other in a node-parallel phase --
+// independent loads and arithmetic that fill any slot -- the arbiter should prefer the first.  Measured (profiles/r05/
+// occupancy_sweep.txt, three alternating rounds on one box, bit-identical): S8192_K30 9.63 -> 9.43 ms, S4096_K100 12.06 -> 11.97,
+// S4096_K30 4.85 -> 4.86 (its 2 x 2048 satellites start in lock step: the SIMD's two waves are in the same phase most of the time);
+// the sweeps and the border solve at the same priority add nothing, a higher priority for the node-parallel phases or for one
+// wave slot of every SIMD loses.
+#ifndef MPCX_PRIO_RIC
+#define MPCX_PRIO_RIC 3
+#endif
 struct Scratch {   // LDS working set of the recursion (and, between recursions, the staging area of newton_blocks)
     union {                        // the factorisation and the stand-alone sweeps never run at the same time
 #ifdef MPCX_TWO_WAVE
@@ -622,6 +632,7 @@ __device__ __forceinline__ bool riccati_factor(const Sat &s, SatData &sd, Scratc
 // right after its matrices, while they are still in LDS (same arithmetic as sweep_backward).
 __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratch &w, int lane, bool fuse_sweep, bool keep_pt)
 {
+    if (MPCX_PRIO_RIC) __builtin_amdgcn_s_setprio(MPCX_PRIO_RIC);
     const Sat s = uniform_view(s_in);   // private copy: scalar registers, not re-read after every LDS fence
     const int K = s.K;
     bool good = true;
@@ -934,6 +945,7 @@ __device__ __noinline__ bool riccati_factor(const Sat &s_in, SatData &sd, Scratc
         sweep_store(0, sw_p, sw_qu);
     }
     WG_SYNC();
+    if (MPCX_PRIO_RIC) __builtin_amdgcn_s_setprio(0);
     return __all(good);
 }
 
