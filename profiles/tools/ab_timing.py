@@ -11,7 +11,10 @@ sys.path.insert(0, "%s")
 from mpconstellation_amd import _ffi
 _ffi.LIB_PATH = "%s"
 import torch, bench
+import re
 for wl in %r:
+    if wl not in bench.WORKLOADS:          # any S<satellites>_K<nodes>
+        m = re.fullmatch(r"S(\\d+)_K(\\d+)", wl); bench.WORKLOADS[wl] = (int(m.group(1)), int(m.group(2)), 1)
     r = bench.Runner(wl, 0, 1, 0)
     r.opts.flags = int(__import__("os").environ.get("SOLVE_FLAGS", "0"))      # (64: the time-parallel kernel)
     best = 1e9
