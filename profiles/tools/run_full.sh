@@ -1,4 +1,5 @@
 #!/bin/bash
+# the round-end check in one gpurun call: the whole GPU suite, then the default bench line (RUN=<name>: output under gpurun_out/<name>/)
 OUT=gpurun_out/${RUN:-r5n}; mkdir -p $OUT
 timeout -k 10 1100 python -m pytest tests -m gpu -q -x --durations=8 > $OUT/pytest.log 2>&1; rc=$?
 tail -16 $OUT/pytest.log
